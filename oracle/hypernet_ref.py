@@ -1,0 +1,192 @@
+"""numpy fp32 oracle of the ZeTT hypernetwork forward (as-written math).
+
+TEST INFRASTRUCTURE — see oracle/__init__.py.  Never imported by zett_amd/.
+
+Every padded position is computed, every (row, position) runs the input
+projection, every position runs the last encoder layer: this is the
+reference's arithmetic, not the optimised schedule the HIP path uses, so that a
+disagreement between the two points at the HIP path.
+
+Weights are a dict of numpy arrays under the reference checkpoint names
+(reference scripts/convert_to_pt.py:35-49).  All Linear weights
+are torch-layout ``[out, in]``.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+try:  # scipy is present on both boxes; keep a slow fallback anyway
+    from scipy.special import erf as _erf
+except Exception:  # pragma: no cover
+    _erf = np.vectorize(math.erf, otypes=[np.float32])
+
+F32 = np.float32
+ROBERTA_LN_EPS = 1e-5      # roberta-base layer_norm_eps, modeling_hypernet.py:67-69
+PROJECTOR_LN_EPS = 1e-6    # modeling_hypernet.py:34
+
+
+def _cfg(cfg, name, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    return getattr(cfg, name, default)
+
+
+def linear(x, w, b):
+    """torch.nn.Linear: x @ w.T + b (fp32)."""
+    return (x @ w.T + b).astype(F32, copy=False)
+
+
+def gelu_tanh(x):
+    """F.gelu(approximate="tanh") — modeling_hypernet.py:36-39."""
+    x = x.astype(F32, copy=False)
+    c = F32(math.sqrt(2.0 / math.pi))
+    inner = c * (x + F32(0.044715) * x * x * x)
+    return (F32(0.5) * x * (F32(1.0) + np.tanh(inner))).astype(F32, copy=False)
+
+
+def gelu_erf(x):
+    """hidden_act="gelu" of RobertaIntermediate (exact erf form)."""
+    x = x.astype(F32, copy=False)
+    return (x * F32(0.5) * (F32(1.0) + _erf(x / F32(math.sqrt(2.0))).astype(F32))).astype(F32, copy=False)
+
+
+def layer_norm(x, w, b, eps):
+    """torch.nn.LayerNorm over the last axis (biased variance)."""
+    x = x.astype(F32, copy=False)
+    mu = x.mean(axis=-1, keepdims=True, dtype=F32)
+    xc = x - mu
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=F32)
+    return (xc / np.sqrt(var + F32(eps)) * w + b).astype(F32, copy=False)
+
+
+def projector_block(x, W, prefix):
+    """ProjectorBlock.__call__ — modeling_hypernet.py:22-40."""
+    h = gelu_tanh(linear(x, W[prefix + "dense1.weight"], W[prefix + "dense1.bias"]))
+    h = gelu_tanh(linear(h, W[prefix + "dense2.weight"], W[prefix + "dense2.bias"]))
+    return layer_norm(h + x, W[prefix + "ln.weight"], W[prefix + "ln.bias"], PROJECTOR_LN_EPS)
+
+
+def embed_inputs(W, cfg, ids, source_embeddings):
+    """A2 + A3: id split, gather, in_scaler, fallback select.
+
+    modeling_hypernet.py:170-188.
+    """
+    v0 = int(_cfg(cfg, "original_vocab_size"))
+    use_fallback = ids >= v0
+    main_ids = np.minimum(ids, v0 - 1)
+    fallback_ids = np.maximum(ids - v0, 0)
+    # F.embedding on an fp16/bf16 table is upcast by the next fp32 op (SURVEY §3.2 :179)
+    src = np.asarray(source_embeddings)[main_ids].astype(F32)
+    if _cfg(cfg, "hn_rescale_embeddings", False):
+        src = W["in_scaler.w"].reshape(-1) * src + W["in_scaler.b"].reshape(-1)
+    fb = W["fallback_embeddings.weight"][fallback_ids]
+    return np.where(use_fallback[..., None], fb, src).astype(F32)
+
+
+def roberta_encoder(W, cfg, x, key_mask):
+    """RobertaModel(inputs_embeds, attention_mask, position_ids=arange) in eval mode.
+
+    Mirrors the installed transformers ``RobertaEmbeddings.forward`` /
+    ``eager_attention_forward`` / ``RobertaSelfOutput`` / ``RobertaIntermediate`` /
+    ``RobertaOutput`` as called at modeling_hypernet.py:220-229.  ``key_mask`` is
+    ``ids != pad`` (plus the always-visible language token).  The additive mask is
+    ``finfo(float32).min`` on masked keys, so a row whose keys are ALL masked gets
+    uniform attention over every position (eager / Flax semantics).
+    """
+    n, lp, hdim = x.shape
+    heads = int(_cfg(cfg, "hn_num_attention_heads") or hdim // 64)
+    d = hdim // heads
+    p = "model.embeddings."
+    emb = x + W[p + "token_type_embeddings.weight"][0]
+    emb = emb + W[p + "position_embeddings.weight"][np.arange(lp)]
+    z = layer_norm(emb, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], ROBERTA_LN_EPS)
+
+    bias = np.where(key_mask, F32(0.0), np.finfo(F32).min).astype(F32)[:, None, None, :]
+    scaling = F32(d ** -0.5)
+    for layer in range(int(_cfg(cfg, "hn_n_layers", 3))):
+        lpfx = f"model.encoder.layer.{layer}."
+        a = lpfx + "attention.self."
+        q = linear(z, W[a + "query.weight"], W[a + "query.bias"]).reshape(n, lp, heads, d).transpose(0, 2, 1, 3)
+        k = linear(z, W[a + "key.weight"], W[a + "key.bias"]).reshape(n, lp, heads, d).transpose(0, 2, 1, 3)
+        v = linear(z, W[a + "value.weight"], W[a + "value.bias"]).reshape(n, lp, heads, d).transpose(0, 2, 1, 3)
+        s = (q @ k.transpose(0, 1, 3, 2)).astype(F32) * scaling
+        s = s + bias
+        s = s - s.max(axis=-1, keepdims=True)
+        e = np.exp(s).astype(F32)
+        prob = e / e.sum(axis=-1, keepdims=True, dtype=F32)
+        ctx = (prob @ v).astype(F32).transpose(0, 2, 1, 3).reshape(n, lp, hdim)
+        o = lpfx + "attention.output."
+        z = layer_norm(linear(ctx, W[o + "dense.weight"], W[o + "dense.bias"]) + z,
+                       W[o + "LayerNorm.weight"], W[o + "LayerNorm.bias"], ROBERTA_LN_EPS)
+        inter = gelu_erf(linear(z, W[lpfx + "intermediate.dense.weight"], W[lpfx + "intermediate.dense.bias"]))
+        o = lpfx + "output."
+        z = layer_norm(linear(inter, W[o + "dense.weight"], W[o + "dense.bias"]) + z,
+                       W[o + "LayerNorm.weight"], W[o + "LayerNorm.bias"], ROBERTA_LN_EPS)
+    return z
+
+
+def forward(W, cfg, target_surface_forms, source_embeddings, lang_index=None):
+    """ZettHypernet.__call__ — modeling_hypernet.py:156-267.
+
+    Returns (pred_in [N,E], pred_out [N,E] | None, bias [N]) as fp32 numpy arrays.
+    """
+    if not _cfg(cfg, "hn_embed_using_source_embeddings", False):
+        raise NotImplementedError()          # modeling_hypernet.py:167-168
+    ids = np.asarray(target_surface_forms).astype(np.int64)
+    n, seq = ids.shape
+    e = int(_cfg(cfg, "n_embd"))
+    separate = bool(_cfg(cfg, "separate_out_embeddings", False))
+    pad = int(_cfg(cfg, "pad_token_id"))
+
+    x = embed_inputs(W, cfg, ids, source_embeddings)                      # :170-188
+    x = linear(x, W["input_projection.0.weight"], W["input_projection.0.bias"])
+    x = projector_block(x, W, "input_projection.1.")                      # :189
+    mask = ids != pad                                                     # :190
+
+    if _cfg(cfg, "hn_embed_lang_id", False):                              # :192-218
+        lang = W["lang_embeddings.weight"][int(lang_index)].astype(F32).copy()
+        lang = lang - (W["model.embeddings.token_type_embeddings.weight"][0]
+                       + W["model.embeddings.position_embeddings.weight"][seq])
+        x = np.concatenate([x, np.broadcast_to(lang[None, None, :], (n, 1, x.shape[-1]))], axis=1)
+        mask = np.concatenate([mask, np.ones((n, 1), dtype=bool)], axis=1)
+
+    hidden = roberta_encoder(W, cfg, x.astype(F32), mask)                 # :220-229
+    cls = hidden[:, 0]                                                    # :234
+
+    pred = linear(projector_block(cls, W, "output_projection.0."),
+                  W["output_projection.1.weight"], W["output_projection.1.bias"])
+    if _cfg(cfg, "hn_single_head", False):                                # :238-246
+        pred_in = pred[..., :e]
+        pred_out = pred[..., e:] if separate else None
+    else:
+        pred_in = pred
+        pred_out = None
+        if separate:                                                      # :248-252
+            pred_out = linear(projector_block(cls, W, "output_projection_out.0."),
+                              W["output_projection_out.1.weight"], W["output_projection_out.1.bias"])
+    if _cfg(cfg, "hn_rescale_embeddings", False):                         # :254-258
+        pred_in = W["scaler.w"].reshape(-1) * pred_in + W["scaler.b"].reshape(-1)
+        if pred_out is not None:
+            pred_out = W["out_scaler.w"].reshape(-1) * pred_out + W["out_scaler.b"].reshape(-1)
+    if _cfg(cfg, "hn_predict_bias", False):                               # :260-265
+        bias = (cls @ W["bias_projection.weight"][0] + W["bias_projection.bias"][0]).astype(F32)
+    else:
+        bias = np.zeros((n,), dtype=F32)
+    return (pred_in.astype(F32), None if pred_out is None else pred_out.astype(F32), bias)
+
+
+def flops_per_row(cfg, seq):
+    """As-written algorithmic FLOPs per target row (SURVEY.md §8d F_ref)."""
+    e = int(_cfg(cfg, "n_embd"))
+    e_in = 2 * e if _cfg(cfg, "separate_out_embeddings", False) else e
+    h = int(_cfg(cfg, "hn_hidden_size"))
+    i = int(_cfg(cfg, "hn_intermediate_size"))
+    lp = seq + (1 if _cfg(cfg, "hn_embed_lang_id", False) else 0)
+    layers = int(_cfg(cfg, "hn_n_layers", 3))
+    heads_out = 1 if (_cfg(cfg, "hn_single_head", False) or not _cfg(cfg, "separate_out_embeddings", False)) else 2
+    e_out = e_in if _cfg(cfg, "hn_single_head", False) else e
+    return (seq * (2 * e_in * h + 4 * h * i)
+            + layers * (lp * (8 * h * h + 4 * h * i) + 4 * lp * lp * h)
+            + heads_out * (4 * h * i + 2 * h * e_out) + 2 * h)
