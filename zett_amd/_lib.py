@@ -1,0 +1,113 @@
+"""ctypes binding of libzett_hip.so (C ABI: include/zett_hip.h).
+
+The library is the product: if it cannot be loaded there is no fallback — the
+import of anything that computes raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from .build import LIB_PATH
+
+ZETT_OK = 0
+E_INVALID, E_HIP, E_STATE, E_INDEX, E_NOT_IMPLEMENTED, E_KEY = -1, -2, -3, -4, -5, -6
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+PREC_BF16, PREC_F32 = 0, 1
+RETOK_BPE, RETOK_UNIGRAM = 0, 1
+
+ABI_SYMBOLS = (
+    "zett_last_error", "zett_abi_version", "zett_create", "zett_destroy", "zett_load_weight",
+    "zett_finalize", "zett_forward", "zett_get_stats", "zett_set_option",
+    "zett_retok_create", "zett_retok_destroy", "zett_retokenize",
+)
+
+
+class ZettConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_embd", "n_in_embd", "hidden", "intermediate", "heads", "layers", "n_extra",
+        "original_vocab_size", "pad_token_id", "separate_out", "single_head", "rescale",
+        "predict_bias", "embed_lang", "n_langs", "max_positions")] + [
+        ("ln_eps_encoder", C.c_float), ("ln_eps_projector", C.c_float)]
+
+
+class ZettStats(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("packed_tokens", C.c_int64), ("distinct_ids", C.c_int64),
+                ("chunks", C.c_int64), ("executed_flops", C.c_double), ("gemm_ms", C.c_double),
+                ("gemm_launches", C.c_int64), ("gemm_flops_timed", C.c_double)]
+
+
+class ZettRetokModel(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("n_pieces", C.c_int32),
+        ("piece_bytes", C.c_void_p), ("piece_offsets", C.c_void_p), ("piece_ids", C.c_void_p),
+        ("piece_scores", C.c_void_p),
+        ("n_merges", C.c_int32), ("merges", C.c_void_p),
+        ("unk_id", C.c_int32), ("fuse_unk", C.c_int32), ("byte_fallback", C.c_int32),
+        ("byte_fallback_ids", C.c_void_p), ("ignore_merges", C.c_int32),
+        ("n_special", C.c_int32), ("special_bytes", C.c_void_p), ("special_offsets", C.c_void_p),
+        ("special_ids", C.c_void_p),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib_path() -> str:
+    return os.environ.get("ZETT_HIP_LIB", LIB_PATH)
+
+
+def load():
+    """dlopen the library (once) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: the HIP extension has not been built. Run "
+                "`python -m zett_amd.build` (needs hipcc); zett_amd has no CPU fallback.")
+        lib = C.CDLL(path)
+        lib.zett_last_error.restype = C.c_char_p
+        lib.zett_abi_version.restype = C.c_int
+        lib.zett_create.argtypes = [C.POINTER(ZettConfig), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.zett_destroy.argtypes = [C.c_void_p]
+        lib.zett_load_weight.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
+        lib.zett_finalize.argtypes = [C.c_void_p]
+        lib.zett_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_int64,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.zett_get_stats.argtypes = [C.c_void_p, C.POINTER(ZettStats)]
+        lib.zett_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        lib.zett_retok_create.argtypes = [C.POINTER(ZettRetokModel), C.c_int, C.POINTER(C.c_void_p)]
+        lib.zett_retok_destroy.argtypes = [C.c_void_p]
+        lib.zett_retokenize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]
+        for name in ABI_SYMBOLS:
+            fn = getattr(lib, name)
+            if name != "zett_last_error":
+                fn.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map a negative status to the exception the reference would raise."""
+    if rc == ZETT_OK:
+        return
+    msg = load().zett_last_error().decode("utf-8", "replace")
+    if what:
+        msg = f"{what}: {msg}"
+    if rc == E_INDEX:
+        raise IndexError(msg)
+    if rc == E_NOT_IMPLEMENTED:
+        raise NotImplementedError(msg)
+    if rc == E_KEY:
+        raise KeyError(msg)
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)

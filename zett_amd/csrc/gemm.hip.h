@@ -1,0 +1,260 @@
+// gemm.hip.h — MFMA GEMM for gfx950 (CDNA4) with a fused row-wise epilogue.
+//
+//   C[M,N] = epilogue( A[M,K] · W[N,K]ᵀ )
+//
+// Both operands are K-contiguous ("B-transposed" form: torch Linear weights are
+// stored [out,in] so no transposition is needed).  One kernel body serves both
+// arithmetic modes of the library:
+//   T = bf16  -> v_mfma_f32_32x32x16_bf16  (8 bf16 of K per lane and instruction)
+//   T = float -> v_mfma_f32_32x32x2_f32    (exact fp32; a 16-byte LDS chunk feeds 4
+//                instructions, the K permutation is the same for A and W)
+// The LDS image is identical in both modes: rows of 128 bytes of K, 16-byte chunks
+// XOR-swizzled by (row>>1)&7 so that a ds_read_b128 lane group (16 lanes, 16
+// distinct rows) touches 16 distinct 16-byte slots of the 256-byte bank row.
+//
+// Reduction order over K is fixed by the tile loop and never depends on M or on the
+// position of a row inside the launch, so one input row always produces bit-identical
+// output — the property the vocab-sharded multi-GPU path relies on.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zett {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+typedef uint16_t bf16_t;   // storage type of bf16 activations / weights
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round to nearest even, NaN kept quiet
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2 };
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {   // F.gelu(approximate="tanh")
+    const float c = 0.7978845608028654f;
+    float inner = c * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) {    // F.gelu (erf form)
+    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// Row-wise epilogue description (all pointers device, nullable unless noted).
+//   v = acc + bias[col]; v = act(v); v += residual[row, col]; v = scale[col]*v + shift[col]
+//   col <  split_col -> out_f32[row*ld_f32 + col], out_lo[row*ld_lo + col]
+//   col >= split_col -> out_f32_b[row*ld_f32 + (col - split_col)]
+template <typename T>
+struct GemmEpilogue {
+    const float* bias;
+    int act;
+    const float* residual;
+    int ld_res;
+    const float* scale;
+    const float* shift;
+    float* out_f32;
+    int ld_f32;
+    T* out_lo;
+    int ld_lo;
+    int split_col;
+    float* out_f32_b;
+};
+
+template <typename T>
+struct GemmArgs {
+    const T* A;
+    int lda;     // elements
+    const T* W;
+    int ldw;     // elements
+    int M, N, K;
+    GemmEpilogue<T> epi;
+};
+
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BN = 128;
+constexpr int GEMM_ROW_BYTES = 128;                 // K bytes per tile row
+constexpr int GEMM_TILE_BYTES = GEMM_BM * GEMM_ROW_BYTES;   // 16 KiB per operand tile
+
+__device__ __forceinline__ int lds_chunk_off(int row, int chunk) {
+    return row * GEMM_ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T>
+__device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x16& acc);
+
+template <>
+__device__ __forceinline__ void mfma_chunk<bf16_t>(const u32x4& a, const u32x4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                  acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mfma_chunk<float>(const u32x4& a, const u32x4& b, f32x16& acc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
+}
+
+// 128x128 output tile, 256 threads = 4 waves in a 2x2 grid, each wave 64x64 =
+// 2x2 MFMA tiles of 32x32.  Register-staged global->LDS with two LDS buffers: the
+// loads of K-tile t+1 are in flight while K-tile t is multiplied.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int EPC = 16 / (int)sizeof(T);            // elements per 16-byte chunk
+    constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);  // K elements per tile
+
+    // XCD-aware tile order: consecutive workgroups of one XCD share the W panel.
+    const int tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
+    const int tiles_n = (g.N + GEMM_BN - 1) / GEMM_BN;
+    const int nwg = tiles_m * tiles_n;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    // grouped order inside the XCD's range: 8 row-tiles x 8 col-tiles of concurrently
+    // resident workgroups share 8 A panels + 8 W panels in that XCD's L2.
+    constexpr int GROUP_M = 8;
+    const int group_size = GROUP_M * tiles_n;
+    const int first_m = (wg / group_size) * GROUP_M;
+    const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+    const int tm = first_m + (wg % group_size) % gm;
+    const int tn = (wg % group_size) / gm;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // global staging: 4 chunks of A and 4 of W per thread
+    const unsigned char* a_src[4];
+    const unsigned char* w_src[4];
+    int lds_dst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c >> 3, ch = c & 7;
+        int ar = m0 + row; ar = ar < g.M ? ar : g.M - 1;
+        int wr = n0 + row; wr = wr < g.N ? wr : g.N - 1;
+        a_src[i] = (const unsigned char*)(g.A + (size_t)ar * g.lda) + ch * 16;
+        w_src[i] = (const unsigned char*)(g.W + (size_t)wr * g.ldw) + ch * 16;
+        lds_dst[i] = lds_chunk_off(row, ch);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = g.K / BK;
+    u32x4 ra[4], rw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = *(const u32x4*)(a_src[i]);
+        rw[i] = *(const u32x4*)(w_src[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *(u32x4*)(smem + lds_dst[i]) = ra[i];
+        *(u32x4*)(smem + GEMM_TILE_BYTES + lds_dst[i]) = rw[i];
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const unsigned char* As = smem + cur * 2 * GEMM_TILE_BYTES;
+        const unsigned char* Ws = As + GEMM_TILE_BYTES;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const size_t koff = (size_t)(kt + 1) * GEMM_ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = *(const u32x4*)(a_src[i] + koff);
+                rw[i] = *(const u32x4*)(w_src[i] + koff);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ch = kk * 2 + hi;
+            u32x4 fa[2], fw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *(const u32x4*)(As + lds_chunk_off(wm * 64 + i * 32 + l31, ch));
+                fw[i] = *(const u32x4*)(Ws + lds_chunk_off(wn * 64 + i * 32 + l31, ch));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mfma_chunk<T>(fa[i], fw[j], acc[i][j]);
+        }
+        if (more) {
+            unsigned char* Ad = smem + (cur ^ 1) * 2 * GEMM_TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *(u32x4*)(Ad + lds_dst[i]) = ra[i];
+                *(u32x4*)(Ad + GEMM_TILE_BYTES + lds_dst[i]) = rw[i];
+            }
+        }
+        __syncthreads();
+    }
+    (void)EPC;
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31,
+    //      row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const GemmEpilogue<T>& e = g.epi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= g.N) continue;
+        const float bias = e.bias ? e.bias[col] : 0.f;
+        const float sc = e.scale ? e.scale[col] : 1.f;
+        const float sh = e.shift ? e.shift[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (e.act == ACT_GELU_TANH) v = gelu_tanh_f(v);
+                else if (e.act == ACT_GELU_ERF) v = gelu_erf_f(v);
+                if (e.residual) v += e.residual[(size_t)row * e.ld_res + col];
+                if (e.scale) v = sc * v + sh;
+                if (col < e.split_col) {
+                    if (e.out_f32) e.out_f32[(size_t)row * e.ld_f32 + col] = v;
+                    if (e.out_lo) {
+                        if constexpr (sizeof(T) == 2) e.out_lo[(size_t)row * e.ld_lo + col] = f32_to_bf16(v);
+                        else e.out_lo[(size_t)row * e.ld_lo + col] = v;
+                    }
+                } else if (e.out_f32_b) {
+                    e.out_f32_b[(size_t)row * e.ld_f32 + (col - e.split_col)] = v;
+                }
+            }
+        }
+    }
+}
+
+constexpr int GEMM_LDS_BYTES = 4 * GEMM_TILE_BYTES;   // two buffers x (A tile + W tile) = 64 KiB
+
+template <typename T>
+inline hipError_t launch_gemm(const GemmArgs<T>& g, hipStream_t stream) {
+    const int tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
+    const int tiles_n = (g.N + GEMM_BN - 1) / GEMM_BN;
+    if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(tiles_m * tiles_n), dim3(256), GEMM_LDS_BYTES, stream, g);
+    return hipGetLastError();
+}
+
+}  // namespace zett

@@ -1,0 +1,458 @@
+// rowops.hip.h — the HBM-bound kernels of the hypernet forward (gfx950).
+//
+//   plan_*          surface-form matrix -> packed-token plan (pad skipping, distinct ids)
+//   gather_src      A2/A3: source-embedding gather + in_scaler + fallback select
+//   layernorm_rows  LayerNorm over H (+ the RobertaEmbeddings add for the embed variant)
+//   attention_rows  per-row bidirectional attention over <= L' packed positions
+//   cls_gather      position-0 readout + bias head
+//
+// All of them are one-pass streaming kernels: 16-byte vector accesses, one
+// workgroup (or wave) per row, no inter-workgroup communication.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.hip.h"
+
+namespace zett {
+
+// ---------------------------------------------------------------------------
+// Plan.  Reference semantics being preserved (modeling_hypernet.py:190, 220-234 and
+// the eager RobertaSelfAttention mask):
+//   * key j of row n is visible iff ids[n,j] != pad (the language token always is);
+//   * only hidden[:,0] is read out, so a position matters only as a visible key or as
+//     position 0 (a query even when it is pad);
+//   * a row whose keys are ALL masked attends uniformly to every position (additive
+//     finfo.min on every key), so such a row keeps all L positions, flagged uniform.
+// Everything else (pad positions of ordinary rows) never influences an output and is
+// not computed.
+// ---------------------------------------------------------------------------
+
+struct PlanArrays {
+    int32_t* row_count;     // [N]   packed positions of row n
+    int32_t* row_offset;    // [N+1] exclusive scan of row_count
+    uint8_t* row_uniform;   // [N]
+    int32_t* id_flag;       // [V]   1 if the id is referenced by a kept position
+    int32_t* id_slot;       // [V+1] exclusive scan of id_flag; id_slot[V] = distinct ids
+    int32_t* id_list;       // [<=V] slot -> id
+    int32_t* tok_slot;      // [T]   table slot of the token, -1 = language token
+    int32_t* tok_pos;       // [T]   position index (for position_embeddings)
+    uint8_t* tok_key;       // [T]   visible as key
+    int32_t* err;           // [1]   set to 1 + row on an out-of-range id
+};
+
+__global__ void plan_rows_kernel(const int32_t* __restrict__ sfm, int64_t n_rows, int seq, int pad, int lam,
+                                 int n_ids, PlanArrays p) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_rows) return;
+    const int32_t* row = sfm + n * seq;
+    int visible = 0;
+    for (int j = 0; j < seq; ++j) {
+        const int id = row[j];
+        if (id < 0 || id >= n_ids) {          // F.embedding would raise IndexError here
+            atomicMax(p.err, (int)(n < 0x7ffffffe ? n + 1 : 0x7fffffff));
+            p.row_count[n] = 0;
+            p.row_uniform[n] = 2;             // poisoned: skipped by plan_tokens_kernel
+            return;
+        }
+        visible += (id != pad);
+    }
+    const bool uniform = (visible + lam) == 0;
+    int count;
+    if (uniform) {
+        count = seq;
+        for (int j = 0; j < seq; ++j) p.id_flag[row[j]] = 1;
+    } else {
+        count = visible + lam + (row[0] == pad ? 1 : 0);
+        for (int j = 0; j < seq; ++j)
+            if (j == 0 || row[j] != pad) p.id_flag[row[j]] = 1;
+    }
+    p.row_count[n] = count;
+    p.row_uniform[n] = uniform ? 1 : 0;
+}
+
+// Single-workgroup exclusive scan (n <= a few million): out[i] = sum(in[0..i)), out[n] = total.
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int32_t* __restrict__ in,
+                                                              int32_t* __restrict__ out, int64_t n) {
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b = (int64_t)t * per, e = (b + per < n) ? b + per : n;
+    int32_t s = 0;
+    for (int64_t i = b; i < e; ++i) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int32_t v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int32_t run = (t == 0) ? 0 : part[t - 1];
+    for (int64_t i = b; i < e; ++i) { const int32_t v = in[i]; out[i] = run; run += v; }
+    if (t == 1023) out[n] = part[1023];
+}
+
+__global__ void plan_tokens_kernel(const int32_t* __restrict__ sfm, int64_t n_rows, int seq, int pad, int lam,
+                                   PlanArrays p) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_rows) return;
+    const int32_t* row = sfm + n * seq;
+    int t = p.row_offset[n];
+    if (p.row_uniform[n] == 2) return;
+    const bool uniform = p.row_uniform[n] == 1;
+    for (int j = 0; j < seq; ++j) {
+        const int id = row[j];
+        const bool vis = id != pad;
+        if (uniform || vis || j == 0) {
+            p.tok_slot[t] = p.id_slot[id];
+            p.tok_pos[t] = j;
+            p.tok_key[t] = vis ? 1 : 0;
+            ++t;
+        }
+    }
+    if (lam) {
+        p.tok_slot[t] = -1;
+        p.tok_pos[t] = seq;
+        p.tok_key[t] = 1;
+    }
+}
+
+__global__ void plan_idlist_kernel(int n_ids, PlanArrays p) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < n_ids && p.id_flag[id]) p.id_list[p.id_slot[id]] = id;
+}
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// sum over a 256-thread workgroup; every thread gets the result
+__device__ __forceinline__ float block_sum_256(float v, float* red /* [4] */) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T> __device__ __forceinline__ void store_lo4(T* dst, float4 v);
+template <> __device__ __forceinline__ void store_lo4<float>(float* dst, float4 v) { *(float4*)dst = v; }
+template <> __device__ __forceinline__ void store_lo4<bf16_t>(bf16_t* dst, float4 v) {
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *(uint2*)dst = o;
+}
+
+template <int SRC_DTYPE> __device__ __forceinline__ float4 load_src4(const void* base, size_t elem);
+template <> __device__ __forceinline__ float4 load_src4<0>(const void* base, size_t e) {
+    return *(const float4*)((const float*)base + e);
+}
+template <> __device__ __forceinline__ float4 load_src4<1>(const void* base, size_t e) {   // fp16
+    const uint2 u = *(const uint2*)((const uint16_t*)base + e);
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+    const f16x4 hv = __builtin_bit_cast(f16x4, u);
+    return make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+}
+template <> __device__ __forceinline__ float4 load_src4<2>(const void* base, size_t e) {   // bf16
+    const uint2 u = *(const uint2*)((const uint16_t*)base + e);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
+// ---------------------------------------------------------------------------
+// A2 + A3 (modeling_hypernet.py:170-188): one workgroup per distinct id.
+//   id <  V0 : x = in_scaler.w * source_embeddings[id] + in_scaler.b   (if rescale)
+//   id >= V0 : x = fallback_embeddings[id - V0]                         (never rescaled)
+// ---------------------------------------------------------------------------
+template <typename T, int SRC_DTYPE>
+__global__ __launch_bounds__(256) void gather_src_kernel(const int32_t* __restrict__ id_list, int slot0, int n_slots,
+                                                         const void* __restrict__ src, int e_in, int v0,
+                                                         const float* __restrict__ fallback,
+                                                         const float* __restrict__ sc_w, const float* __restrict__ sc_b,
+                                                         T* __restrict__ out) {
+    const int s = blockIdx.x;
+    if (s >= n_slots) return;
+    const int id = id_list[slot0 + s];
+    T* dst = out + (size_t)s * e_in;
+    if (id >= v0) {
+        const float* f = fallback + (size_t)(id - v0) * e_in;
+        for (int c = threadIdx.x * 4; c < e_in; c += 1024) store_lo4<T>(dst + c, *(const float4*)(f + c));
+    } else {
+        const size_t base = (size_t)id * e_in;
+        for (int c = threadIdx.x * 4; c < e_in; c += 1024) {
+            float4 v = load_src4<SRC_DTYPE>(src, base + c);
+            if (sc_w) {
+                const float4 w = *(const float4*)(sc_w + c), b = *(const float4*)(sc_b + c);
+                v.x = w.x * v.x + b.x; v.y = w.y * v.y + b.y; v.z = w.z * v.z + b.z; v.w = w.w * v.w + b.w;
+            }
+            store_lo4<T>(dst + c, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over H for one row per workgroup (256 threads, float4 per thread, the row
+// is held in registers for H <= 8192 and re-read otherwise).  Two-pass mean/variance
+// like torch.nn.LayerNorm.
+//   plain variant : x = in[row]
+//   embed variant : RobertaEmbeddings (x + token_type[0] + position[pos]) where
+//                   x = table[slot] or, for the language token (slot < 0),
+//                   lang - (token_type[0] + position[L])   (modeling_hypernet.py:192-199)
+// ---------------------------------------------------------------------------
+struct LnEmbed {
+    const float* table;        // [D, H] hoisted input projection
+    const int32_t* tok_slot;
+    const int32_t* tok_pos;
+    const float* type0;        // [H]
+    const float* pos_emb;      // [max_positions, H]
+    const float* lang;         // [H] or null
+    int lang_pos;              // L
+};
+
+constexpr int LN_MAX_VEC = 8;   // 8 float4 x 256 threads = 8192 columns in registers
+
+template <typename T, bool EMBED>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ in, int ld_in, int rows, int H,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             float* __restrict__ out_f32, T* __restrict__ out_lo,
+                                                             LnEmbed emb, int tok0) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    if (r >= rows) return;
+    const int nvec = H >> 2;
+    const int tid = threadIdx.x;
+    const float* x = nullptr;
+    const float* posr = nullptr;
+    bool is_lang = false;
+    if constexpr (EMBED) {
+        const int slot = emb.tok_slot[tok0 + r];
+        is_lang = slot < 0;
+        x = is_lang ? emb.lang : emb.table + (size_t)slot * H;
+        posr = emb.pos_emb + (size_t)emb.tok_pos[tok0 + r] * H;
+    } else {
+        x = in + (size_t)r * ld_in;
+    }
+    auto load = [&](int v) -> float4 {
+        float4 a = *(const float4*)(x + v * 4);
+        if constexpr (EMBED) {
+            const float4 t0 = *(const float4*)(emb.type0 + v * 4);
+            const float4 p = *(const float4*)(posr + v * 4);
+            if (is_lang) {   // lang -= type0 + pos[L]   (then the embeddings add them back)
+                const float4 pl = *(const float4*)(emb.pos_emb + (size_t)emb.lang_pos * H + v * 4);
+                a.x -= (t0.x + pl.x); a.y -= (t0.y + pl.y); a.z -= (t0.z + pl.z); a.w -= (t0.w + pl.w);
+            }
+            a.x = (a.x + t0.x) + p.x; a.y = (a.y + t0.y) + p.y; a.z = (a.z + t0.z) + p.z; a.w = (a.w + t0.w) + p.w;
+        }
+        return a;
+    };
+    float4 v[LN_MAX_VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_VEC; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < nvec) { v[j] = load(idx); s += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
+    }
+    for (int idx = tid + 256 * LN_MAX_VEC; idx < nvec; idx += 256) { const float4 a = load(idx); s += (a.x + a.y) + (a.z + a.w); }
+    const float mean = block_sum_256(s, red) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_VEC; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < nvec) {
+            const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    for (int idx = tid + 256 * LN_MAX_VEC; idx < nvec; idx += 256) {
+        const float4 t = load(idx);
+        const float a = t.x - mean, b = t.y - mean, c = t.z - mean, d = t.w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float var = block_sum_256(q, red) / (float)H;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    auto emit = [&](int idx, float4 a) {
+        const float4 g = *(const float4*)(gamma + idx * 4), b = *(const float4*)(beta + idx * 4);
+        float4 o;
+        o.x = (a.x - mean) * rstd * g.x + b.x; o.y = (a.y - mean) * rstd * g.y + b.y;
+        o.z = (a.z - mean) * rstd * g.z + b.z; o.w = (a.w - mean) * rstd * g.w + b.w;
+        if (out_f32) *(float4*)(out_f32 + (size_t)r * H + idx * 4) = o;
+        if (out_lo) store_lo4<T>(out_lo + (size_t)r * H + idx * 4, o);
+    };
+#pragma unroll
+    for (int j = 0; j < LN_MAX_VEC; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < nvec) emit(idx, v[j]);
+    }
+    for (int idx = tid + 256 * LN_MAX_VEC; idx < nvec; idx += 256) emit(idx, load(idx));
+}
+
+// ---------------------------------------------------------------------------
+// Attention over the packed positions of one row (A6).  One wave handles one row and
+// one group of 512 hidden columns (8 per lane): 512/d heads at a time, head-local
+// reductions by xor-shuffles over d/8 lanes.  Two passes over the keys (row max, then
+// exp / sum / PV) reproduce softmax(QKᵀ·d^-½ + mask)·V of eager_attention_forward; keys
+// with ids == pad contribute exactly 0 (their exp underflows to 0 in the reference),
+// uniform rows weigh every position equally.
+// ---------------------------------------------------------------------------
+template <typename T> struct Vec8 { float v[8]; };
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&o)[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&o)[8]) {
+    const uint4 u = *(const uint4*)p;
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+    o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+    o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&o)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&o)[8]) {
+    *(float4*)p = make_float4(o[0], o[1], o[2], o[3]);
+    *(float4*)(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&o)[8]) {
+    uint4 u;
+    u.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+    u.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+    u.z = (uint32_t)f32_to_bf16(o[4]) | ((uint32_t)f32_to_bf16(o[5]) << 16);
+    u.w = (uint32_t)f32_to_bf16(o[6]) | ((uint32_t)f32_to_bf16(o[7]) << 16);
+    *(uint4*)p = u;
+}
+
+// qkv: [T, 3H] (q | k | v), ctx: [T or rows, H].  cls_only: compute query 0 only and
+// write it at ctx[row_local] (compact [rows, H] output for the last layer).
+template <typename T>
+__global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict__ qkv, int H, int head_dim,
+                                                             const int32_t* __restrict__ row_offset,
+                                                             const uint8_t* __restrict__ row_uniform,
+                                                             const uint8_t* __restrict__ tok_key, int64_t row0,
+                                                             int rows, int tok0, float scaling, int cls_only,
+                                                             T* __restrict__ ctx) {
+    const int groups = (H + 511) >> 9;
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (int64_t)rows * groups) return;
+    const int rl = (int)(w / groups), grp = (int)(w % groups);
+    const int col = grp * 512 + lane * 8;
+    const bool active = col < H;
+    const int lph = head_dim >> 3;                     // lanes per head (power of two)
+    const int64_t n = row0 + rl;
+    const int t0 = row_offset[n] - tok0, t1 = row_offset[n + 1] - tok0;
+    const bool uniform = row_uniform[n];
+    const size_t ld = (size_t)3 * H;
+    const int nq = cls_only ? 1 : (t1 - t0);
+    const int ccol = active ? col : 0;
+    for (int qi = 0; qi < nq; ++qi) {
+        float q[8];
+        load8<T>(qkv + (size_t)(t0 + qi) * ld + ccol, q);
+        float mx = -INFINITY;
+        for (int kj = t0; kj < t1; ++kj) {
+            if (!uniform && !tok_key[tok0 + kj]) continue;
+            float k[8];
+            load8<T>(qkv + (size_t)kj * ld + H + ccol, k);
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s = fmaf(q[c], k[c], s);
+            for (int off = 1; off < lph; off <<= 1) s += __shfl_xor(s, off, 64);
+            s = uniform ? 0.f : s * scaling;
+            mx = fmaxf(mx, s);
+        }
+        float l = 0.f, acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+        for (int kj = t0; kj < t1; ++kj) {
+            if (!uniform && !tok_key[tok0 + kj]) continue;
+            float k[8], v[8];
+            load8<T>(qkv + (size_t)kj * ld + H + ccol, k);
+            load8<T>(qkv + (size_t)kj * ld + 2 * H + ccol, v);
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s = fmaf(q[c], k[c], s);
+            for (int off = 1; off < lph; off <<= 1) s += __shfl_xor(s, off, 64);
+            s = uniform ? 0.f : s * scaling;
+            const float p = expf(s - mx);
+            l += p;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = fmaf(p, v[c], acc[c]);
+        }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] *= inv;
+        if (active) {
+            const size_t orow = cls_only ? (size_t)rl : (size_t)(t0 + qi);
+            store8<T>(ctx + orow * H + col, acc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Position-0 readout (modeling_hypernet.py:231-234) + bias head (:260-265).
+// src rows are either packed tokens (index row_offset[n] - tok0) or already compact.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict__ z_f32, const T* __restrict__ z_lo,
+                                                         int H, const int32_t* __restrict__ row_offset, int64_t row0,
+                                                         int rows, int tok0, int compact,
+                                                         float* __restrict__ c_f32, T* __restrict__ c_lo,
+                                                         const float* __restrict__ bias_w, const float* __restrict__ bias_b,
+                                                         float* __restrict__ out_bias) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    if (r >= rows) return;
+    const size_t srow = compact ? (size_t)r : (size_t)(row_offset[row0 + r] - tok0);
+    const float* zf = z_f32 + srow * H;
+    float dot = 0.f;
+    for (int c = threadIdx.x * 4; c < H; c += 1024) {
+        const float4 a = *(const float4*)(zf + c);
+        if (c_f32) *(float4*)(c_f32 + (size_t)r * H + c) = a;
+        if (c_lo) {
+            if (z_lo) {
+                if constexpr (sizeof(T) == 2) *(uint2*)(c_lo + (size_t)r * H + c) = *(const uint2*)(z_lo + srow * H + c);
+                else *(float4*)(c_lo + (size_t)r * H + c) = a;
+            } else {
+                store_lo4<T>(c_lo + (size_t)r * H + c, a);
+            }
+        }
+        if (bias_w) {
+            const float4 w = *(const float4*)(bias_w + c);
+            dot += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+        }
+    }
+    if (out_bias) {
+        const float tot = block_sum_256(dot, red);
+        if (threadIdx.x == 0) out_bias[row0 + r] = bias_w ? tot + bias_b[0] : 0.f;
+    }
+}
+
+// dtype conversion used when weights are uploaded
+__global__ void convert_f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) store_lo4<bf16_t>(out + i, *(const float4*)(in + i));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (size_t j = n & ~(size_t)3; j < n; ++j) out[j] = f32_to_bf16(in[j]);
+    }
+}
+template <int SRC_DTYPE>
+__global__ void convert_to_f32_kernel(const void* __restrict__ in, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if constexpr (SRC_DTYPE == 1) out[i] = (float)((const _Float16*)in)[i];
+        else out[i] = __uint_as_float(((uint32_t)((const uint16_t*)in)[i]) << 16);
+    }
+}
+
+}  // namespace zett

@@ -1,0 +1,636 @@
+// zett_hip.hip — C ABI of libzett_hip.so (see include/zett_hip.h).
+//
+// Host-side orchestration of the hypernet forward on one MI355X:
+//
+//   plan      surface forms -> packed positions, distinct referenced source ids
+//   table     for each DISTINCT source id once: gather + in_scaler/fallback ->
+//             input_projection (Linear + ProjectorBlock)            [hoisting, exact]
+//   encoder   RobertaEmbeddings + hn_n_layers encoder layers over the PACKED
+//             positions only (pad positions never influence hidden[:,0])  [exact]
+//             last layer: keys/values for every position, query / O-proj / FFN for
+//             position 0 only                                            [exact]
+//   heads     ProjectorBlock + Linear (+ Rescaler) per output head, bias head
+//
+// Every dense contraction goes through gemm.hip.h (MFMA); everything else through
+// the streaming kernels of rowops.hip.h.  All launches go to the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/zett_hip.h"
+#include "common.hip.h"
+#include "gemm.hip.h"
+#include "rowops.hip.h"
+#include "retok.hip.h"
+
+using namespace zett;
+
+namespace {
+
+struct Tensor {
+    float* f32 = nullptr;       // device fp32 copy (biases, LN, embeddings, ... and GEMM weights in F32 mode)
+    void* lo = nullptr;         // GEMM operand copy in the handle's arithmetic type
+    std::vector<int64_t> shape;
+    size_t numel = 0;
+};
+
+inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct zett_hypernet {
+    zett_config cfg{};
+    int device = 0;
+    int precision = ZETT_PREC_BF16;
+    bool finalized = false;
+    std::map<std::string, Tensor> w;
+    // fused / derived operands built by zett_finalize
+    std::vector<void*> qkv_w;         // per layer [3H, H]
+    std::vector<float*> qkv_b;        // per layer [3H]
+    float* head_scale = nullptr;      // [head_out_width] scaler.w (| out_scaler.w for single_head)
+    float* head_shift = nullptr;
+    std::vector<void*> owned;         // everything to hipFree at destroy
+    // options
+    int64_t max_chunk_tokens = 65536;
+    int time_gemm = 0;
+    int cls_only_last = 1;
+    // workspace
+    DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct;
+    int32_t* host_pinned = nullptr;
+    size_t host_pinned_ints = 0;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    std::vector<double> ev_flops;
+    zett_stats stats{};
+};
+
+namespace {
+
+size_t elt_size(int precision) { return precision == ZETT_PREC_BF16 ? 2 : 4; }
+
+bool is_gemm_weight(const std::string& n) {
+    static const char* suffixes[] = {"input_projection.0.weight", "dense1.weight", "dense2.weight",
+                                     "query.weight", "key.weight", "value.weight", "dense.weight",
+                                     "output_projection.1.weight", "output_projection_out.1.weight"};
+    for (const char* s : suffixes) {
+        const size_t ls = strlen(s);
+        if (n.size() >= ls && n.compare(n.size() - ls, ls, s) == 0) return true;
+    }
+    return false;
+}
+
+// expected shapes (mirrors zett_amd/dims.py:weight_shapes)
+void expected_shapes(const zett_config& c, std::map<std::string, std::vector<int64_t>>& s) {
+    const int64_t H = c.hidden, I = c.intermediate;
+    auto proj = [&](const std::string& p) {
+        s[p + "dense1.weight"] = {I, H}; s[p + "dense1.bias"] = {I};
+        s[p + "dense2.weight"] = {H, I}; s[p + "dense2.bias"] = {H};
+        s[p + "ln.weight"] = {H}; s[p + "ln.bias"] = {H};
+    };
+    if (c.embed_lang) s["lang_embeddings.weight"] = {c.n_langs, H};
+    s["model.embeddings.token_type_embeddings.weight"] = {1, H};
+    s["model.embeddings.LayerNorm.weight"] = {H};
+    s["model.embeddings.LayerNorm.bias"] = {H};
+    s["model.embeddings.position_embeddings.weight"] = {c.max_positions, H};
+    for (int l = 0; l < c.layers; ++l) {
+        const std::string p = "model.encoder.layer." + std::to_string(l) + ".";
+        for (const char* q : {"query", "key", "value"}) {
+            s[p + "attention.self." + q + ".weight"] = {H, H};
+            s[p + "attention.self." + q + ".bias"] = {H};
+        }
+        s[p + "attention.output.dense.weight"] = {H, H}; s[p + "attention.output.dense.bias"] = {H};
+        s[p + "attention.output.LayerNorm.weight"] = {H}; s[p + "attention.output.LayerNorm.bias"] = {H};
+        s[p + "intermediate.dense.weight"] = {I, H}; s[p + "intermediate.dense.bias"] = {I};
+        s[p + "output.dense.weight"] = {H, I}; s[p + "output.dense.bias"] = {H};
+        s[p + "output.LayerNorm.weight"] = {H}; s[p + "output.LayerNorm.bias"] = {H};
+    }
+    s["fallback_embeddings.weight"] = {c.n_extra, c.n_in_embd};
+    s["input_projection.0.weight"] = {H, c.n_in_embd}; s["input_projection.0.bias"] = {H};
+    proj("input_projection.1.");
+    proj("output_projection.0.");
+    const int64_t w0 = c.single_head ? c.n_in_embd : c.n_embd;
+    s["output_projection.1.weight"] = {w0, H}; s["output_projection.1.bias"] = {w0};
+    if (c.separate_out && !c.single_head) {
+        proj("output_projection_out.0.");
+        s["output_projection_out.1.weight"] = {c.n_embd, H}; s["output_projection_out.1.bias"] = {c.n_embd};
+    }
+    if (c.rescale) {
+        s["in_scaler.w"] = {1, c.n_in_embd}; s["in_scaler.b"] = {1, c.n_in_embd};
+        s["scaler.w"] = {1, c.n_embd}; s["scaler.b"] = {1, c.n_embd};
+        if (c.separate_out) { s["out_scaler.w"] = {1, c.n_embd}; s["out_scaler.b"] = {1, c.n_embd}; }
+    }
+    if (c.predict_bias) { s["bias_projection.weight"] = {1, H}; s["bias_projection.bias"] = {1}; }
+}
+
+int validate_config(const zett_config& c, int precision) {
+    if (c.n_embd <= 0 || c.hidden <= 0 || c.intermediate <= 0 || c.heads <= 0 || c.layers <= 0)
+        return fail(ZETT_E_INVALID, "non-positive dimension in zett_config");
+    if (c.n_in_embd != (c.separate_out ? 2 * c.n_embd : c.n_embd))
+        return fail(ZETT_E_INVALID, "n_in_embd must be 2*n_embd iff separate_out");
+    if (c.hidden % c.heads) return fail(ZETT_E_INVALID, "hidden %d not divisible by heads %d", c.hidden, c.heads);
+    const int d = c.hidden / c.heads;
+    if (d < 8 || d > 512 || (d & (d - 1))) return fail(ZETT_E_INVALID, "head_dim %d unsupported (need a power of two in [8,512])", d);
+    const int kq = precision == ZETT_PREC_BF16 ? 64 : 32;
+    for (int k : {c.n_in_embd, c.hidden, c.intermediate})
+        if (k % kq) return fail(ZETT_E_INVALID, "contraction width %d is not a multiple of %d", k, kq);
+    if (c.n_embd % 4) return fail(ZETT_E_INVALID, "n_embd must be a multiple of 4");
+    if (c.n_extra < 1) return fail(ZETT_E_INVALID, "n_extra must be >= 1 (reference allocates max(hn_n_extra_tokens,1))");
+    if (c.pad_token_id < 0) return fail(ZETT_E_INVALID, "pad_token_id is required");
+    if (c.embed_lang && c.n_langs <= 0) return fail(ZETT_E_INVALID, "hn_embed_lang_id needs n_langs");
+    return 0;
+}
+
+template <typename T>
+int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const void* src, int src_dtype,
+               int64_t v_src, int lang_index, float* out_in, float* out_out, float* out_bias, hipStream_t st);
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+extern "C" {
+
+const char* zett_last_error(void) { return g_err.c_str(); }
+int zett_abi_version(void) { return ZETT_ABI_VERSION; }
+
+int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet** out) {
+    if (!cfg || !out) return fail(ZETT_E_INVALID, "null argument");
+    if (precision != ZETT_PREC_BF16 && precision != ZETT_PREC_F32) return fail(ZETT_E_INVALID, "unknown precision %d", precision);
+    if (int rc = validate_config(*cfg, precision)) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(ZETT_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    auto* h = new zett_hypernet();
+    h->cfg = *cfg;
+    h->device = device;
+    h->precision = precision;
+    *out = h;
+    return 0;
+}
+
+int zett_destroy(zett_hypernet* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    for (auto& kv : h->w) {
+        if (kv.second.f32) (void)hipFree(kv.second.f32);
+        if (kv.second.lo && kv.second.lo != (void*)kv.second.f32) (void)hipFree(kv.second.lo);
+    }
+    for (void* p : h->owned) (void)hipFree(p);
+    for (DevBuf* b : {&h->plan_i32, &h->plan_u8, &h->table, &h->x0, &h->yf, &h->yt, &h->big, &h->pre, &h->ctx, &h->cf, &h->ct})
+        b->release();
+    if (h->host_pinned) (void)hipHostFree(h->host_pinned);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+    return 0;
+}
+
+int zett_load_weight(zett_hypernet* h, const char* name, const void* data, int dtype, const int64_t* shape, int ndim) {
+    if (!h || !name || !data || !shape || ndim < 1) return fail(ZETT_E_INVALID, "null argument");
+    if (h->finalized) return fail(ZETT_E_STATE, "weights are frozen after zett_finalize");
+    std::map<std::string, std::vector<int64_t>> exp;
+    expected_shapes(h->cfg, exp);
+    const std::string n(name);
+    auto it = exp.find(n);
+    if (it == exp.end()) return 0;   // e.g. model.embeddings.word_embeddings.weight: never read
+    std::vector<int64_t> got(shape, shape + ndim);
+    if (got != it->second) {
+        std::string a, b;
+        for (auto v : got) a += std::to_string(v) + ",";
+        for (auto v : it->second) b += std::to_string(v) + ",";
+        return fail(ZETT_E_INVALID, "%s: shape [%s] does not match the config's [%s]", name, a.c_str(), b.c_str());
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    size_t numel = 1;
+    for (auto v : got) numel *= (size_t)v;
+    Tensor& t = h->w[n];
+    if (t.f32) { (void)hipFree(t.f32); t.f32 = nullptr; }
+    t.shape = got;
+    t.numel = numel;
+    HIP_TRY(hipMalloc((void**)&t.f32, numel * 4));
+    if (dtype == ZETT_F32) {
+        HIP_TRY(hipMemcpy(t.f32, data, numel * 4, hipMemcpyDefault));
+    } else if (dtype == ZETT_F16 || dtype == ZETT_BF16) {
+        void* stage = nullptr;
+        HIP_TRY(hipMalloc(&stage, numel * 2));
+        hipError_t e = hipMemcpy(stage, data, numel * 2, hipMemcpyDefault);
+        if (e == hipSuccess) {
+            const int blocks = (int)std::min<size_t>((numel + 255) / 256, 65535);
+            if (dtype == ZETT_F16) hipLaunchKernelGGL(convert_to_f32_kernel<1>, dim3(blocks), dim3(256), 0, 0, stage, t.f32, numel);
+            else hipLaunchKernelGGL(convert_to_f32_kernel<2>, dim3(blocks), dim3(256), 0, 0, stage, t.f32, numel);
+            e = hipDeviceSynchronize();
+        }
+        (void)hipFree(stage);
+        if (e != hipSuccess) return fail(ZETT_E_HIP, "upload of %s failed: %s", name, hipGetErrorString(e));
+    } else {
+        return fail(ZETT_E_INVALID, "unknown dtype %d", dtype);
+    }
+    return 0;
+}
+
+int zett_finalize(zett_hypernet* h) {
+    if (!h) return fail(ZETT_E_INVALID, "null handle");
+    if (h->finalized) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    std::map<std::string, std::vector<int64_t>> exp;
+    expected_shapes(h->cfg, exp);
+    for (auto& kv : exp)
+        if (!h->w.count(kv.first)) return fail(ZETT_E_STATE, "missing weight: %s", kv.first.c_str());
+    const zett_config& c = h->cfg;
+    const size_t es = elt_size(h->precision);
+    // GEMM operands in the arithmetic type
+    for (auto& kv : h->w) {
+        Tensor& t = kv.second;
+        if (!is_gemm_weight(kv.first)) continue;
+        if (h->precision == ZETT_PREC_F32) { t.lo = t.f32; continue; }
+        HIP_TRY(hipMalloc(&t.lo, t.numel * 2));
+        const int blocks = (int)std::min<size_t>((t.numel / 4 + 255) / 256 + 1, 65535);
+        hipLaunchKernelGGL(convert_f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, 0, t.f32, (bf16_t*)t.lo, t.numel);
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    // fused QKV operand per layer: rows [q | k | v]
+    const size_t H = c.hidden;
+    for (int l = 0; l < c.layers; ++l) {
+        const std::string p = "model.encoder.layer." + std::to_string(l) + ".attention.self.";
+        void* wq = nullptr; float* bq = nullptr;
+        HIP_TRY(hipMalloc(&wq, 3 * H * H * es));
+        HIP_TRY(hipMalloc((void**)&bq, 3 * H * 4));
+        h->owned.push_back(wq); h->owned.push_back(bq);
+        int k = 0;
+        for (const char* q : {"query", "key", "value"}) {
+            Tensor& tw = h->w[p + q + ".weight"];
+            Tensor& tb = h->w[p + q + ".bias"];
+            HIP_TRY(hipMemcpy((char*)wq + (size_t)k * H * H * es, tw.lo, H * H * es, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(bq + (size_t)k * H, tb.f32, H * 4, hipMemcpyDeviceToDevice));
+            ++k;
+        }
+        h->qkv_w.push_back(wq);
+        h->qkv_b.push_back(bq);
+    }
+    // output Rescaler vectors laid out over the first head's columns
+    if (c.rescale) {
+        const size_t w0 = c.single_head ? c.n_in_embd : c.n_embd;
+        HIP_TRY(hipMalloc((void**)&h->head_scale, w0 * 4));
+        HIP_TRY(hipMalloc((void**)&h->head_shift, w0 * 4));
+        h->owned.push_back(h->head_scale); h->owned.push_back(h->head_shift);
+        HIP_TRY(hipMemcpy(h->head_scale, h->w["scaler.w"].f32, c.n_embd * 4, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(h->head_shift, h->w["scaler.b"].f32, c.n_embd * 4, hipMemcpyDeviceToDevice));
+        if (c.single_head && c.separate_out) {
+            HIP_TRY(hipMemcpy(h->head_scale + c.n_embd, h->w["out_scaler.w"].f32, c.n_embd * 4, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(h->head_shift + c.n_embd, h->w["out_scaler.b"].f32, c.n_embd * 4, hipMemcpyDeviceToDevice));
+        }
+    }
+    // the fp32 originals of bf16 GEMM operands are no longer needed
+    if (h->precision == ZETT_PREC_BF16) {
+        for (auto& kv : h->w) {
+            Tensor& t = kv.second;
+            if (is_gemm_weight(kv.first) && t.f32) { (void)hipFree(t.f32); t.f32 = nullptr; }
+        }
+    }
+    h->finalized = true;
+    return 0;
+}
+
+int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
+    if (!h || !key) return fail(ZETT_E_INVALID, "null argument");
+    const std::string k(key);
+    if (k == "max_chunk_tokens") {
+        if (value < 1024) return fail(ZETT_E_INVALID, "max_chunk_tokens must be >= 1024");
+        h->max_chunk_tokens = value;
+    } else if (k == "time_gemm") {
+        h->time_gemm = value != 0;
+    } else if (k == "cls_only_last_layer") {
+        h->cls_only_last = value != 0;
+    } else {
+        return fail(ZETT_E_INVALID, "unknown option %s", key);
+    }
+    return 0;
+}
+
+int zett_get_stats(const zett_hypernet* h, zett_stats* out) {
+    if (!h || !out) return fail(ZETT_E_INVALID, "null argument");
+    *out = h->stats;
+    return 0;
+}
+
+int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq,
+                 const void* source_embeddings, int src_dtype, int64_t v_src, int32_t lang_index,
+                 float* out_in, float* out_out, float* out_bias, void* stream) {
+    if (!h) return fail(ZETT_E_INVALID, "null handle");
+    if (!h->finalized) return fail(ZETT_E_STATE, "zett_finalize has not been called");
+    const zett_config& c = h->cfg;
+    if (n_rows < 0 || seq < 1) return fail(ZETT_E_INVALID, "bad surface-form shape [%lld, %d]", (long long)n_rows, seq);
+    if (seq + (c.embed_lang ? 1 : 0) > c.max_positions) return fail(ZETT_E_INDEX, "sequence %d exceeds position_embeddings (%d rows)", seq, c.max_positions);
+    if (!surface_forms || !source_embeddings || !out_in || !out_bias) return fail(ZETT_E_INVALID, "null tensor argument");
+    const bool has_out = c.separate_out;
+    if (has_out && !out_out) return fail(ZETT_E_INVALID, "out_out is required when separate_out_embeddings is set");
+    if (src_dtype < ZETT_F32 || src_dtype > ZETT_BF16) return fail(ZETT_E_INVALID, "unknown source dtype %d", src_dtype);
+    if (v_src < c.original_vocab_size) return fail(ZETT_E_INDEX, "source_embeddings has %lld rows, config.original_vocab_size is %d", (long long)v_src, c.original_vocab_size);
+    if (c.embed_lang && (lang_index < 0 || lang_index >= c.n_langs)) return fail(ZETT_E_INDEX, "lang_index %d outside [0,%d)", lang_index, c.n_langs);
+    if (n_rows * (int64_t)(seq + 1) >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many positions for one call");
+    HIP_TRY(hipSetDevice(h->device));
+    if (n_rows == 0) { h->stats = zett_stats{}; return 0; }
+    hipStream_t st = (hipStream_t)stream;
+    if (h->precision == ZETT_PREC_BF16)
+        return do_forward<bf16_t>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);
+    return do_forward<float>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+struct Runner {
+    zett_hypernet* h;
+    hipStream_t st;
+    int rc = 0;
+
+    const Tensor& W(const std::string& n) { return h->w.at(n); }
+    const T* Wlo(const std::string& n) { return (const T*)h->w.at(n).lo; }
+    const float* Wf(const std::string& n) { return h->w.at(n).f32; }
+
+    GemmEpilogue<T> epi() {
+        GemmEpilogue<T> e{};
+        e.split_col = 0x7fffffff;
+        return e;
+    }
+
+    void gemm(const T* A, int lda, const T* Wp, int ldw, int M, int N, int K, const GemmEpilogue<T>& e) {
+        if (rc || M <= 0) return;
+        GemmArgs<T> g{A, lda, Wp, ldw, M, N, K, e};
+        const double fl = 2.0 * (double)M * (double)N * (double)K;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->time_gemm) {
+            while (h->ev.size() < h->ev_used + 2) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) { rc = fail(ZETT_E_HIP, "hipEventCreate failed"); return; }
+                h->ev.push_back(ev);
+            }
+            e0 = h->ev[h->ev_used++];
+            e1 = h->ev[h->ev_used++];
+            h->ev_flops.push_back(fl);
+            (void)hipEventRecord(e0, st);
+        }
+        hipError_t err = launch_gemm<T>(g, st);
+        if (h->time_gemm) (void)hipEventRecord(e1, st);
+        if (err != hipSuccess) { rc = fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(err)); return; }
+        h->stats.executed_flops += fl;
+        h->stats.gemm_launches += 1;
+    }
+
+    void check(const char* what) {
+        if (rc) return;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(ZETT_E_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    }
+
+    void layernorm(const float* in, int rows, const float* gamma, const float* beta, float eps, float* of, T* ol) {
+        if (rc || rows <= 0) return;
+        hipLaunchKernelGGL((layernorm_rows_kernel<T, false>), dim3(rows), dim3(256), 0, st, in, h->cfg.hidden, rows,
+                           h->cfg.hidden, gamma, beta, eps, of, ol, LnEmbed{}, 0);
+        check("layernorm");
+    }
+
+    // ProjectorBlock (modeling_hypernet.py:22-40) on rows already projected to H:
+    //   out = LN_1e-6( gelu_t(W2·gelu_t(W1·x + b1) + b2) + x )
+    void projector(const std::string& p, const T* x_lo, const float* x_f32, int rows, T* big, float* pre, float* of, T* ol) {
+        const zett_config& c = h->cfg;
+        GemmEpilogue<T> e1 = epi();
+        e1.bias = Wf(p + "dense1.bias"); e1.act = ACT_GELU_TANH; e1.out_lo = big; e1.ld_lo = c.intermediate;
+        gemm(x_lo, c.hidden, Wlo(p + "dense1.weight"), c.hidden, rows, c.intermediate, c.hidden, e1);
+        GemmEpilogue<T> e2 = epi();
+        e2.bias = Wf(p + "dense2.bias"); e2.act = ACT_GELU_TANH; e2.residual = x_f32; e2.ld_res = c.hidden;
+        e2.out_f32 = pre; e2.ld_f32 = c.hidden;
+        gemm(big, c.intermediate, Wlo(p + "dense2.weight"), c.intermediate, rows, c.hidden, c.intermediate, e2);
+        layernorm(pre, rows, Wf(p + "ln.weight"), Wf(p + "ln.bias"), c.ln_eps_projector, of, ol);
+    }
+};
+
+template <typename T, int SD>
+void launch_gather(hipStream_t st, const int32_t* id_list, int s0, int m, const void* src, const zett_config& c,
+                   const float* fallback, const float* sw, const float* sb, T* out) {
+    hipLaunchKernelGGL((gather_src_kernel<T, SD>), dim3(m), dim3(256), 0, st, id_list, s0, m, src, c.n_in_embd,
+                       c.original_vocab_size, fallback, sw, sb, out);
+}
+
+template <typename T>
+int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const void* src, int src_dtype,
+               int64_t v_src, int lang_index, float* out_in, float* out_out, float* out_bias, hipStream_t st) {
+    (void)v_src;
+    const zett_config& c = h->cfg;
+    const int H = c.hidden, I = c.intermediate, E = c.n_embd, EIN = c.n_in_embd;
+    const int lam = c.embed_lang ? 1 : 0;
+    const int V = c.original_vocab_size + c.n_extra;
+    const int64_t max_tok = N * (int64_t)(seq + lam);
+    h->stats = zett_stats{};
+    h->stats.rows = N;
+    h->ev_used = 0;
+    h->ev_flops.clear();
+
+    // ---- plan ---------------------------------------------------------------------
+    // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] err[1]
+    const size_t n_i32 = (size_t)N + (N + 1) + V + (V + 1) + V + 2 * (size_t)max_tok + 1;
+    if (int rc = h->plan_i32.reserve(n_i32 * 4)) return rc;
+    if (int rc = h->plan_u8.reserve((size_t)N + (size_t)max_tok)) return rc;
+    PlanArrays p{};
+    int32_t* base = h->plan_i32.as<int32_t>();
+    p.row_count = base; base += N;
+    p.row_offset = base; base += N + 1;
+    p.id_flag = base; base += V;
+    p.id_slot = base; base += V + 1;
+    p.id_list = base; base += V;
+    p.tok_slot = base; base += max_tok;
+    p.tok_pos = base; base += max_tok;
+    p.err = base;
+    p.row_uniform = h->plan_u8.as<uint8_t>();
+    p.tok_key = p.row_uniform + N;
+    HIP_TRY(hipMemsetAsync(p.id_flag, 0, (size_t)V * 4, st));
+    HIP_TRY(hipMemsetAsync(p.err, 0, 4, st));
+    const int rb = (int)((N + 255) / 256);
+    hipLaunchKernelGGL(plan_rows_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, p.row_count, p.row_offset, N);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, p.id_flag, p.id_slot, (int64_t)V);
+    hipLaunchKernelGGL(plan_tokens_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, p);
+    hipLaunchKernelGGL(plan_idlist_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, p);
+    HIP_TRY(hipGetLastError());
+    // bring the row offsets, the distinct-id count and the error word to the host
+    const size_t need_ints = (size_t)N + 1 + 2;
+    if (h->host_pinned_ints < need_ints) {
+        if (h->host_pinned) (void)hipHostFree(h->host_pinned);
+        h->host_pinned = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&h->host_pinned, need_ints * 4, hipHostMallocDefault));
+        h->host_pinned_ints = need_ints;
+    }
+    int32_t* hoff = h->host_pinned;
+    HIP_TRY(hipMemcpyAsync(hoff, p.row_offset, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hoff + N + 1, p.id_slot + V, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hoff + N + 2, p.err, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (hoff[N + 2] != 0)
+        return fail(ZETT_E_INDEX, "surface-form row %d holds an id outside [0, %d) (original_vocab_size %d + %d fallback rows)",
+                    hoff[N + 2] - 1, V, c.original_vocab_size, c.n_extra);
+    const int64_t Ttot = hoff[N];
+    const int D = hoff[N + 1];
+    h->stats.packed_tokens = Ttot;
+    h->stats.distinct_ids = D;
+
+    // ---- workspace ------------------------------------------------------------------
+    const int64_t cap = h->max_chunk_tokens;
+    const int64_t MC = std::max<int64_t>(std::min<int64_t>(cap, std::max<int64_t>(Ttot, D)), seq + lam);
+    const size_t es = sizeof(T);
+    const size_t wide = (size_t)std::max(I, 3 * H);
+    if (int rc = h->table.reserve((size_t)D * H * 4)) return rc;
+    if (int rc = h->x0.reserve((size_t)MC * EIN * es)) return rc;
+    if (int rc = h->yf.reserve((size_t)MC * H * 4)) return rc;
+    if (int rc = h->yt.reserve((size_t)MC * H * es)) return rc;
+    if (int rc = h->big.reserve((size_t)MC * wide * es)) return rc;
+    if (int rc = h->pre.reserve((size_t)MC * H * 4)) return rc;
+    if (int rc = h->ctx.reserve((size_t)MC * H * es)) return rc;
+    if (int rc = h->cf.reserve((size_t)MC * H * 4)) return rc;
+    if (int rc = h->ct.reserve((size_t)MC * H * es)) return rc;
+    float* TBL = h->table.as<float>();
+    T* X0 = h->x0.as<T>();
+    float* Zf = h->yf.as<float>();
+    T* Zt = h->yt.as<T>();
+    T* BIG = h->big.as<T>();
+    float* PRE = h->pre.as<float>();
+    T* CTX = h->ctx.as<T>();
+    float* Cf = h->cf.as<float>();
+    T* Ct = h->ct.as<T>();
+
+    Runner<T> R{h, st};
+
+    // ---- table: input_projection once per distinct source id (A2-A4) -----------------
+    const float* in_w = c.rescale ? R.Wf("in_scaler.w") : nullptr;
+    const float* in_b = c.rescale ? R.Wf("in_scaler.b") : nullptr;
+    for (int s0 = 0; s0 < D && !R.rc; s0 += (int)MC) {
+        const int m = (int)std::min<int64_t>(MC, D - s0);
+        const float* fb = R.Wf("fallback_embeddings.weight");
+        if (src_dtype == ZETT_F32) launch_gather<T, 0>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0);
+        else if (src_dtype == ZETT_F16) launch_gather<T, 1>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0);
+        else launch_gather<T, 2>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0);
+        R.check("gather_src");
+        GemmEpilogue<T> e0 = R.epi();
+        e0.bias = R.Wf("input_projection.0.bias"); e0.out_f32 = Zf; e0.ld_f32 = H; e0.out_lo = Zt; e0.ld_lo = H;
+        R.gemm(X0, EIN, R.Wlo("input_projection.0.weight"), EIN, m, H, EIN, e0);
+        R.projector("input_projection.1.", Zt, Zf, m, BIG, PRE, TBL + (size_t)s0 * H, nullptr);
+    }
+    if (R.rc) return R.rc;
+
+    // ---- encoder + heads over row chunks -----------------------------------------------
+    const float* lang_vec = lam ? R.Wf("lang_embeddings.weight") + (size_t)lang_index * H : nullptr;
+    const float scaling = 1.0f / std::sqrt((float)(H / c.heads));
+    const int groups = (H + 511) / 512;
+    int64_t r0 = 0;
+    while (r0 < N && !R.rc) {
+        int64_t r1 = r0 + 1;
+        while (r1 < N && (int64_t)hoff[r1 + 1] - hoff[r0] <= MC) ++r1;
+        const int rows = (int)(r1 - r0);
+        const int tok0 = hoff[r0];
+        const int m = hoff[r1] - tok0;
+        h->stats.chunks += 1;
+
+        LnEmbed emb{TBL, p.tok_slot, p.tok_pos, R.Wf("model.embeddings.token_type_embeddings.weight"),
+                    R.Wf("model.embeddings.position_embeddings.weight"), lang_vec, seq};
+        hipLaunchKernelGGL((layernorm_rows_kernel<T, true>), dim3(m), dim3(256), 0, st, (const float*)nullptr, H, m, H,
+                           R.Wf("model.embeddings.LayerNorm.weight"), R.Wf("model.embeddings.LayerNorm.bias"),
+                           c.ln_eps_encoder, Zf, Zt, emb, tok0);
+        R.check("embed_layernorm");
+
+        int zrows = m;            // rows of the current hidden state (m packed, or `rows` once compact)
+        bool compact = false;
+        for (int l = 0; l < c.layers && !R.rc; ++l) {
+            const std::string lp = "model.encoder.layer." + std::to_string(l) + ".";
+            const bool cls_only = h->cls_only_last && l == c.layers - 1;
+            GemmEpilogue<T> eq = R.epi();
+            eq.bias = h->qkv_b[l]; eq.out_lo = BIG; eq.ld_lo = 3 * H;
+            R.gemm(Zt, H, (const T*)h->qkv_w[l], H, m, 3 * H, H, eq);
+            {
+                const int64_t waves = (int64_t)rows * groups;
+                hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
+                                   (const T*)BIG, H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0,
+                                   scaling, cls_only ? 1 : 0, CTX);
+                R.check("attention");
+            }
+            const float* resid = Zf;
+            if (cls_only) {   // only hidden[:,0] is consumed after this layer (modeling_hypernet.py:234)
+                hipLaunchKernelGGL((cls_gather_kernel<T>), dim3(rows), dim3(256), 0, st, (const float*)Zf, (const T*)nullptr, H,
+                                   p.row_offset, r0, rows, tok0, 0, Cf, (T*)nullptr, (const float*)nullptr,
+                                   (const float*)nullptr, (float*)nullptr);
+                R.check("cls_gather(residual)");
+                resid = Cf;
+                zrows = rows;
+                compact = true;
+            }
+            GemmEpilogue<T> eo = R.epi();
+            eo.bias = R.Wf(lp + "attention.output.dense.bias"); eo.residual = resid; eo.ld_res = H; eo.out_f32 = PRE; eo.ld_f32 = H;
+            R.gemm(CTX, H, R.Wlo(lp + "attention.output.dense.weight"), H, zrows, H, H, eo);
+            R.layernorm(PRE, zrows, R.Wf(lp + "attention.output.LayerNorm.weight"), R.Wf(lp + "attention.output.LayerNorm.bias"),
+                        c.ln_eps_encoder, Zf, Zt);
+            GemmEpilogue<T> ei = R.epi();
+            ei.bias = R.Wf(lp + "intermediate.dense.bias"); ei.act = ACT_GELU_ERF; ei.out_lo = BIG; ei.ld_lo = I;
+            R.gemm(Zt, H, R.Wlo(lp + "intermediate.dense.weight"), H, zrows, I, H, ei);
+            GemmEpilogue<T> ef = R.epi();
+            ef.bias = R.Wf(lp + "output.dense.bias"); ef.residual = Zf; ef.ld_res = H; ef.out_f32 = PRE; ef.ld_f32 = H;
+            R.gemm(BIG, I, R.Wlo(lp + "output.dense.weight"), I, zrows, H, I, ef);
+            R.layernorm(PRE, zrows, R.Wf(lp + "output.LayerNorm.weight"), R.Wf(lp + "output.LayerNorm.bias"),
+                        c.ln_eps_encoder, Zf, Zt);
+        }
+        if (R.rc) break;
+
+        // position-0 readout + bias head (modeling_hypernet.py:231-234, 260-265)
+        hipLaunchKernelGGL((cls_gather_kernel<T>), dim3(rows), dim3(256), 0, st, (const float*)Zf, (const T*)Zt, H,
+                           p.row_offset, r0, rows, tok0, compact ? 1 : 0, Cf, Ct,
+                           c.predict_bias ? R.Wf("bias_projection.weight") : (const float*)nullptr,
+                           c.predict_bias ? R.Wf("bias_projection.bias") : (const float*)nullptr, out_bias);
+        R.check("cls_gather");
+
+        // output heads (modeling_hypernet.py:236-258)
+        {
+            R.projector("output_projection.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX);
+            GemmEpilogue<T> e = R.epi();
+            e.bias = R.Wf("output_projection.1.bias");
+            e.scale = c.rescale ? h->head_scale : nullptr;
+            e.shift = c.rescale ? h->head_shift : nullptr;
+            e.out_f32 = out_in + (size_t)r0 * E; e.ld_f32 = E;
+            const int width = c.single_head ? EIN : E;
+            if (c.single_head && c.separate_out) { e.split_col = E; e.out_f32_b = out_out + (size_t)r0 * E; }
+            R.gemm(CTX, H, R.Wlo("output_projection.1.weight"), H, rows, width, H, e);
+        }
+        if (c.separate_out && !c.single_head) {
+            R.projector("output_projection_out.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX);
+            GemmEpilogue<T> e = R.epi();
+            e.bias = R.Wf("output_projection_out.1.bias");
+            e.scale = c.rescale ? R.Wf("out_scaler.w") : nullptr;
+            e.shift = c.rescale ? R.Wf("out_scaler.b") : nullptr;
+            e.out_f32 = out_out + (size_t)r0 * E; e.ld_f32 = E;
+            R.gemm(CTX, H, R.Wlo("output_projection_out.1.weight"), H, rows, E, H, e);
+        }
+        r0 = r1;
+    }
+    if (R.rc) return R.rc;
+
+    if (h->time_gemm) {
+        HIP_TRY(hipStreamSynchronize(st));
+        double ms = 0.0, fl = 0.0;
+        for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]) == hipSuccess) { ms += t; fl += h->ev_flops[i / 2]; }
+        }
+        h->stats.gemm_ms = ms;
+        h->stats.gemm_flops_timed = fl;
+    }
+    return 0;
+}
+
+}  // namespace

@@ -1,0 +1,251 @@
+"""``ZettHypernet`` — the hypernetwork behind the reference's ``AutoModel`` API,
+computing on MI355X through libzett_hip.so.
+
+Drop-in for hf_hypernet/modeling_hypernet.py:43-267:
+
+    hypernet = AutoModel.from_pretrained(path)          # after `import zett_amd`
+    pred_in, pred_out, bias = hypernet(target_surface_forms,
+                                       source_embeddings=source_embeddings,
+                                       lang_index=lang_index)
+
+Same config class fields, same ``state_dict`` names and shapes (so checkpoints
+written by scripts/convert_to_pt.py load unchanged), same call signature, return
+tuple and error behaviour.  The arithmetic runs in HIP kernels; this module only
+holds the parameters as torch tensors and hands device pointers across the C ABI.
+There is no CPU path: calling the model with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+from transformers import PreTrainedModel
+
+from . import _lib
+from .config import ZettHypernetConfig
+from .dims import PROJECTOR_LN_EPS, ROBERTA_LN_EPS, ROBERTA_MAX_POSITIONS, HypernetDims, weight_shapes
+
+_TORCH_TO_ZETT = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
+_PRECISIONS = {"bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16, "f32": _lib.PREC_F32,
+               "fp32": _lib.PREC_F32, "float32": _lib.PREC_F32}
+
+
+def _backbone_settings(name_or_path: str) -> Tuple[int, float]:
+    """max_position_embeddings / layer_norm_eps of the RoBERTa backbone config.
+
+    The reference reads them from ``RobertaConfig.from_pretrained(hn_model_name_or_path)``
+    (modeling_hypernet.py:67-69).  A local directory is honoured; otherwise the
+    roberta-base values apply (every shipped config uses roberta-base and there is no
+    network to fetch anything else).
+    """
+    path = os.path.join(str(name_or_path), "config.json")
+    if os.path.isfile(path):
+        with open(path) as f:
+            d = json.load(f)
+        return int(d.get("max_position_embeddings", ROBERTA_MAX_POSITIONS)), float(d.get("layer_norm_eps", ROBERTA_LN_EPS))
+    return ROBERTA_MAX_POSITIONS, ROBERTA_LN_EPS
+
+
+class _Node(nn.Module):
+    """Plain container: gives parameters the dotted names of the reference modules."""
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
+    *path, leaf = dotted.split(".")
+    node = root
+    for part in path:
+        child = node._modules.get(part)
+        if child is None:
+            child = _Node()
+            node.add_module(part, child)
+        node = child
+    node.register_parameter(leaf, param)
+
+
+class HipEngine:
+    """One libzett_hip handle: device + arithmetic mode + uploaded weights."""
+
+    def __init__(self, dims: HypernetDims, ln_eps_encoder: float, device: torch.device, precision: str):
+        if device.type != "cuda":
+            raise RuntimeError("zett_amd computes on MI355X only: tensors must live on a cuda (ROCm) device")
+        self.lib = _lib.load()
+        self.dims = dims
+        self.device = device
+        self.precision = precision
+        cfg = _lib.ZettConfig(
+            n_embd=dims.n_embd, n_in_embd=dims.n_in_embd, hidden=dims.hidden, intermediate=dims.intermediate,
+            heads=dims.heads, layers=dims.layers, n_extra=dims.n_extra, original_vocab_size=dims.original_vocab_size,
+            pad_token_id=dims.pad_token_id, separate_out=int(dims.separate_out), single_head=int(dims.single_head),
+            rescale=int(dims.rescale), predict_bias=int(dims.predict_bias), embed_lang=int(dims.embed_lang),
+            n_langs=dims.n_langs, max_positions=dims.max_positions, ln_eps_encoder=ln_eps_encoder,
+            ln_eps_projector=PROJECTOR_LN_EPS)
+        handle = C.c_void_p()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        _lib.check(self.lib.zett_create(C.byref(cfg), index, _PRECISIONS[precision], C.byref(handle)), "zett_create")
+        self.handle = handle
+
+    def load_weights(self, tensors: Dict[str, torch.Tensor]) -> None:
+        for name, t in tensors.items():
+            t = t.detach()
+            if t.dtype not in _TORCH_TO_ZETT:
+                t = t.float()
+            t = t.contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(self.lib.zett_load_weight(self.handle, name.encode(), C.c_void_p(t.data_ptr()),
+                                                 _TORCH_TO_ZETT[t.dtype], shape, t.dim()), f"zett_load_weight({name})")
+        _lib.check(self.lib.zett_finalize(self.handle), "zett_finalize")
+
+    def set_option(self, key: str, value: int) -> None:
+        _lib.check(self.lib.zett_set_option(self.handle, key.encode(), int(value)), f"zett_set_option({key})")
+
+    def stats(self) -> dict:
+        s = _lib.ZettStats()
+        _lib.check(self.lib.zett_get_stats(self.handle, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in s._fields_}
+
+    def forward(self, surface_forms: torch.Tensor, source_embeddings: torch.Tensor, lang_index: int):
+        d = self.dims
+        if surface_forms.dim() != 2:
+            raise ValueError("target_surface_forms must be [n_tokens, surface_maxlen]")
+        if surface_forms.device != self.device or source_embeddings.device != self.device:
+            raise RuntimeError(f"all tensors must be on {self.device}")
+        ids = surface_forms.to(torch.int32).contiguous()
+        src = source_embeddings
+        if src.dtype not in _TORCH_TO_ZETT:
+            src = src.float()
+        src = src.contiguous()
+        if src.dim() != 2 or src.shape[1] != d.n_in_embd:
+            raise ValueError(f"source_embeddings must be [V, {d.n_in_embd}], got {tuple(src.shape)}")
+        n, seq = ids.shape
+        out_in = torch.empty((n, d.n_embd), dtype=torch.float32, device=self.device)
+        out_out = torch.empty((n, d.n_embd), dtype=torch.float32, device=self.device) if d.separate_out else None
+        out_bias = torch.empty((n,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.zett_forward(
+                self.handle, C.c_void_p(ids.data_ptr()), n, seq, C.c_void_p(src.data_ptr()),
+                _TORCH_TO_ZETT[src.dtype], src.shape[0], int(lang_index),
+                C.c_void_p(out_in.data_ptr()), C.c_void_p(out_out.data_ptr() if out_out is not None else 0),
+                C.c_void_p(out_bias.data_ptr()), C.c_void_p(stream))
+        _lib.check(rc, "zett_forward")
+        return out_in, out_out, out_bias
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.zett_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ZettHypernet(PreTrainedModel):
+    config_class = ZettHypernetConfig
+    base_model_prefix = ""
+    _no_split_modules = []
+
+    def __init__(self, config: ZettHypernetConfig):
+        super().__init__(config)
+        if getattr(config, "hn_model_type", "roberta") != "roberta":
+            raise NotImplementedError()                          # modeling_hypernet.py:78-79
+        if getattr(config, "hn_add_inter_token_attention", False) or getattr(config, "hn_embed_target_priors", False):
+            raise NotImplementedError()                          # modeling_hypernet.py:85-89
+        assert getattr(config, "pad_token_id", None) is not None  # modeling_hypernet.py:92
+        if getattr(config, "hn_num_attention_heads", None) is None:
+            config.hn_num_attention_heads = config.hn_hidden_size // 64   # modeling_hypernet.py:73-74
+        self.has_separate_out_embeddings = getattr(config, "separate_out_embeddings", False)
+        self.pad_token_id = config.pad_token_id
+        max_pos, ln_eps = _backbone_settings(getattr(config, "hn_model_name_or_path", "roberta-base"))
+        self._ln_eps_encoder = ln_eps
+        self.dims = HypernetDims.from_config(config, max_positions=max_pos)
+        # arithmetic of the dense contractions: "bf16" (MFMA bf16, fp32 accumulate) or "f32"
+        self.precision = os.environ.get("ZETT_PRECISION", getattr(config, "zett_precision", None) or "bf16")
+        for name, shape in weight_shapes(self.dims).items():
+            _attach(self, name, nn.Parameter(torch.empty(shape, dtype=torch.float32), requires_grad=False))
+        self._engines: Dict[Tuple[str, str], HipEngine] = {}
+        self._reset_parameters()
+        self.post_init()
+
+    # ---- parameter initialisation (same distributions as the torch modules of the reference)
+    def _reset_parameters(self) -> None:
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if p.device.type == "meta":
+                    continue
+                leaf = name.rsplit(".", 1)[-1]
+                if name.endswith("LayerNorm.weight") or name.endswith("ln.weight") or "scaler." in name:
+                    p.fill_(1.0)                                  # Rescaler w and b start at ones (:15-16)
+                elif name.endswith("LayerNorm.bias") or name.endswith("ln.bias") or leaf == "bias":
+                    p.zero_()
+                else:
+                    p.normal_(mean=0.0, std=0.02)
+
+    def _init_weights(self, module) -> None:     # parameters are initialised in __init__
+        return
+
+    # ---- engine management ---------------------------------------------------------------
+    def _drop_engines(self) -> None:
+        for eng in self._engines.values():
+            eng.close()
+        self._engines.clear()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, "_engines"):
+            self._drop_engines()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._drop_engines()
+        return out
+
+    def refresh_weights(self) -> None:
+        """Re-upload parameters after they were modified in place."""
+        self._drop_engines()
+
+    def engine(self, device: torch.device, precision: Optional[str] = None) -> HipEngine:
+        precision = precision or self.precision
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        key = (str(device), precision)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = HipEngine(self.dims, self._ln_eps_encoder, device, precision)
+            eng.load_weights({n: p.data for n, p in self.named_parameters()})
+            self._engines[key] = eng
+        return eng
+
+    # ---- the forward ----------------------------------------------------------------------
+    def forward(self, target_surface_forms, target_priors=None, source_embeddings=None, lang_index=None,
+                deterministic: bool = True):
+        if target_priors is not None:
+            raise NotImplementedError()                          # modeling_hypernet.py:164-165
+        if not getattr(self.config, "hn_embed_using_source_embeddings", False):
+            raise NotImplementedError()                          # modeling_hypernet.py:167-168
+        if getattr(self.config, "hn_concat_last_hidden_state", False):
+            raise NotImplementedError("hn_concat_last_hidden_state is not set by any shipped config")
+        if source_embeddings is None:
+            raise ValueError("source_embeddings is required")
+        if not torch.is_tensor(target_surface_forms):
+            target_surface_forms = torch.as_tensor(target_surface_forms)
+        device = source_embeddings.device
+        if device.type != "cuda":
+            raise RuntimeError("zett_amd computes on MI355X only: move target_surface_forms and "
+                               "source_embeddings to a cuda (ROCm) device; there is no CPU path")
+        if target_surface_forms.device != device:
+            target_surface_forms = target_surface_forms.to(device)
+        if self.dims.embed_lang:
+            if lang_index is None:
+                raise ValueError("this hypernetwork embeds a language id: lang_index is required")
+            lang = int(lang_index.item()) if torch.is_tensor(lang_index) else int(lang_index)
+        else:
+            lang = -1
+        return self.engine(device).forward(target_surface_forms, source_embeddings, lang)
