@@ -1,0 +1,45 @@
+"""Differential test of the retokenizer oracle against the installed HF `tokenizers`
+wheel — the third-party library whose Model.tokenize the reference calls
+(zett/utils.py:681).  Random BPE / Unigram models with every option combination."""
+import random
+
+import pytest
+
+from oracle import retok_ref
+from tests import retok_random as rr
+
+tokenizers = pytest.importorskip("tokenizers")
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_oracle_equals_tokenizers_library(seed):
+    rng = random.Random(seed)
+    for make in (rr.random_bpe, rr.random_unigram):
+        model_json = make(rng)
+        lib_model = rr.build_tokenizers_model(model_json)
+        model = retok_ref.model_from_tokenizer_json(model_json)
+        tokens = rr.random_tokens(rng, 80)
+        want = [[t.id for t in lib_model.tokenize(tok)] for tok in tokens]
+        got_py = [retok_ref.tokenize(model, retok_ref.token_to_bytes(tok)) for tok in tokens]
+        assert got_py == want
+        mat, _ = retok_ref.surface_form_matrix_c(model, tokens, 16, -7)
+        for row, w in zip(mat, want):
+            assert list(row[:len(w)]) == w[:16] and all(x == -7 for x in row[len(w):])
+
+
+def test_known_answers():
+    """Tie-breaks / drops probed on tokenizers 0.22.2."""
+    m = retok_ref.model_from_tokenizer_json({"type": "Unigram", "unk_id": 0, "byte_fallback": False, "vocab": [
+        ["<unk>", 0.0], ["a", -1.0], ["b", -1.0], ["ab", -2.0], ["c", -1.0], ["bc", -2.0], ["abc", -3.0]]})
+    assert retok_ref.tokenize(m, b"ab") == [3]            # `ab`(-2) beats `a`+`b`(-1-1): earliest start wins ties
+    assert retok_ref.tokenize(m, b"abc") == [6]
+    assert retok_ref.tokenize(m, b"axxb") == [1, 0, 2]     # consecutive unknowns fuse
+    b = retok_ref.model_from_tokenizer_json({"type": "BPE", "vocab": {"a": 0, "b": 1, "c": 2, "ab": 3, "bc": 4, "abc": 5},
+                                             "merges": [["a", "b"], ["b", "c"], ["ab", "c"]]})
+    assert retok_ref.tokenize(b, b"bcab") == [4, 3]
+    assert retok_ref.tokenize(b, b"axb") == [3]            # unknown char silently dropped when there is no unk token
+    v = {"a": 0, "b": 1, "c": 2, "abc": 3, "ab": 4}
+    ign = retok_ref.model_from_tokenizer_json({"type": "BPE", "vocab": v, "merges": [["a", "b"]], "ignore_merges": True})
+    assert retok_ref.tokenize(ign, b"abc") == [3]
+    noign = retok_ref.model_from_tokenizer_json({"type": "BPE", "vocab": v, "merges": [["a", "b"]]})
+    assert retok_ref.tokenize(noign, b"abc") == [4, 2]
