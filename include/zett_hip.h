@@ -143,6 +143,8 @@ typedef struct zett_retok_model {
     const int32_t* piece_offsets;  /* host: n_pieces + 1                           */
     const int32_t* piece_ids;      /* host: vocabulary id of each piece            */
     const double* piece_scores;    /* host: Unigram log-probs (NULL for BPE)       */
+    double unigram_min_score;      /* Unigram: min score over the WHOLE vocabulary (also pieces
+                                      omitted above); unknown pieces score min - 10 */
     int32_t n_merges;              /* BPE                                          */
     const int32_t* merges;         /* host: n_merges x 3 (left id, right id, new id), rank = row */
     int32_t unk_id;                /* -1 = none                                    */

@@ -1,0 +1,113 @@
+"""GPU parity of the retokenizer (get_surface_form_matrix through the C ABI): bit-exact
+against the reference's outputs (golden fixtures) and against the oracle on random models."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import retok_ref
+from tests import retok_random as rr
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+RETOK = sorted(p for p in os.listdir(util.GOLDEN) if p.startswith("retok_") and p.endswith(".json"))
+
+
+def _spec(g):
+    from zett_amd.surface_forms import HnTokenizerSpec
+    return HnTokenizerSpec.from_model_json(g["model"], g["special_tokens"], g["special_ids"], g["pad_token_id"])
+
+
+@pytest.mark.parametrize("name", RETOK)
+def test_golden_matrix(name):
+    from zett_amd.surface_forms import get_surface_form_matrix
+    g = json.load(open(os.path.join(util.GOLDEN, name)))
+    got, n_tr = get_surface_form_matrix(g["tokens"], g["maxlen"], _spec(g))
+    assert got.dtype == np.int32
+    np.testing.assert_array_equal(got, np.array(g["expected"], dtype=np.int32))
+    assert n_tr == g["n_truncated"]
+
+
+def test_padding_rows_and_tokenizer_object():
+    """`padding` extra rows (zett/utils.py:662-666) and the transformers-tokenizer entry point."""
+    from tokenizers import Tokenizer
+    from transformers import PreTrainedTokenizerFast
+
+    from zett_amd.surface_forms import get_surface_form_matrix
+    g = json.load(open(os.path.join(util.GOLDEN, "retok_unigram.json")))
+    tok = Tokenizer.from_str(json.dumps({"version": "1.0", "truncation": None, "padding": None, "added_tokens": [],
+                                         "normalizer": None, "pre_tokenizer": None, "post_processor": None,
+                                         "decoder": None, "model": g["model"]}))
+    hf = PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", unk_token="<unk>", pad_token="<pad>")
+    assert hf.pad_token_id == g["pad_token_id"]
+    got, n_tr = get_surface_form_matrix(g["tokens"], g["maxlen"], hf, padding=5)
+    want = np.array(g["expected"], dtype=np.int32)
+    assert got.shape == (len(want) + 5, g["maxlen"])
+    np.testing.assert_array_equal(got[:len(want)], want)
+    assert (got[len(want):] == g["pad_token_id"]).all()
+    assert n_tr == g["n_truncated"]
+
+
+def test_keyerror_names_the_character():
+    from zett_amd.surface_forms import get_surface_form_matrix
+    g = json.load(open(os.path.join(util.GOLDEN, "retok_bytebpe.json")))
+    with pytest.raises(KeyError) as e:
+        get_surface_form_matrix(["fine", "Ġalso", "not▁byte"], 7, _spec(g))
+    assert e.value.args[0] == "▁"
+    with pytest.raises(KeyError):
+        get_surface_form_matrix(["a b"], 7, _spec(g))      # a raw space is not in the alphabet
+
+
+def test_empty_inputs():
+    from zett_amd.surface_forms import get_surface_form_matrix
+    g = json.load(open(os.path.join(util.GOLDEN, "retok_bytebpe.json")))
+    got, n_tr = get_surface_form_matrix([], 7, _spec(g))
+    assert got.shape == (0, 7) and n_tr == 0
+    got, n_tr = get_surface_form_matrix(["", "", ""], 7, _spec(g))
+    assert (got == g["pad_token_id"]).all() and n_tr == 0
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_models_match_oracle(seed):
+    from zett_amd.surface_forms import HnTokenizerSpec, get_surface_form_matrix
+    rng = random.Random(1000 + seed)
+    for make in (rr.random_bpe, rr.random_unigram):
+        model_json = make(rng, 80)
+        specials, special_ids = (["<unk>"], [model_json["vocab"]["<unk>"]]) if isinstance(model_json["vocab"], dict) and "<unk>" in model_json["vocab"] else ([], [])
+        tokens = rr.random_tokens(rng, 300, maxlen=40) + rr.random_tokens(rng, 20, maxlen=300) + specials
+        oracle_model = retok_ref.model_from_tokenizer_json(model_json, specials, special_ids)
+        want, want_tr = retok_ref.surface_form_matrix_c(oracle_model, tokens, 9, 77)
+        spec = HnTokenizerSpec.from_model_json(model_json, specials, special_ids, 77)
+        got, got_tr = get_surface_form_matrix(tokens, 9, spec)
+        np.testing.assert_array_equal(got, want)
+        assert got_tr == want_tr
+
+
+def test_unigram_without_unk_raises():
+    from zett_amd.surface_forms import HnTokenizerSpec, get_surface_form_matrix
+    model = {"type": "Unigram", "unk_id": None, "byte_fallback": False, "vocab": [["a", -1.0], ["b", -1.0]]}
+    spec = HnTokenizerSpec.from_model_json(model, [], [], 0)
+    got, _ = get_surface_form_matrix(["ab", "ba"], 4, spec)
+    np.testing.assert_array_equal(got, [[0, 1, 0, 0], [1, 0, 0, 0]])
+    with pytest.raises(Exception, match="unk_id"):
+        get_surface_form_matrix(["ab", "azb"], 4, spec)
+
+
+def test_full_size_vocab_matches_oracle():
+    """50k-token target vocabulary against the C oracle (size of the GPT-2 / GPT-NeoX configs)."""
+    from zett_amd.surface_forms import get_surface_form_matrix
+    g = json.load(open(os.path.join(util.GOLDEN, "retok_mistral_like.json")))
+    rng = random.Random(5)
+    base = [t for t in g["tokens"] if t not in g["special_tokens"] and t]
+    tokens = list(g["tokens"])
+    while len(tokens) < 50000:
+        a, b = rng.choice(base), rng.choice(base)
+        tokens.append((a + b)[:rng.randint(1, 24)])
+    oracle_model = retok_ref.model_from_tokenizer_json({"model": g["model"]}, g["special_tokens"], g["special_ids"])
+    want, want_tr = retok_ref.surface_form_matrix_c(oracle_model, tokens, 7, g["pad_token_id"])
+    got, got_tr = get_surface_form_matrix(tokens, 7, _spec(g))
+    np.testing.assert_array_equal(got, want)
+    assert got_tr == want_tr

@@ -42,7 +42,7 @@ class ZettRetokModel(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("n_pieces", C.c_int32),
         ("piece_bytes", C.c_void_p), ("piece_offsets", C.c_void_p), ("piece_ids", C.c_void_p),
-        ("piece_scores", C.c_void_p),
+        ("piece_scores", C.c_void_p), ("unigram_min_score", C.c_double),
         ("n_merges", C.c_int32), ("merges", C.c_void_p),
         ("unk_id", C.c_int32), ("fuse_unk", C.c_int32), ("byte_fallback", C.c_int32),
         ("byte_fallback_ids", C.c_void_p), ("ignore_merges", C.c_int32),

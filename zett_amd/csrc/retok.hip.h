@@ -1,13 +1,594 @@
-// retok.hip.h — placeholder until the retokenizer kernels land.
+// retok.hip.h — get_surface_form_matrix on the device (reference zett/utils.py:651-689).
+//
+// Two stages, both HBM/latency-bound integer work (no MFMA here):
+//
+//  1. chars -> bytes.  The target tokens arrive as UTF-8 text of byte-level characters
+//     (the GPT-2 printable-character alphabet, zett/utils.py:351-609).  A workgroup
+//     takes 4 KiB of text with coalesced 16-byte loads, marks character starts, looks
+//     every character up in the byte table staged in LDS, and compacts the bytes with a
+//     wavefront scan (DPP-free shuffles inside a wave, LDS across the 4 waves); block
+//     totals are chained by one tiny scan launch.  A character outside the table is the
+//     reference's KeyError (zett/utils.py:675).
+//
+//  2. bytes -> source-subtoken ids, one lane per token: special-token lookup
+//     (zett/utils.py:671-673) or the hn tokenizer's bare model (zett/utils.py:681):
+//       BPE      tokenizers `BPE::tokenize`: merge_word (byte fallback / unk / drop) then
+//                Word::merge_all with its (rank, position) priority order and its
+//                expired-entry rule, on open-addressing pair tables;
+//       Unigram  tokenizers `Unigram::tokenize`: Viterbi over an FNV-hashed piece table
+//                (strictly-greater updates, start positions ascending => earliest start
+//                wins ties), unknown runs fused, optional byte fallback;
+//     then truncation to maxlen with the n_truncated count (zett/utils.py:683-685).
+//
+// Results are integers: bit-exact against the oracle and the reference by construction.
 #pragma once
-#include "common.hip.h"
 
-struct zett_retok { int device; };
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.hip.h"
+#include "rowops.hip.h"
+
+namespace zett {
+
+struct PieceEntry {
+    uint64_t hash;
+    int32_t off;
+    int32_t len;      // 0 = empty slot
+    int32_t id;
+    int32_t pad_;
+    double score;
+};
+
+struct MergeEntry {
+    int32_t a, b;     // a == -1: empty slot
+    int32_t rank, new_id;
+};
+
+struct RetokTables {
+    const PieceEntry* pieces; uint32_t piece_mask; const uint8_t* piece_blob;
+    const PieceEntry* specials; uint32_t special_mask; const uint8_t* special_blob;
+    const MergeEntry* merges; uint32_t merge_mask;
+    const int32_t* single_id;     // [256] id of the one-byte piece or -1
+    const int32_t* bf_ids;        // [256] id of "<0xXX>" or -1
+    const int16_t* cp_to_byte;    // [324] code point -> byte or -1
+    int kind, unk_id, fuse_unk, byte_fallback, ignore_merges, max_piece_len;
+    double unk_score;             // min_score - kUnkPenalty
+};
+
+constexpr uint64_t FNV_OFFSET = 14695981039346656037ull;
+constexpr uint64_t FNV_PRIME = 1099511628211ull;
+
+__host__ __device__ inline uint64_t fnv_step(uint64_t h, uint8_t b) { return (h ^ b) * FNV_PRIME; }
+__host__ __device__ inline uint32_t piece_slot(uint64_t h, uint32_t mask) { return (uint32_t)(h ^ (h >> 32)) & mask; }
+__host__ __device__ inline uint32_t merge_slot(int32_t a, int32_t b, uint32_t mask) {
+    const uint64_t k = (((uint64_t)(uint32_t)a) << 32 | (uint32_t)b) * 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(k >> 32) & mask;
+}
+
+__device__ inline const PieceEntry* piece_find(const PieceEntry* tab, uint32_t mask, const uint8_t* blob, uint64_t h,
+                                               const uint8_t* s, int len) {
+    for (uint32_t slot = piece_slot(h, mask);; slot = (slot + 1) & mask) {
+        const PieceEntry* e = tab + slot;
+        if (e->len == 0) return nullptr;
+        if (e->hash == h && e->len == len) {
+            const uint8_t* p = blob + e->off;
+            int i = 0;
+            while (i < len && p[i] == s[i]) ++i;
+            if (i == len) return e;
+        }
+    }
+}
+
+__device__ inline const MergeEntry* merge_find(const RetokTables& t, int32_t a, int32_t b) {
+    if (t.merge_mask == 0xffffffffu) return nullptr;   // no merges at all
+    for (uint32_t slot = merge_slot(a, b, t.merge_mask);; slot = (slot + 1) & t.merge_mask) {
+        const MergeEntry* e = t.merges + slot;
+        if (e->a == -1) return nullptr;
+        if (e->a == a && e->b == b) return e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// stage 1: UTF-8 byte-level characters -> raw bytes
+// ---------------------------------------------------------------------------------------
+constexpr int CH_PER_THREAD = 16;
+constexpr int CH_PER_BLOCK = 256 * CH_PER_THREAD;
+
+__device__ inline int block_excl_scan_256(int v, int* total, int* lds /* [4] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int n = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += n;
+    }
+    __syncthreads();
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += lds[w];
+    *total = lds[0] + lds[1] + lds[2] + lds[3];
+    return base + inc - v;
+}
+
+// MODE 0: count character starts per block.  MODE 1: decode + compact.
+template <int MODE>
+__global__ __launch_bounds__(256) void chars_to_bytes_kernel(const uint8_t* __restrict__ text, int64_t n_text,
+                                                             const int16_t* __restrict__ cp_to_byte,
+                                                             int32_t* __restrict__ blk_count,      // MODE 0 out / MODE 1 in (scanned)
+                                                             uint8_t* __restrict__ raw, uint32_t* __restrict__ raw_pos,
+                                                             int32_t* __restrict__ err_pos) {
+    __shared__ int16_t s_tab[324];
+    __shared__ int s_red[4];
+    __shared__ uint8_t s_next[256];        // first byte of the following thread's span
+    if (MODE == 1)
+        for (int i = threadIdx.x; i < 324; i += 256) s_tab[i] = cp_to_byte[i];
+    const int64_t base = (int64_t)blockIdx.x * CH_PER_BLOCK + (int64_t)threadIdx.x * CH_PER_THREAD;
+    uint8_t b[CH_PER_THREAD + 1];
+    if (base + CH_PER_THREAD <= n_text && ((uintptr_t)(text + base) & 15) == 0) {
+        const uint4 v = *(const uint4*)(text + base);
+        memcpy(b, &v, 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < CH_PER_THREAD; ++i) b[i] = (base + i < n_text) ? text[base + i] : 0x80;   // 0x80: never a start
+    }
+    if (MODE == 1) {
+        s_next[threadIdx.x] = b[0];
+        __syncthreads();
+        if (threadIdx.x < 255) b[CH_PER_THREAD] = s_next[threadIdx.x + 1];
+        else b[CH_PER_THREAD] = (base + CH_PER_THREAD < n_text) ? text[base + CH_PER_THREAD] : 0;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < CH_PER_THREAD; ++i) cnt += (base + i < n_text) && ((b[i] & 0xC0) != 0x80);
+    int total = 0;
+    const int excl = block_excl_scan_256(cnt, &total, s_red);
+    if (MODE == 0) {
+        if (threadIdx.x == 0) blk_count[blockIdx.x] = total;
+        return;
+    }
+    uint32_t pos = (uint32_t)blk_count[blockIdx.x] + (uint32_t)excl;
+#pragma unroll
+    for (int i = 0; i < CH_PER_THREAD; ++i) {
+        if (base + i >= n_text) break;
+        raw_pos[base + i] = pos;                                   // characters before text[base+i]
+        const uint8_t c = b[i];
+        if ((c & 0xC0) == 0x80) continue;                          // continuation byte
+        int cp = -1;
+        if (c < 0x80) cp = c;
+        else if (c >= 0xC2 && c <= 0xDF && (b[i + 1] & 0xC0) == 0x80 && base + i + 1 < n_text) cp = ((c & 0x1F) << 6) | (b[i + 1] & 0x3F);
+        const int byte = (cp >= 0 && cp < 324) ? s_tab[cp] : -1;
+        if (byte < 0) atomicMin(err_pos, (int32_t)(base + i < 0x7fffffff ? base + i : 0x7ffffffe));
+        raw[pos] = (uint8_t)(byte < 0 ? 0 : byte);
+        ++pos;
+    }
+}
+
+__global__ void token_raw_offsets_kernel(const int32_t* __restrict__ offsets, int64_t n_tokens, int64_t n_text,
+                                         const uint32_t* __restrict__ raw_pos, const int32_t* __restrict__ blk_scan,
+                                         int n_blocks, int32_t* __restrict__ raw_off) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tokens) return;
+    const int64_t o = offsets[t];
+    raw_off[t] = (o >= n_text) ? blk_scan[n_blocks] : (int32_t)raw_pos[o];
+}
+
+__global__ void fill_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// stage 2: one lane per token
+// ---------------------------------------------------------------------------------------
+struct RetokLds {
+    int32_t single_id[256];
+    int32_t bf_ids[256];
+};
+
+// UTF-8 bytes of the printable character standing for raw byte b
+__device__ inline int byte_char_utf8(int b, uint8_t out[2]) {
+    int cp;
+    if ((b >= 33 && b <= 126) || (b >= 161 && b <= 172) || (b >= 174)) cp = b;
+    else if (b <= 32) cp = 256 + b;
+    else if (b <= 160) cp = 256 + 33 + (b - 127);
+    else cp = 256 + 33 + 34;                                        // b == 173
+    if (cp < 0x80) { out[0] = (uint8_t)cp; return 1; }
+    out[0] = (uint8_t)(0xC0 | (cp >> 6));
+    out[1] = (uint8_t)(0x80 | (cp & 0x3F));
+    return 2;
+}
+
+__device__ inline bool fallback_pair(const RetokLds& L, int b, int32_t out[2], int* n) {
+    uint8_t u[2];
+    const int nu = byte_char_utf8(b, u);
+    for (int k = 0; k < nu; ++k) {
+        const int32_t id = L.bf_ids[u[k]];
+        if (id < 0) return false;
+        out[k] = id;
+    }
+    *n = nu;
+    return true;
+}
+
+struct RowWriter {
+    int32_t* row;
+    int maxlen;
+    int n;
+    __device__ void push(int32_t id) { if (n < maxlen) row[n] = id; ++n; }
+};
+
+// scratch layout per token: region of SCR_PER_BYTE * len + SCR_FIXED int32 words
+constexpr int SCR_PER_BYTE = 24;
+constexpr int SCR_FIXED = 16;
+
+__device__ void bpe_token(const RetokTables& t, const RetokLds& L, const uint8_t* raw, int len, int32_t* scr, RowWriter& w) {
+    if (t.ignore_merges) {
+        uint64_t h = FNV_OFFSET;
+        for (int i = 0; i < len; ++i) h = fnv_step(h, raw[i]);
+        const PieceEntry* e = piece_find(t.pieces, t.piece_mask, t.piece_blob, h, raw, len);
+        if (e) { w.push(e->id); return; }
+    }
+    const int cap = 2 * len + 1;
+    int32_t* c = scr;                 // symbol ids, -1 = removed
+    int32_t* prev = c + cap;
+    int32_t* next = prev + cap;
+    int32_t* q = next + cap;          // queue triples (rank, pos, new_id), capacity 3*cap
+    int n = 0;
+    bool unk_pending = false;
+    for (int i = 0; i < len; ++i) {   // merge_word
+        const int b = raw[i];
+        const int32_t id = L.single_id[b];
+        if (id >= 0) {
+            if (unk_pending) { c[n++] = t.unk_id; unk_pending = false; }
+            c[n++] = id;
+            continue;
+        }
+        if (t.byte_fallback) {
+            int32_t fb[2]; int nfb = 0;
+            if (fallback_pair(L, b, fb, &nfb)) {            // a pending unk is not flushed first (library behaviour)
+                for (int k = 0; k < nfb; ++k) c[n++] = fb[k];
+                continue;
+            }
+        }
+        if (t.unk_id >= 0) {
+            if (unk_pending && !t.fuse_unk) c[n++] = t.unk_id;
+            unk_pending = true;
+        }
+    }
+    if (unk_pending) c[n++] = t.unk_id;
+    for (int i = 0; i < n; ++i) { prev[i] = i - 1; next[i] = (i + 1 < n) ? i + 1 : -1; }
+    int nq = 0;
+    for (int i = 0; i + 1 < n; ++i) {
+        const MergeEntry* e = merge_find(t, c[i], c[i + 1]);
+        if (e) { q[3 * nq] = e->rank; q[3 * nq + 1] = i; q[3 * nq + 2] = e->new_id; ++nq; }
+    }
+    while (nq > 0) {                  // Word::merge_all
+        int best = 0;
+        for (int i = 1; i < nq; ++i)
+            if (q[3 * i] < q[3 * best] || (q[3 * i] == q[3 * best] && q[3 * i + 1] < q[3 * best + 1])) best = i;
+        const int pos = q[3 * best + 1], new_id = q[3 * best + 2];
+        --nq;
+        q[3 * best] = q[3 * nq]; q[3 * best + 1] = q[3 * nq + 1]; q[3 * best + 2] = q[3 * nq + 2];
+        if (c[pos] < 0 || next[pos] == -1) continue;
+        const int r = next[pos];
+        const MergeEntry* e = merge_find(t, c[pos], c[r]);
+        if (!e || e->new_id != new_id) continue;             // expired entry: compared by new id only
+        c[pos] = new_id;
+        c[r] = -1;
+        next[pos] = next[r];
+        if (next[r] != -1) prev[next[r]] = pos;
+        if (prev[pos] >= 0) {
+            e = merge_find(t, c[prev[pos]], c[pos]);
+            if (e) { q[3 * nq] = e->rank; q[3 * nq + 1] = prev[pos]; q[3 * nq + 2] = e->new_id; ++nq; }
+        }
+        if (next[pos] != -1) {
+            e = merge_find(t, c[pos], c[next[pos]]);
+            if (e) { q[3 * nq] = e->rank; q[3 * nq + 1] = pos; q[3 * nq + 2] = e->new_id; ++nq; }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (c[i] >= 0) w.push(c[i]);
+}
+
+// returns false on "unknown token but unk_id is missing"
+__device__ bool unigram_token(const RetokTables& t, const RetokLds& L, const uint8_t* raw, int len, int32_t* scr, RowWriter& w) {
+    double* best = (double*)scr;                   // [len+1]   (scr is 8-byte aligned)
+    int32_t* bstart = (int32_t*)(best + len + 1);  // [len+1]
+    int32_t* bid = bstart + len + 1;               // [len+1]  piece id, -2 = unknown
+    int32_t* fwd = bid + len + 1;                  // [len+1]  forward links of the best path
+    for (int i = 0; i <= len; ++i) { best[i] = 0.0; bstart[i] = -1; bid[i] = -1; }
+    for (int s = 0; s < len; ++s) {
+        const double base = best[s];
+        bool has_single = false;
+        const int emax = (s + t.max_piece_len < len) ? s + t.max_piece_len : len;
+        uint64_t h = FNV_OFFSET;
+        for (int e = s + 1; e <= emax; ++e) {
+            h = fnv_step(h, raw[e - 1]);
+            const PieceEntry* p = piece_find(t.pieces, t.piece_mask, t.piece_blob, h, raw + s, e - s);
+            if (!p) continue;
+            const double cand = p->score + base;
+            if (bstart[e] == -1 || cand > best[e]) { best[e] = cand; bstart[e] = s; bid[e] = p->id; }
+            if (e == s + 1) has_single = true;
+        }
+        if (!has_single) {
+            if (t.unk_id < 0) return false;
+            const double cand = t.unk_score + base;
+            const int e = s + 1;
+            if (bstart[e] == -1 || cand > best[e]) { best[e] = cand; bstart[e] = s; bid[e] = -2; }
+        }
+    }
+    for (int e = len; e > 0; e = bstart[e]) fwd[bstart[e]] = e;
+    for (int s = 0; s < len;) {
+        int e = fwd[s];
+        if (bid[e] != -2) { w.push(bid[e]); s = e; continue; }
+        int fe = e;                                 // fuse the run of unknown pieces
+        while (fe < len && bid[fwd[fe]] == -2) fe = fwd[fe];
+        bool ok = t.byte_fallback != 0;
+        if (ok) {
+            for (int i = s; i < fe && ok; ++i) { int32_t fb[2]; int nfb; ok = fallback_pair(L, raw[i], fb, &nfb); }
+        }
+        if (ok) {
+            for (int i = s; i < fe; ++i) { int32_t fb[2]; int nfb = 0; fallback_pair(L, raw[i], fb, &nfb); for (int k = 0; k < nfb; ++k) w.push(fb[k]); }
+        } else {
+            w.push(t.unk_id);
+        }
+        s = fe;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const uint8_t* __restrict__ raw,
+                                                          const int32_t* __restrict__ raw_off, int64_t n_tokens,
+                                                          int maxlen, int32_t* __restrict__ out, int32_t* __restrict__ scratch,
+                                                          unsigned long long* __restrict__ n_truncated,
+                                                          int32_t* __restrict__ err_unk) {
+    __shared__ RetokLds L;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) { L.single_id[i] = t.single_id[i]; L.bf_ids[i] = t.bf_ids[i]; }
+    __syncthreads();
+    const int64_t tok = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tok >= n_tokens) return;
+    const int o0 = raw_off[tok], len = raw_off[tok + 1] - o0;
+    const uint8_t* s = raw + o0;
+    RowWriter w{out + tok * maxlen, maxlen, 0};
+    if (len > 0 && t.special_mask != 0xffffffffu) {          // zett/utils.py:671-673
+        uint64_t h = FNV_OFFSET;
+        for (int i = 0; i < len; ++i) h = fnv_step(h, s[i]);
+        const PieceEntry* e = piece_find(t.specials, t.special_mask, t.special_blob, h, s, len);
+        if (e) { w.row[0] = e->id; return; }
+    }
+    if (len == 0) return;
+    int32_t* scr = scratch + ((int64_t)o0 * SCR_PER_BYTE + tok * SCR_FIXED);
+    if (t.kind == ZETT_RETOK_BPE) {
+        bpe_token(t, L, s, len, scr, w);
+    } else if (!unigram_token(t, L, s, len, scr, w)) {
+        atomicMax(err_unk, (int32_t)(tok < 0x7ffffffe ? tok + 1 : 0x7fffffff));
+        return;
+    }
+    if (w.n > maxlen) atomicAdd(n_truncated, 1ull);          // zett/utils.py:683-685
+}
+
+}  // namespace zett
+
+// =========================================================================================
+// host side
+// =========================================================================================
+struct zett_retok {
+    int device = 0;
+    zett::RetokTables t{};
+    std::vector<void*> owned;
+    zett::DevBuf raw, raw_pos, raw_off, blk, scratch, misc;
+    int32_t* host_pinned = nullptr;
+};
+
+namespace zett {
+
+inline uint32_t pow2_capacity(size_t n) {
+    uint32_t c = 16;
+    while (c < 2 * n + 2) c <<= 1;
+    return c;
+}
+
+struct HostPieceTable {
+    std::vector<PieceEntry> slots;
+    std::vector<uint8_t> blob;
+    uint32_t mask = 0xffffffffu;
+    int max_len = 0;
+};
+
+inline void build_piece_table(const uint8_t* bytes, const int32_t* offsets, const int32_t* ids, const double* scores, int n,
+                              HostPieceTable& out, int32_t* single_id /* nullable */) {
+    // duplicates: the LAST listed piece wins (tokenizers inserts into a HashMap in listing order)
+    std::unordered_map<std::string, int> last;
+    last.reserve((size_t)n * 2);
+    for (int i = 0; i < n; ++i) {
+        const int len = offsets[i + 1] - offsets[i];
+        if (len <= 0) continue;
+        last[std::string((const char*)bytes + offsets[i], (size_t)len)] = i;
+    }
+    if (last.empty()) return;
+    const uint32_t cap = pow2_capacity(last.size());
+    out.mask = cap - 1;
+    out.slots.assign(cap, PieceEntry{0, 0, 0, 0, 0, 0.0});
+    for (auto& kv : last) {
+        const int i = kv.second;
+        const int len = (int)kv.first.size();
+        uint64_t h = FNV_OFFSET;
+        for (int k = 0; k < len; ++k) h = fnv_step(h, (uint8_t)kv.first[k]);
+        PieceEntry e{h, (int32_t)out.blob.size(), len, ids[i], 0, scores ? scores[i] : 0.0};
+        out.blob.insert(out.blob.end(), kv.first.begin(), kv.first.end());
+        uint32_t slot = piece_slot(h, out.mask);
+        while (out.slots[slot].len != 0) slot = (slot + 1) & out.mask;
+        out.slots[slot] = e;
+        if (len > out.max_len) out.max_len = len;
+        if (single_id && len == 1) single_id[(uint8_t)kv.first[0]] = ids[i];
+    }
+}
+
+template <typename U>
+inline int upload(zett_retok* r, const std::vector<U>& v, const U** dev) {
+    *dev = nullptr;
+    if (v.empty()) return 0;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, v.size() * sizeof(U)));
+    r->owned.push_back(p);
+    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice));
+    *dev = (const U*)p;
+    return 0;
+}
+
+}  // namespace zett
 
 extern "C" {
-int zett_retok_create(const zett_retok_model*, int, zett_retok**) { return zett::fail(ZETT_E_NOT_IMPLEMENTED, "retokenizer not built yet"); }
-int zett_retok_destroy(zett_retok*) { return 0; }
-int zett_retokenize(zett_retok*, const uint8_t*, const int32_t*, int64_t, int32_t, int32_t, int32_t*, int64_t*, int64_t*, void*) {
-    return zett::fail(ZETT_E_NOT_IMPLEMENTED, "retokenizer not built yet");
+
+int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
+    using namespace zett;
+    if (!m || !out) return fail(ZETT_E_INVALID, "null argument");
+    if (m->kind != ZETT_RETOK_BPE && m->kind != ZETT_RETOK_UNIGRAM) return fail(ZETT_E_NOT_IMPLEMENTED, "hn tokenizer model kind %d", m->kind);
+    if (m->n_pieces < 0 || m->n_merges < 0 || m->n_special < 0) return fail(ZETT_E_INVALID, "negative count");
+    if (m->n_pieces && (!m->piece_bytes || !m->piece_offsets || !m->piece_ids)) return fail(ZETT_E_INVALID, "piece arrays missing");
+    if (m->kind == ZETT_RETOK_UNIGRAM && m->n_pieces && !m->piece_scores) return fail(ZETT_E_INVALID, "Unigram needs piece_scores");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(ZETT_E_INVALID, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    auto* r = new zett_retok();
+    r->device = device;
+    std::vector<int32_t> single(256, -1), bf(256, -1);
+    if (m->byte_fallback && m->byte_fallback_ids) bf.assign(m->byte_fallback_ids, m->byte_fallback_ids + 256);
+    HostPieceTable pt, st;
+    build_piece_table(m->piece_bytes, m->piece_offsets, m->piece_ids, m->piece_scores, m->n_pieces, pt, single.data());
+    build_piece_table(m->special_bytes, m->special_offsets, m->special_ids, nullptr, m->n_special, st, nullptr);
+    std::vector<MergeEntry> mt;
+    uint32_t mmask = 0xffffffffu;
+    if (m->n_merges > 0) {
+        const uint32_t cap = pow2_capacity((size_t)m->n_merges);
+        mmask = cap - 1;
+        mt.assign(cap, MergeEntry{-1, -1, 0, 0});
+        for (int i = 0; i < m->n_merges; ++i) {   // a pair listed twice: the later entry wins (HashMap collect)
+            const int32_t a = m->merges[3 * i], b = m->merges[3 * i + 1], nid = m->merges[3 * i + 2];
+            if (a < 0 || b < 0) { delete r; return fail(ZETT_E_INVALID, "merge %d has a negative id", i); }
+            uint32_t slot = merge_slot(a, b, mmask);
+            while (mt[slot].a != -1 && !(mt[slot].a == a && mt[slot].b == b)) slot = (slot + 1) & mmask;
+            mt[slot] = MergeEntry{a, b, i, nid};
+        }
+    }
+    std::vector<int16_t> cp(324, -1);           // GPT-2 bytes_to_unicode, inverted
+    {
+        int extra = 0;
+        for (int b = 0; b < 256; ++b) {
+            const bool keep = (b >= 33 && b <= 126) || (b >= 161 && b <= 172) || (b >= 174);
+            cp[keep ? b : 256 + extra++] = (int16_t)b;
+        }
+    }
+    RetokTables& t = r->t;
+    int rc = 0;
+    const PieceEntry* dp = nullptr; const uint8_t* db = nullptr; const MergeEntry* dm = nullptr;
+    const int32_t* di = nullptr; const int16_t* dc = nullptr;
+    if ((rc = upload(r, pt.slots, &dp))) { zett_retok_destroy(r); return rc; } t.pieces = dp;
+    if ((rc = upload(r, pt.blob, &db))) { zett_retok_destroy(r); return rc; } t.piece_blob = db;
+    t.piece_mask = pt.mask;
+    if (!dp) {   // empty vocabulary: one empty slot so lookups terminate
+        std::vector<PieceEntry> one(16, PieceEntry{0, 0, 0, 0, 0, 0.0});
+        if ((rc = upload(r, one, &dp))) { zett_retok_destroy(r); return rc; }
+        t.pieces = dp; t.piece_mask = 15;
+    }
+    if ((rc = upload(r, st.slots, &dp))) { zett_retok_destroy(r); return rc; } t.specials = dp;
+    if ((rc = upload(r, st.blob, &db))) { zett_retok_destroy(r); return rc; } t.special_blob = db;
+    t.special_mask = st.mask;
+    if ((rc = upload(r, mt, &dm))) { zett_retok_destroy(r); return rc; } t.merges = dm; t.merge_mask = mmask;
+    if ((rc = upload(r, single, &di))) { zett_retok_destroy(r); return rc; } t.single_id = di;
+    if ((rc = upload(r, bf, &di))) { zett_retok_destroy(r); return rc; } t.bf_ids = di;
+    if ((rc = upload(r, cp, &dc))) { zett_retok_destroy(r); return rc; } t.cp_to_byte = dc;
+    t.kind = m->kind; t.unk_id = m->unk_id; t.fuse_unk = m->fuse_unk; t.byte_fallback = m->byte_fallback;
+    t.ignore_merges = m->ignore_merges; t.max_piece_len = pt.max_len;
+    t.unk_score = m->unigram_min_score - 10.0;   // tokenizers kUnkPenalty
+    HIP_TRY(hipHostMalloc((void**)&r->host_pinned, 64, hipHostMallocDefault));
+    *out = r;
+    return 0;
 }
+
+int zett_retok_destroy(zett_retok* r) {
+    if (!r) return 0;
+    (void)hipSetDevice(r->device);
+    for (void* p : r->owned) (void)hipFree(p);
+    for (zett::DevBuf* b : {&r->raw, &r->raw_pos, &r->raw_off, &r->blk, &r->scratch, &r->misc}) b->release();
+    if (r->host_pinned) (void)hipHostFree(r->host_pinned);
+    delete r;
+    return 0;
 }
+
+int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* offsets, int64_t n_tokens, int32_t maxlen,
+                    int32_t pad_id, int32_t* out, int64_t* n_truncated, int64_t* bad_token, void* stream) {
+    using namespace zett;
+    if (!r || !offsets || !out || !n_truncated) return fail(ZETT_E_INVALID, "null argument");
+    if (n_tokens < 0 || maxlen < 1) return fail(ZETT_E_INVALID, "bad shape");
+    if (bad_token) *bad_token = -1;
+    *n_truncated = 0;
+    HIP_TRY(hipSetDevice(r->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (n_tokens == 0) return 0;
+    // total text length = offsets[n_tokens]
+    int32_t* hp = r->host_pinned;
+    HIP_TRY(hipMemcpyAsync(hp, offsets + n_tokens, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int64_t n_text = hp[0];
+    if (n_text < 0) return fail(ZETT_E_INVALID, "offsets must be non-decreasing from 0");
+    if (n_text > 0 && !token_chars) return fail(ZETT_E_INVALID, "token_chars is null");
+    const int n_blocks = (int)((n_text + CH_PER_BLOCK - 1) / CH_PER_BLOCK);
+    if (int rc = r->raw.reserve((size_t)n_text + 16)) return rc;
+    if (int rc = r->raw_pos.reserve(((size_t)n_text + 1) * 4)) return rc;
+    if (int rc = r->raw_off.reserve(((size_t)n_tokens + 1) * 4)) return rc;
+    if (int rc = r->blk.reserve(((size_t)n_blocks + 2) * 2 * 4)) return rc;
+    if (int rc = r->misc.reserve(64)) return rc;
+    if (int rc = r->scratch.reserve(((size_t)n_text * SCR_PER_BYTE + (size_t)n_tokens * SCR_FIXED + 64) * 4)) return rc;
+    int32_t* blk_count = r->blk.as<int32_t>();
+    int32_t* blk_scan = blk_count + n_blocks + 1;
+    int32_t* err_pos = r->misc.as<int32_t>();                 // [0] first bad text position
+    int32_t* err_unk = err_pos + 1;                           // [1] 1 + token that needed a missing unk id
+    unsigned long long* ntr = (unsigned long long*)(err_pos + 2);
+    hp[0] = 0x7fffffff; hp[1] = 0; hp[2] = 0; hp[3] = 0;
+    HIP_TRY(hipMemcpyAsync(err_pos, hp, 16, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1024), dim3(256), 0, st, out, n_tokens * (int64_t)maxlen, pad_id);   // :662-666
+    if (n_blocks > 0) {
+        hipLaunchKernelGGL((chars_to_bytes_kernel<0>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
+                           blk_count, (uint8_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr);
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, blk_count, blk_scan, (int64_t)n_blocks);
+        hipLaunchKernelGGL((chars_to_bytes_kernel<1>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
+                           blk_scan, r->raw.as<uint8_t>(), r->raw_pos.as<uint32_t>(), err_pos);
+    } else {
+        HIP_TRY(hipMemsetAsync(blk_scan, 0, 8, st));
+    }
+    hipLaunchKernelGGL(token_raw_offsets_kernel, dim3((unsigned)((n_tokens + 1 + 255) / 256)), dim3(256), 0, st, offsets, n_tokens,
+                       n_text, r->raw_pos.as<uint32_t>(), blk_scan, n_blocks, r->raw_off.as<int32_t>());
+    hipLaunchKernelGGL(retok_tokens_kernel, dim3((unsigned)((n_tokens + 63) / 64)), dim3(64), 0, st, r->t, r->raw.as<uint8_t>(),
+                       r->raw_off.as<int32_t>(), n_tokens, maxlen, out, r->scratch.as<int32_t>(), ntr, err_unk);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hp, err_pos, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (hp[0] != 0x7fffffff) {                                 // KeyError: locate the token of the first bad character
+        std::vector<int32_t> ho((size_t)n_tokens + 1);
+        HIP_TRY(hipMemcpy(ho.data(), offsets, ((size_t)n_tokens + 1) * 4, hipMemcpyDeviceToHost));
+        int64_t lo = 0, hi = n_tokens;                         // last token with offset <= pos
+        while (lo + 1 < hi) { const int64_t mid = (lo + hi) / 2; if (ho[mid] <= hp[0]) lo = mid; else hi = mid; }
+        if (bad_token) *bad_token = lo;
+        return fail(ZETT_E_KEY, "token %lld holds a character outside the byte-level table (text offset %d)", (long long)lo, hp[0]);
+    }
+    if (hp[1] != 0) {
+        if (bad_token) *bad_token = hp[1] - 1;
+        return fail(ZETT_E_STATE, "Encountered an unknown token but `unk_id` is missing (token %d)", hp[1] - 1);
+    }
+    unsigned long long trunc;
+    memcpy(&trunc, hp + 2, 8);
+    *n_truncated = (int64_t)trunc;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+"""``get_surface_form_matrix`` on MI355X — drop-in for zett/utils.py:651-689.
+
+    matrix, n_truncated = get_surface_form_matrix(tokens_or_tokenizer, maxlen, tokenizer_to_use)
+
+expresses every (byte-level) target token as at most ``maxlen`` ids of the source
+model's ("hn") tokenizer, pad-filled, exactly as the reference does — but the per-token
+Python loop around ``tokenizer_to_use._tokenizer.model.tokenize`` is replaced by two
+HIP kernels behind ``zett_retokenize`` (byte-table gather + scan, then BPE merge /
+Unigram Viterbi per token; zett_amd/csrc/retok.hip.h).  This module only flattens the
+hn tokenizer's bare model (vocabulary, merges / scores, flags, special tokens) into
+the arrays the C ABI takes.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+# ---- the byte <-> character table (reference zett/utils.py:351-609) -----------------------
+def _build_byte_table() -> Tuple[List[str], Dict[str, int]]:
+    """Printable Latin-1 bytes stand for themselves; the remaining 68 bytes (controls,
+    space, DEL..0xA0, soft hyphen) are numbered upwards from U+0100 in byte order."""
+    b2c: List[str] = []
+    shifted = 0
+    for b in range(256):
+        if 0x21 <= b <= 0x7E or 0xA1 <= b <= 0xAC or 0xAE <= b <= 0xFF:
+            b2c.append(chr(b))
+        else:
+            b2c.append(chr(0x100 + shifted))
+            shifted += 1
+    return b2c, {c: b for b, c in enumerate(b2c)}
+
+
+BYTES_TO_CHARS_LIST, CHARS_TO_BYTES = _build_byte_table()
+BYTES_TO_CHARS = dict(enumerate(BYTES_TO_CHARS_LIST))
+_TRANSLATE = {ord(c): b for c, b in CHARS_TO_BYTES.items()}
+
+
+def _raw(piece: str) -> Optional[bytes]:
+    """Byte string of a byte-level piece, or None if it holds a character outside the table."""
+    try:
+        return bytes(_TRANSLATE[ord(ch)] for ch in piece)
+    except KeyError:
+        return None
+
+
+# ---- flattening the hn tokenizer ---------------------------------------------------------------
+@dataclass
+class HnTokenizerSpec:
+    """The hn tokenizer's bare model in the layout of ``zett_retok_model`` (include/zett_hip.h)."""
+    kind: int
+    piece_bytes: np.ndarray          # uint8
+    piece_offsets: np.ndarray        # int32 [n_pieces + 1]
+    piece_ids: np.ndarray            # int32
+    piece_scores: Optional[np.ndarray]
+    unigram_min_score: float
+    merges: np.ndarray               # int32 [n_merges, 3]
+    unk_id: int
+    fuse_unk: bool
+    byte_fallback: bool
+    byte_fallback_ids: Optional[np.ndarray]
+    ignore_merges: bool
+    special_bytes: np.ndarray
+    special_offsets: np.ndarray
+    special_ids: np.ndarray
+    pad_token_id: int
+    special_tokens: Tuple[str, ...] = ()
+
+    @staticmethod
+    def _pack(items: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+        offsets = np.zeros(len(items) + 1, dtype=np.int32)
+        if len(items):
+            np.cumsum(np.fromiter(map(len, items), dtype=np.int64, count=len(items)), out=offsets[1:])
+        blob = np.frombuffer(b"".join(items) or b"\0", dtype=np.uint8).copy()
+        return blob, offsets
+
+    @classmethod
+    def from_model_json(cls, model: dict, special_tokens: Sequence[str], special_ids: Sequence[int],
+                        pad_token_id: int) -> "HnTokenizerSpec":
+        kind_name = model.get("type") or ("BPE" if "merges" in model else None)
+        if model.get("continuing_subword_prefix") or model.get("end_of_word_suffix"):
+            raise NotImplementedError("hn tokenizers with a continuing_subword_prefix / end_of_word_suffix")
+        if model.get("dropout"):
+            raise NotImplementedError("BPE dropout")
+        pieces: List[bytes] = []
+        ids: List[int] = []
+        scores: Optional[List[float]] = None
+        merges = np.zeros((0, 3), dtype=np.int32)
+        bf_ids = None
+        min_score = 0.0
+        if kind_name == "BPE":
+            vocab: Dict[str, int] = model["vocab"]
+            for piece, i in vocab.items():
+                raw = _raw(piece)
+                if raw:
+                    pieces.append(raw)
+                    ids.append(int(i))
+            rows = []
+            for entry in model.get("merges", []):
+                left, right = entry.split(" ") if isinstance(entry, str) else entry
+                rows.append((vocab[left], vocab[right], vocab[left + right]))
+            if rows:
+                merges = np.asarray(rows, dtype=np.int32)
+            unk = model.get("unk_token")
+            unk_id = int(vocab[unk]) if unk is not None else -1
+            fuse_unk = bool(model.get("fuse_unk", False))
+            if model.get("byte_fallback"):
+                bf_ids = np.asarray([vocab.get("<0x%02X>" % b, -1) for b in range(256)], dtype=np.int32)
+            kind = _lib.RETOK_BPE
+        elif kind_name == "Unigram":
+            scores = []
+            lookup: Dict[str, int] = {}
+            listing = model["vocab"]
+            for i, (piece, score) in enumerate(listing):
+                lookup[piece] = i
+                raw = _raw(piece)
+                if raw:
+                    pieces.append(raw)
+                    ids.append(i)
+                    scores.append(float(score))
+            min_score = min((float(s) for _, s in listing), default=0.0)
+            unk_id = -1 if model.get("unk_id") is None else int(model["unk_id"])
+            fuse_unk = True
+            if model.get("byte_fallback"):
+                bf_ids = np.asarray([lookup.get("<0x%02X>" % b, -1) for b in range(256)], dtype=np.int32)
+            kind = _lib.RETOK_UNIGRAM
+        else:
+            raise NotImplementedError(f"hn tokenizer model type {kind_name!r} (the reference's shipped hn "
+                                      "tokenizers are BPE or Unigram)")
+        sp = [(r, int(i)) for r, i in ((_raw(s), i) for s, i in zip(special_tokens, special_ids)) if r]
+        pb, po = cls._pack(pieces)
+        sb, so = cls._pack([r for r, _ in sp])
+        return cls(kind=kind, piece_bytes=pb, piece_offsets=po, piece_ids=np.asarray(ids, dtype=np.int32),
+                   piece_scores=None if scores is None else np.asarray(scores, dtype=np.float64),
+                   unigram_min_score=float(min_score), merges=np.ascontiguousarray(merges), unk_id=unk_id,
+                   fuse_unk=fuse_unk, byte_fallback=bool(model.get("byte_fallback", False)), byte_fallback_ids=bf_ids,
+                   ignore_merges=bool(model.get("ignore_merges", False)), special_bytes=sb, special_offsets=so,
+                   special_ids=np.asarray([i for _, i in sp], dtype=np.int32), pad_token_id=int(pad_token_id),
+                   special_tokens=tuple(special_tokens))
+
+    @classmethod
+    def from_tokenizer(cls, tokenizer) -> "HnTokenizerSpec":
+        """From the object the reference passes as ``tokenizer_to_use`` (a transformers fast tokenizer)."""
+        if type(tokenizer).__name__ == "ByT5Tokenizer":
+            raise NotImplementedError("ByT5 hn tokenizers (zett/utils.py:677-678) are not used by any shipped config")
+        data = json.loads(tokenizer._tokenizer.to_str())
+        specials = list(tokenizer.all_special_tokens)
+        ids = [tokenizer.convert_tokens_to_ids(s) for s in specials]
+        return cls.from_model_json(data["model"], specials, ids, tokenizer.pad_token_id)
+
+
+class DeviceRetokenizer:
+    """A ``zett_retok`` handle: the hn tokenizer's tables resident on one GPU."""
+
+    def __init__(self, spec: HnTokenizerSpec, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("zett_amd computes on MI355X only: pass a cuda (ROCm) device; there is no CPU path")
+        self.lib = _lib.load()
+        self.spec = spec
+        self.device = device
+
+        def ptr(a):
+            return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+        m = _lib.ZettRetokModel(
+            kind=spec.kind, n_pieces=len(spec.piece_ids), piece_bytes=ptr(spec.piece_bytes),
+            piece_offsets=ptr(spec.piece_offsets), piece_ids=ptr(spec.piece_ids), piece_scores=ptr(spec.piece_scores),
+            unigram_min_score=spec.unigram_min_score, n_merges=len(spec.merges), merges=ptr(spec.merges),
+            unk_id=spec.unk_id, fuse_unk=int(spec.fuse_unk), byte_fallback=int(spec.byte_fallback),
+            byte_fallback_ids=ptr(spec.byte_fallback_ids), ignore_merges=int(spec.ignore_merges),
+            n_special=len(spec.special_ids), special_bytes=ptr(spec.special_bytes),
+            special_offsets=ptr(spec.special_offsets), special_ids=ptr(spec.special_ids))
+        handle = C.c_void_p()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        _lib.check(self.lib.zett_retok_create(C.byref(m), index, C.byref(handle)), "zett_retok_create")
+        self.handle = handle
+
+    def __call__(self, tokens: Sequence[str], maxlen: int) -> Tuple[torch.Tensor, int]:
+        """int32 [len(tokens), maxlen] on the device + number of truncated tokens."""
+        encoded = [t.encode("utf-8") for t in tokens]
+        n = len(encoded)
+        offsets = np.zeros(n + 1, dtype=np.int32)
+        if n:
+            np.cumsum(np.fromiter(map(len, encoded), dtype=np.int64, count=n), out=offsets[1:])
+        text = np.frombuffer(b"".join(encoded) or b"\0", dtype=np.uint8)
+        d_text = torch.from_numpy(text.copy()).to(self.device)
+        d_off = torch.from_numpy(offsets).to(self.device)
+        out = torch.empty((n, maxlen), dtype=torch.int32, device=self.device)
+        n_trunc = C.c_int64(0)
+        bad = C.c_int64(-1)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.zett_retokenize(self.handle, C.c_void_p(d_text.data_ptr()), C.c_void_p(d_off.data_ptr()), n,
+                                          int(maxlen), self.spec.pad_token_id, C.c_void_p(out.data_ptr()),
+                                          C.byref(n_trunc), C.byref(bad), C.c_void_p(stream))
+        if rc == _lib.E_KEY and bad.value >= 0:
+            for ch in tokens[bad.value]:                 # the reference raises KeyError(<character>)
+                if ch not in CHARS_TO_BYTES:
+                    raise KeyError(ch)
+        if rc == _lib.E_STATE:
+            raise Exception(self.lib.zett_last_error().decode())      # tokenizers raises a bare Exception here
+        _lib.check(rc, "zett_retokenize")
+        return out, int(n_trunc.value)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.zett_retok_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_CACHE: Dict[Tuple[int, str], DeviceRetokenizer] = {}
+
+
+def device_retokenizer(tokenizer_to_use, device=None) -> DeviceRetokenizer:
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("zett_amd computes on MI355X only: no cuda (ROCm) device is visible; there is no CPU path")
+        device = torch.device("cuda", torch.cuda.current_device())
+    else:
+        device = torch.device(device)
+    if isinstance(tokenizer_to_use, HnTokenizerSpec):
+        spec = tokenizer_to_use
+    else:
+        spec = getattr(tokenizer_to_use, "_zett_spec", None)
+        if spec is None:
+            spec = HnTokenizerSpec.from_tokenizer(tokenizer_to_use)
+            try:
+                tokenizer_to_use._zett_spec = spec
+            except Exception:
+                pass
+    key = (id(spec), str(device))
+    rt = _CACHE.get(key)
+    if rt is None:
+        rt = DeviceRetokenizer(spec, device)
+        _CACHE[key] = rt
+    return rt
+
+
+def surface_form_matrix_device(tokens: Sequence[str], maxlen: int, tokenizer_to_use, device=None) -> Tuple[torch.Tensor, int]:
+    """Like get_surface_form_matrix but leaves the int32 matrix on the GPU (feeds ZettHypernet directly)."""
+    return device_retokenizer(tokenizer_to_use, device)(tokens, maxlen)
+
+
+def get_surface_form_matrix(tokenizer_or_tokens, maxlen, tokenizer_to_use=None, padding=0, verbose=False, device=None):
+    """Drop-in for zett.utils.get_surface_form_matrix (zett/utils.py:651-689).
+
+    Returns ``(np.int32 [V + padding, maxlen], n_truncated)``; raises ``KeyError`` on a token
+    holding a character outside the byte-level alphabet (zett/utils.py:675).
+    """
+    if isinstance(tokenizer_or_tokens, list):
+        tokens = tokenizer_or_tokens
+    else:
+        tokens = tokenizer_or_tokens.convert_ids_to_tokens(range(len(tokenizer_or_tokens)))   # :659
+    if tokenizer_to_use is None:
+        raise ValueError("tokenizer_to_use (the hn tokenizer) is required")
+    rt = device_retokenizer(tokenizer_to_use, device)
+    matrix, n_truncated = rt(tokens, maxlen)
+    out = np.full((len(tokens) + padding, maxlen), rt.spec.pad_token_id, dtype=np.int32)      # :662-666
+    out[:len(tokens)] = matrix.cpu().numpy()
+    return out, n_truncated
