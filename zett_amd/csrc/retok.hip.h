@@ -528,13 +528,14 @@ int zett_retok_destroy(zett_retok* r) {
 int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* offsets, int64_t n_tokens, int32_t maxlen,
                     int32_t pad_id, int32_t* out, int64_t* n_truncated, int64_t* bad_token, void* stream) {
     using namespace zett;
-    if (!r || !offsets || !out || !n_truncated) return fail(ZETT_E_INVALID, "null argument");
+    if (!r || !n_truncated) return fail(ZETT_E_INVALID, "null argument");
     if (n_tokens < 0 || maxlen < 1) return fail(ZETT_E_INVALID, "bad shape");
     if (bad_token) *bad_token = -1;
     *n_truncated = 0;
+    if (n_tokens == 0) return 0;
+    if (!offsets || !out) return fail(ZETT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(r->device));
     hipStream_t st = (hipStream_t)stream;
-    if (n_tokens == 0) return 0;
     // total text length = offsets[n_tokens]
     int32_t* hp = r->host_pinned;
     HIP_TRY(hipMemcpyAsync(hp, offsets + n_tokens, 4, hipMemcpyDeviceToHost, st));
