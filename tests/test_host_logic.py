@@ -1,0 +1,240 @@
+"""Host-side logic that needs no GPU: the C ABI surface, config / checkpoint contract,
+batched_inference, special-token overwrite, row sharding (gloo, world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from zett_amd import synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI ---------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    from zett_amd import _lib
+    header = open(os.path.join(REPO, "include", "zett_hip.h")).read()
+    declared = set(re.findall(r"\b(zett_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.zett_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from zett_amd import _lib
+    assert ctypes.sizeof(_lib.ZettConfig) == 16 * 4 + 2 * 4
+    assert ctypes.sizeof(_lib.ZettStats) == 8 * 8
+    # zett_retok_model: int,int,4 ptr,double,int,ptr,3 int,ptr,int,int,3 ptr  (natural alignment)
+    assert _lib.ZettRetokModel.piece_scores.offset == 32
+    assert _lib.ZettRetokModel.unigram_min_score.offset == 40
+
+
+def test_no_cpu_fallback():
+    """The product path refuses CPU tensors instead of silently computing elsewhere."""
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg, *_ = synth.workload("tiny")
+    model = ZettHypernet(ZettHypernetConfig(**cfg))
+    with pytest.raises(RuntimeError, match="MI355X"):
+        model(torch.zeros(2, 7, dtype=torch.long), source_embeddings=torch.zeros(300, 128), lang_index=torch.tensor(0))
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "zett_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+# ---- config / checkpoint contract --------------------------------------------------------------
+def test_reference_error_behaviour():
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg, *_ = synth.workload("tiny")
+    with pytest.raises(NotImplementedError):
+        ZettHypernet(ZettHypernetConfig(**dict(cfg, hn_model_type="t5")))
+    with pytest.raises(NotImplementedError):
+        ZettHypernet(ZettHypernetConfig(**dict(cfg, hn_add_inter_token_attention=True)))
+    with pytest.raises(NotImplementedError):
+        ZettHypernet(ZettHypernetConfig(**dict(cfg, hn_embed_target_priors=True)))
+    with pytest.raises(AssertionError):
+        ZettHypernet(ZettHypernetConfig(**{k: v for k, v in cfg.items() if k != "pad_token_id"}))
+    model = ZettHypernet(ZettHypernetConfig(**cfg))
+    with pytest.raises(NotImplementedError):
+        model(torch.zeros(1, 7, dtype=torch.long), target_priors=torch.zeros(1), source_embeddings=torch.zeros(300, 128))
+    model2 = ZettHypernet(ZettHypernetConfig(**dict(cfg, hn_embed_using_source_embeddings=False)))
+    with pytest.raises(NotImplementedError):
+        model2(torch.zeros(1, 7, dtype=torch.long), source_embeddings=torch.zeros(300, 128))
+
+
+def test_state_dict_names_and_automodel_roundtrip(tmp_path):
+    from transformers import AutoConfig, AutoModel
+
+    import zett_amd  # noqa: F401
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.dims import weight_shapes
+    from zett_amd.hypernet import ZettHypernet
+    cfg, *_ = synth.workload("tiny")
+    model = ZettHypernet(ZettHypernetConfig(**cfg))
+    sd = model.state_dict()
+    want = weight_shapes(cfg)
+    assert list(sd.keys()) == list(want.keys())
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in want.items())
+    w = synth.make_weights(cfg, 3)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model.save_pretrained(tmp_path)
+    again = AutoModel.from_pretrained(tmp_path)
+    assert type(again).__name__ == "ZettHypernet"
+    for k, v in w.items():
+        assert torch.equal(again.state_dict()[k], torch.from_numpy(v)), k
+    c = AutoConfig.from_pretrained(tmp_path)
+    assert c.model_type == "zett_hypernetwork" and c.hn_surface_maxlen == 7 and c.original_vocab_size == 300
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hf_hypernet"), reason="reference only exists in the build container")
+def test_loads_checkpoint_written_by_reference(tmp_path):
+    """A checkpoint saved by the reference's own torch class loads into ours unchanged."""
+    code = f"""
+import sys, json, torch, numpy as np
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, {REPO!r})
+from hf_hypernet.configuration_hypernet import ZettHypernetConfig
+from hf_hypernet.modeling_hypernet import ZettHypernet
+from zett_amd import synth
+import os
+rb = os.path.join({str(tmp_path)!r}, "rb"); os.makedirs(rb)
+json.dump({{"model_type": "roberta", "max_position_embeddings": 514, "type_vocab_size": 1, "layer_norm_eps": 1e-5,
+           "hidden_act": "gelu", "vocab_size": 50265, "pad_token_id": 1}}, open(os.path.join(rb, "config.json"), "w"))
+cfg, *_ = synth.workload("tiny")
+m = ZettHypernet(ZettHypernetConfig(**dict(cfg, hn_model_name_or_path=rb)))
+m.load_state_dict({{k: torch.from_numpy(v) for k, v in synth.make_weights(cfg, 5).items()}})
+m.save_pretrained(os.path.join({str(tmp_path)!r}, "ckpt"))
+"""
+    subprocess.run([sys.executable, "-c", code], check=True, cwd="/tmp")
+    # reference checkpoints carry no usable model_type (the class sets it on the instance only) and are
+    # loaded by remote code upstream; here the class is addressed directly.
+    from zett_amd.hypernet import ZettHypernet
+    cfg, *_ = synth.workload("tiny")
+    model = ZettHypernet.from_pretrained(os.path.join(tmp_path, "ckpt"))
+    assert model.config.hn_surface_maxlen == 7 and model.dims.original_vocab_size == 300
+    for k, v in synth.make_weights(cfg, 5).items():
+        assert torch.equal(model.state_dict()[k], torch.from_numpy(v)), k
+
+
+# ---- batched_inference / special tokens (scripts/transfer.py:54-124, 274-300) ---------------------
+def _fake_predict(rows):
+    x = rows.float()
+    e = torch.arange(1, 9, dtype=torch.float32)
+    return x.sum(1, keepdim=True) * e, x.max(1, keepdim=True).values * e, x[:, 0].float()
+
+
+def test_batched_inference_is_batching_independent():
+    from zett_amd.transfer import batched_inference
+    sfm = torch.from_numpy(np.random.default_rng(0).integers(0, 50, size=(1001, 7)))
+    want = _fake_predict(sfm)
+    for bs in (64, 1001, 4096):
+        got = batched_inference(_fake_predict, sfm, 8, batch_size=bs, rng=np.random.default_rng(bs))
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
+
+
+def test_batched_inference_sampled_batches_average():
+    from zett_amd.transfer import batched_inference, get_sample_indices
+    n = 200
+    pri = np.random.default_rng(1).normal(size=n)
+    idx = get_sample_indices(n, pri, batch_size=64, min_k=2, n_samples=10, rng=np.random.default_rng(2))
+    assert idx.shape == (10, 64) and set(np.unique(idx)) == set(range(n))
+    assert all(len(set(row)) == 64 for row in idx)
+    sfm = torch.from_numpy(np.random.default_rng(0).integers(0, 50, size=(n, 7)))
+    got = batched_inference(_fake_predict, sfm, 8, batch_size=64, sample_batches=True, target_priors=pri, min_k=2,
+                            n_samples=10, rng=np.random.default_rng(3))
+    for g, w in zip(got, _fake_predict(sfm)):
+        torch.testing.assert_close(g, w, rtol=1e-6, atol=1e-6)
+
+
+def test_overwrite_special_tokens():
+    from zett_amd.transfer import overwrite_special_tokens
+    pred = torch.zeros(10, 4)
+    src = torch.arange(40, dtype=torch.float32).reshape(10, 4)
+    out = overwrite_special_tokens(pred, src, [0, 2, 9], [5, 1, 3])
+    assert torch.equal(out[5], src[0]) and torch.equal(out[1], src[2]) and torch.equal(out[3], src[9])
+    assert out[[0, 2, 4, 6, 7, 8]].abs().sum() == 0
+
+
+def test_transfer_cli_flags_match_reference():
+    import dataclasses
+
+    from zett_amd.transfer import Args
+    names = [f.name for f in dataclasses.fields(Args)]
+    assert names == ["output", "checkpoint_path", "tokenizer_name", "model_class", "target_model",
+                     "copy_inner_parameters_from", "dtype", "revision", "do_batching", "batch_size", "sample_batches",
+                     "min_k", "n_samples", "lang_path", "lang_code", "make_whitespace_consistent", "save_pt"]
+    d = Args(output="x")
+    assert (d.dtype, d.do_batching, d.batch_size, d.make_whitespace_consistent, d.model_class) == \
+        ("bfloat16", True, 16384, True, "AutoModel")
+
+
+# ---- vocab-row sharding over ranks (gloo, world_size 2 and 3) --------------------------------------
+def test_shard_bounds_cover_rows():
+    from zett_amd.sharding import shard_bounds
+    for n in (0, 1, 7, 8, 1001, 32768):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+_WORKER = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r})
+from oracle import hypernet_ref
+from zett_amd import synth
+from zett_amd.sharding import predict_sharded
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg, *_ = synth.workload("tiny")
+w = synth.make_weights(cfg, 9); src = synth.make_source_embeddings(cfg, 9)
+ids = synth.make_surface_forms(cfg, 37, seed=9, n_special=1)
+def predict(rows):   # the oracle stands in for the HIP engine: this test covers the partition + all-gather
+    o = hypernet_ref.forward(w, cfg, rows.numpy(), src, 2)
+    return tuple(None if x is None else torch.from_numpy(x) for x in o)
+full = predict_sharded(predict, torch.from_numpy(ids))
+single = predict(torch.from_numpy(ids))
+# numpy BLAS is not batch-size invariant, so the oracle stand-in is compared to rounding; the
+# bit-exactness of the gather itself is checked with a row-wise deterministic predictor
+ok = all(torch.allclose(a, b, rtol=0, atol=1e-5) for a, b in zip(full, single))
+def fake(rows):
+    x = rows.float(); e = torch.arange(1, 5, dtype=torch.float32)
+    return x.sum(1, keepdim=True) * e, None, x[:, 0].clone()
+f_full = predict_sharded(fake, torch.from_numpy(ids)); f_single = fake(torch.from_numpy(ids))
+ok = ok and torch.equal(f_full[0], f_single[0]) and f_full[1] is None and torch.equal(f_full[2], f_single[2])
+shapes = [tuple(t.shape) for t in full]
+if rank == 0:
+    json.dump({{"ok": ok, "shapes": shapes}}, open({out!r}, "w"))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_predict_sharded_gloo(tmp_path, world):
+    import json
+    out = os.path.join(tmp_path, "res.json")
+    script = os.path.join(tmp_path, "worker.py")
+    open(script, "w").write(_WORKER.format(repo=REPO, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + world + (os.getpid() % 200)),
+               OMP_NUM_THREADS="2")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                    "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], script],
+                   check=True, env=env, timeout=600, cwd="/tmp")
+    res = json.load(open(out))
+    assert res["ok"], "all-gathered shards differ from the single-process result"
+    assert res["shapes"] == [[37, 64], [37, 64], [37]]

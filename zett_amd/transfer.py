@@ -1,0 +1,227 @@
+"""Zero-shot tokenizer transfer CLI — the surface of the reference's scripts/transfer.py
+on MI355X, with PyTorch/safetensors weights instead of Flax msgpack.
+
+    python scripts/transfer.py --output out/ --checkpoint_path <hypernet> \
+        --tokenizer_name <target tokenizer> --target_model <LM> --model_class AutoModelForCausalLM
+
+Same 17 flags and defaults as scripts/transfer.py:30-51.  The embedding-prediction
+path (surface-form matrix -> hypernetwork -> [V, E] matrices) runs in HIP through
+libzett_hip.so; this module holds only the host orchestration the reference keeps in
+Python: ``batched_inference`` (scripts/transfer.py:54-124), the special-token
+overwrite (scripts/transfer.py:274-300) and the splice into the language model.
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass
+from typing import Callable, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+NEGATIVE_INF_FILL_VALUE = -100000.0      # zett/utils.py (score used for filled-in unigram pieces)
+
+
+@dataclass
+class Args:
+    output: str
+    checkpoint_path: str = "output_gpt2_noise_std_1.0_inter_embed_bias_scratch_nlayers=6"
+    tokenizer_name: str = "artifacts/gpt2_unigramify"
+    model_class: str = "AutoModel"
+    # args for target model and projection
+    target_model: str = "gpt2"
+    copy_inner_parameters_from: str = None
+    dtype: str = "bfloat16"
+    revision: str = None
+    do_batching: bool = True
+    batch_size: int = 16384
+    sample_batches: bool = False
+    min_k: int = 10
+    n_samples: int = 100
+    lang_path: str = None
+    lang_code: str = None
+    make_whitespace_consistent: bool = True
+    save_pt: bool = False
+
+
+Predict = Callable[[torch.Tensor], Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]]
+
+
+def get_sample_indices(n: int, p: np.ndarray, batch_size: int, min_k: int, n_samples: int,
+                       rng: Optional[np.random.Generator] = None) -> np.ndarray:
+    """Prior-weighted batch composition of ``--sample_batches`` (zett/utils.py:612-648): every
+    token appears at least ``min_k`` times through shuffled passes, the rest of each batch is
+    drawn without replacement proportionally to exp(prior)."""
+    rng = rng or np.random.default_rng()
+    weights = np.exp(np.where(p > NEGATIVE_INF_FILL_VALUE, p, -np.inf))
+    n_per_k = n_samples // min_k
+    assert n_per_k * min_k == n_samples
+    order = rng.permutation(n)
+    cursor = 0
+    out = np.empty((n_samples, batch_size), dtype=np.int32)
+    for i in range(n_samples):
+        closing = (i + 1) % n_per_k == 0
+        take = len(order) - cursor if closing else len(order) // n_per_k
+        out[i, :take] = order[cursor:cursor + take]
+        if closing:
+            cursor = 0
+            order = rng.permutation(n)
+        else:
+            cursor += take
+        rest = weights.copy()
+        rest[out[i, :take]] = 0
+        rest /= rest.sum()
+        out[i, take:] = rng.choice(n, size=batch_size - take, p=rest, replace=False)
+    return out
+
+
+def batched_inference(predict: Predict, target_surface_form_matrix: torch.Tensor, n_embd: int, batch_size: int = 16384,
+                      sample_batches: bool = False, target_priors: Optional[np.ndarray] = None, min_k: int = 10,
+                      n_samples: int = 100, rng: Optional[np.random.Generator] = None):
+    """scripts/transfer.py:54-124 with device-resident accumulation.
+
+    Rows are visited in a random permutation, the last batch is padded with row 0, predictions
+    are accumulated into fp32 [V, E] matrices (and averaged by visit count when batches are
+    sampled).  Rows are independent, so the result does not depend on the batching.
+    """
+    rng = rng or np.random.default_rng()
+    sfm = target_surface_form_matrix
+    device = sfm.device
+    n = sfm.shape[0]
+    if sample_batches:
+        assert target_priors is not None
+        batches = list(get_sample_indices(n, np.asarray(target_priors), batch_size, min_k, n_samples, rng))
+        empty_in_last = 0
+    else:
+        total = math.ceil(n / batch_size) * batch_size
+        padded = np.pad(rng.permutation(n), (0, total - n))
+        batches = np.array_split(padded, total // batch_size)
+        empty_in_last = total - n
+    acc_in = torch.zeros((n, n_embd), dtype=torch.float32, device=device)
+    acc_out = None
+    acc_bias = torch.zeros((n,), dtype=torch.float32, device=device)
+    counts = torch.zeros((n,), dtype=torch.float32, device=device)
+    for bi, idx in enumerate(batches):
+        index = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(device)
+        p_in, p_out, p_bias = predict(sfm.index_select(0, index))
+        if bi == len(batches) - 1 and empty_in_last > 0:
+            keep = len(idx) - empty_in_last
+            index, p_in, p_bias = index[:keep], p_in[:keep], p_bias[:keep]
+            p_out = None if p_out is None else p_out[:keep]
+        acc_in.index_add_(0, index, p_in.float())
+        acc_bias.index_add_(0, index, p_bias.float())
+        if p_out is not None:
+            if acc_out is None:
+                acc_out = torch.zeros((n, n_embd), dtype=torch.float32, device=device)
+            acc_out.index_add_(0, index, p_out.float())
+        counts.index_add_(0, index, torch.ones_like(index, dtype=torch.float32))
+    if sample_batches:   # tokens seen several times are averaged (scripts/transfer.py:113-122)
+        assert bool((counts > 0).all())
+        acc_in /= counts[:, None]
+        acc_bias /= counts
+        if acc_out is not None:
+            acc_out /= counts[:, None]
+    return acc_in, acc_out, acc_bias
+
+
+def overwrite_special_tokens(predicted: torch.Tensor, source_embeddings: torch.Tensor,
+                             source_special_ids: Sequence[int], target_special_ids: Sequence[int]) -> torch.Tensor:
+    """scripts/transfer.py:274-300: rows of the source model's special tokens are copied, not predicted."""
+    src = torch.as_tensor(list(source_special_ids), dtype=torch.long, device=source_embeddings.device)
+    dst = torch.as_tensor(list(target_special_ids), dtype=torch.long, device=predicted.device)
+    predicted[dst] = source_embeddings.index_select(0, src).to(predicted.dtype).to(predicted.device)
+    return predicted
+
+
+def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, source_embeddings: torch.Tensor,
+                       lang_index=None, args: Optional[Args] = None, target_priors=None, rng=None):
+    """The whole-vocabulary prediction of scripts/transfer.py:221-270 (batching flags honoured)."""
+    args = args or Args(output="")
+
+    def predict(rows):
+        return hypernet(rows, source_embeddings=source_embeddings, lang_index=lang_index)
+
+    if not args.do_batching:   # scripts/transfer.py:243-262 pads to a multiple of 128 for XLA; no need here
+        return predict(target_surface_form_matrix)
+    n_embd = hypernet.config.n_embd
+    return batched_inference(predict, target_surface_form_matrix, n_embd, args.batch_size, args.sample_batches,
+                             target_priors, args.min_k, args.n_samples, rng)
+
+
+def main(argv=None):
+    import transformers
+    from transformers import AutoConfig, AutoModel, AutoTokenizer, HfArgumentParser
+
+    import zett_amd  # noqa: F401  (registers the hypernetwork with AutoModel)
+    from zett_amd.byte_level import convert_to_byte_level
+    from zett_amd.surface_forms import surface_form_matrix_device
+
+    (args,) = HfArgumentParser([Args]).parse_args_into_dataclasses(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("scripts/transfer.py needs an MI355X: torch.cuda.is_available() is False")
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    tokenizer = AutoTokenizer.from_pretrained(args.tokenizer_name)
+    config = AutoConfig.from_pretrained(args.checkpoint_path)
+    lang_index = None
+    if args.lang_code is not None:                                   # scripts/transfer.py:133-143
+        langs = getattr(config, "langs", None)
+        if langs is None:
+            assert args.lang_path is not None
+            langs = [x.strip() for x in open(args.lang_path).readlines()]
+        lang_index = torch.tensor(langs.index(args.lang_code), dtype=torch.int32)
+
+    hypernet = AutoModel.from_pretrained(args.checkpoint_path).to(device)
+    hypernet.precision = {"bfloat16": "bf16", "float32": "f32", "float16": "bf16"}.get(args.dtype, "bf16")
+
+    source_tokenizer = AutoTokenizer.from_pretrained(args.target_model)
+    hn_tokenizer = type(source_tokenizer).from_pretrained(args.checkpoint_path)
+    hn_tokenizer = convert_to_byte_level(hn_tokenizer)[0]            # scripts/transfer.py:153-159
+    if hn_tokenizer.pad_token is None:
+        hn_tokenizer.pad_token = hn_tokenizer.eos_token
+
+    model_cls = getattr(transformers, args.model_class)
+    downstream = model_cls.from_pretrained(args.target_model, revision=args.revision, torch_dtype=torch.float32)
+    emb_in = downstream.get_input_embeddings().weight.data
+    out_layer = downstream.get_output_embeddings() if args.model_class != "AutoModel" else None
+    tied = bool(getattr(downstream.config, "tie_word_embeddings", False)) or out_layer is None
+    emb_out = None if tied else out_layer.weight.data
+    source_embeddings = (emb_in if emb_out is None else torch.cat([emb_in, emb_out], dim=1)).to(device)   # :162-191
+
+    if args.copy_inner_parameters_from is not None:
+        downstream = model_cls.from_pretrained(args.copy_inner_parameters_from, torch_dtype=torch.float32)
+
+    tokenizer = convert_to_byte_level(tokenizer, make_whitespace_consistent=args.make_whitespace_consistent,
+                                      match_special_tokens_to=source_tokenizer)[0]                       # :198-202
+    tokens = tokenizer.convert_ids_to_tokens(range(len(tokenizer)))
+    sfm, n_truncated = surface_form_matrix_device(tokens, config.hn_surface_maxlen, hn_tokenizer, device)  # :204-206
+    print(f"Truncated {n_truncated} tokens.")
+
+    print("WARNING: using uniform priors, get_scores() not available.")
+    target_priors = np.zeros(len(tokenizer))
+    pred_in, pred_out, pred_bias = predict_vocabulary(hypernet, sfm.long(), source_embeddings, lang_index, args, target_priors)
+
+    special_src = list(source_tokenizer.all_special_ids)                                                  # :274-300
+    special_dst = [tokenizer.get_vocab()[t] for t in source_tokenizer.all_special_tokens]
+    os.makedirs(args.output, exist_ok=True)
+    source_tokenizer.save_pretrained(args.output)
+    tokenizer.save_pretrained(args.output)
+    pred_in = overwrite_special_tokens(pred_in, emb_in, special_src, special_dst)
+    downstream.resize_token_embeddings(len(tokenizer))
+    downstream.get_input_embeddings().weight.data.copy_(pred_in.cpu())
+    if emb_out is not None and pred_out is not None:
+        pred_out = overwrite_special_tokens(pred_out, emb_out, special_src, special_dst)
+        downstream.get_output_embeddings().weight.data.copy_(pred_out.cpu())
+    bias_param = getattr(downstream.get_output_embeddings(), "bias", None) if out_layer is not None else None
+    if bias_param is not None:
+        bias_param.data.copy_(pred_bias.cpu())
+    else:
+        from safetensors.torch import save_file
+        save_file({"bias": pred_bias.cpu()}, os.path.join(args.output, "bias.safetensors"))
+    downstream.config.vocab_size = len(tokenizer)
+    downstream.save_pretrained(args.output, max_shard_size="20GB")
+
+
+if __name__ == "__main__":
+    main()
