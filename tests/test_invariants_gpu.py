@@ -1,0 +1,142 @@
+"""Size-independent properties of the HIP forward, checked bit-for-bit,
+at small and at BASELINE.json's full sizes: rows are independent, so the result of a row may
+not depend on its neighbours, on the shard / chunk it lands in, on the content behind pad
+positions, or on the storage dtype of an fp16-representable source table."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from zett_amd import synth
+from zett_amd.dims import HypernetDims
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(cfg, seed, precision, device="cuda:0"):
+    from bench import device_weights
+    from zett_amd.hypernet import HipEngine
+    dev = torch.device(device)
+    eng = HipEngine(HypernetDims.from_config(cfg), 1e-5, dev, precision)
+    eng.load_weights(device_weights(cfg, dev, seed=seed))
+    return eng
+
+
+def _run(eng, ids, src, lang=-1):
+    out = eng.forward(torch.as_tensor(ids).to(eng.device), src, lang)
+    torch.cuda.synchronize()
+    return out
+
+
+def _eq(a, b):
+    return all((x is None and y is None) or torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_row_order_shard_and_chunk_independence_tiny(precision):
+    cfg, *_ = synth.workload("tiny")
+    eng = _engine(cfg, 1, precision)
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 1)).cuda()
+    ids = synth.make_surface_forms(cfg, 3000, seed=1, n_special=3)
+    full = _run(eng, ids, src, 2)
+    perm = np.random.default_rng(0).permutation(len(ids))
+    shuffled = _run(eng, ids[perm], src, 2)
+    assert _eq([None if t is None else t[torch.from_numpy(np.argsort(perm)).cuda()] for t in shuffled], full)
+    # vocab shards of 1, 2, 3, 8 ranks reassemble to the same bits (what the all-gather relies on)
+    from zett_amd.sharding import shard_bounds
+    for world in (2, 3, 8):
+        parts = [_run(eng, ids[slice(*shard_bounds(len(ids), world, r))], src, 2) for r in range(world)]
+        cat = [None if parts[0][k] is None else torch.cat([p[k] for p in parts]) for k in range(3)]
+        assert _eq(cat, full)
+    # encoder chunking
+    eng.set_option("max_chunk_tokens", 1024)
+    assert _eq(_run(eng, ids, src, 2), full)
+    eng.set_option("max_chunk_tokens", 65536)
+    # last layer computed for every position vs position 0 only
+    eng.set_option("cls_only_last_layer", 0)
+    ref = _run(eng, ids, src, 2)
+    eng.set_option("cls_only_last_layer", 1)
+    for a, b in zip(ref, full):
+        if a is not None:
+            torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def test_pad_content_independence():
+    """Changing the pad token's source embedding must change nothing for rows with a visible key."""
+    cfg, *_ = synth.workload("tiny")
+    cfg = dict(cfg, hn_embed_lang_id=False)
+    eng = _engine(cfg, 2, "f32")
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 2)).cuda()
+    ids = synth.make_surface_forms(cfg, 512, seed=2)
+    a = _run(eng, ids, src)
+    src2 = src.clone()
+    src2[cfg["pad_token_id"]] += 3.0
+    b = _run(eng, ids, src2)
+    uses_pad_as_token = (ids[:, 0] == cfg["pad_token_id"])
+    keep = torch.from_numpy(~uses_pad_as_token).cuda()
+    assert _eq([None if t is None else t[keep] for t in a], [None if t is None else t[keep] for t in b])
+
+
+def test_fp16_source_equals_upcast():
+    cfg, *_ = synth.workload("tiny")
+    eng = _engine(cfg, 3, "f32")
+    src16 = torch.from_numpy(synth.make_source_embeddings(cfg, 3, dtype="float16")).cuda()
+    ids = synth.make_surface_forms(cfg, 256, seed=3)
+    assert _eq(_run(eng, ids, src16, 1), _run(eng, ids, src16.float(), 1))
+    assert _eq(_run(eng, ids, src16.float().bfloat16(), 1), _run(eng, ids, src16.float().bfloat16().float(), 1))
+
+
+def test_index_errors_like_f_embedding():
+    cfg, *_ = synth.workload("tiny")
+    eng = _engine(cfg, 4, "bf16")
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 4)).cuda()
+    ids = synth.make_surface_forms(cfg, 64, seed=4)
+    bad = ids.copy()
+    bad[10, 2] = cfg["original_vocab_size"] + max(cfg["hn_n_extra_tokens"], 1)     # one past the fallback rows
+    with pytest.raises(IndexError):
+        _run(eng, bad, src, 0)
+    bad = ids.copy()
+    bad[3, 0] = -1
+    with pytest.raises(IndexError):
+        _run(eng, bad, src, 0)
+    assert _eq(_run(eng, ids, src, 0), _run(eng, ids, src, 0))     # the handle survives an error
+
+
+def test_empty_and_single_row():
+    cfg, *_ = synth.workload("tiny")
+    eng = _engine(cfg, 5, "bf16")
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 5)).cuda()
+    out = _run(eng, np.zeros((0, 7), dtype=np.int32), src, 0)
+    assert out[0].shape == (0, 64) and out[2].shape == (0,)
+    ids = synth.make_surface_forms(cfg, 9, seed=5)
+    nine = _run(eng, ids, src, 0)
+    one = _run(eng, ids[4:5], src, 0)
+    assert _eq([None if t is None else t[4:5] for t in nine], one)
+
+
+@pytest.mark.parametrize("name,rows", [("xlmr_gpt2", 50350), ("mistral_gpt2_32k", 32768)])
+def test_full_size_shards_equal_whole(name, rows):
+    """BASELINE.json sizes: the 8-way row-sharded result is bit-identical to the 1-GPU result,
+    outputs are finite, and a sample of rows matches the oracle."""
+    from oracle import hypernet_ref
+    from zett_amd.sharding import shard_bounds
+    cfg, _, src_dtype, hist = synth.workload(name)
+    eng = _engine(cfg, 0, "bf16")
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 0, dtype=src_dtype)).cuda()
+    ids = synth.make_surface_forms(cfg, rows, seed=0, hist=hist, n_special=2)
+    lang = 3 if cfg.get("hn_embed_lang_id") else -1
+    full = _run(eng, ids, src, lang)
+    assert all(t is None or bool(torch.isfinite(t).all()) for t in full)
+    st = eng.stats()
+    assert st["rows"] == rows and 0 < st["packed_tokens"] <= rows * 8 and 0 < st["distinct_ids"]
+    parts = [_run(eng, ids[slice(*shard_bounds(rows, 8, r))], src, lang) for r in range(8)]
+    cat = [None if parts[0][k] is None else torch.cat([p[k] for p in parts]) for k in range(3)]
+    assert _eq(cat, full)
+    if name == "xlmr_gpt2":     # oracle on a row sample (the big shapes are covered by the golden fixtures)
+        from bench import device_weights
+        w = {k: v.cpu().numpy() for k, v in device_weights(cfg, torch.device("cuda:0"), seed=0).items()}
+        sample = np.random.default_rng(0).choice(rows, 96, replace=False)
+        want = hypernet_ref.forward(w, cfg, ids[sample], src.cpu().numpy(), lang)
+        got = [None if t is None else t[torch.from_numpy(sample).cuda()].cpu().numpy() for t in full]
+        util.assert_bf16_close(got[0], want[0], "xlmr full-size sample pred_in")
+        util.assert_bf16_close(got[2], want[2], "xlmr full-size sample bias")

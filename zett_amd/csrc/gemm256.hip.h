@@ -1,0 +1,206 @@
+// gemm256.hip.h — the large-tile MFMA GEMM for gfx950: 256x256 output tile, 8 waves,
+// K staged 128 bytes per row and step straight from HBM/L2 into LDS by the LDS-DMA path
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass), two LDS stages of
+// 64 KiB so the DMA of K-step t+1 runs under the MFMAs of K-step t, one barrier per step.
+//
+//   C[M,N] = epilogue( A[M,K] · W[N,K]ᵀ )      (same contract and epilogue as gemm.hip.h)
+//
+// LDS image per operand and stage: 256 rows x 128 B, 16-byte chunks XOR-swizzled by
+// (row>>1)&7.  LDS-DMA writes are lane-linear (wave-uniform base + lane*16), so the swizzle
+// is applied to each lane's SOURCE address (the 8 lanes of a row permute the 8 chunks of
+// one 128-byte line: still one coalesced line per row) and undone by the same XOR on the
+// ds_read_b128 side.
+//
+// Waves are laid out 2 (M) x 4 (N); a wave owns 128x64 of the tile = 4x2 MFMA tiles of
+// 32x32 (128 accumulator registers).  Per 16-byte K chunk a wave issues 6 ds_read_b128
+// (4 A, 2 W) for 8 v_mfma_f32_32x32x16_bf16 (or 32 v_mfma_f32_32x32x2_f32 in fp32 mode).
+// The reduction order over K is fixed, so a row's result does not depend on M or on
+// where the row sits in the launch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.hip.h"
+
+namespace zett {
+
+constexpr int G256_BM = 256;
+constexpr int G256_BN = 256;
+constexpr int G256_OPERAND_BYTES = G256_BM * GEMM_ROW_BYTES;      // 32 KiB
+constexpr int G256_STAGE_BYTES = 2 * G256_OPERAND_BYTES;          // A + W = 64 KiB
+constexpr int G256_LDS_BYTES = 2 * G256_STAGE_BYTES;              // 128 KiB
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <typename T> __device__ __forceinline__ void store_out4(T* dst, float4 v);
+template <> __device__ __forceinline__ void store_out4<float>(float* dst, float4 v) { *(float4*)dst = v; }
+template <> __device__ __forceinline__ void store_out4<bf16_t>(bf16_t* dst, float4 v) {
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *(uint2*)dst = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm256_tn_kernel(GemmArgs<T> g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
+
+    const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
+    const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
+    const int nwg = tiles_m * tiles_n;
+    int wg = blockIdx.x;
+    {   // XCD-aware order (block b runs on XCD b % 8): give each XCD a contiguous tile range
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    constexpr int GROUP_M = 8;
+    const int group_size = GROUP_M * tiles_n;
+    const int first_m = (wg / group_size) * GROUP_M;
+    const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+    const int tm = first_m + (wg % group_size) % gm;
+    const int tn = (wg % group_size) / gm;
+    const int m0 = tm * G256_BM, n0 = tn * G256_BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // LDS-DMA plan: a wave instruction moves 64 x 16 B = 8 rows of 128 B.  The 8 waves x 4
+    // instructions cover the 256 rows of one operand; lane l of instruction j of wave w
+    // fills physical slot (row = w*32 + j*8 + l/8, chunk = l%8) from logical chunk
+    // (l%8) ^ swz(row).
+    const unsigned char* a_src[4];
+    const unsigned char* w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave * 32 + j * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+        int ar = m0 + row; ar = ar < g.M ? ar : g.M - 1;
+        int wr = n0 + row; wr = wr < g.N ? wr : g.N - 1;
+        a_src[j] = (const unsigned char*)(g.A + (size_t)ar * g.lda) + ch * 16;
+        w_src[j] = (const unsigned char*)(g.W + (size_t)wr * g.ldw) + ch * 16;
+    }
+    const int dma_base = wave * 32 * GEMM_ROW_BYTES;    // byte offset of this wave's 32 rows in an operand image
+
+    auto issue_stage = [&](int kt, int stage) {
+        unsigned char* sa = smem + stage * G256_STAGE_BYTES + dma_base;
+        unsigned char* sw = sa + G256_OPERAND_BYTES;
+        const size_t koff = (size_t)kt * GEMM_ROW_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[j] + koff), (lds_ptr_t)(sa + j * 8 * GEMM_ROW_BYTES), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[j] + koff), (lds_ptr_t)(sw + j * 8 * GEMM_ROW_BYTES), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets (bytes) inside an operand image, without the chunk term
+    int a_row[4], w_row[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_row[i] = wm * 128 + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w_row[j] = wn * 64 + j * 32 + l31;
+
+    const int nk = g.K / BK;
+    issue_stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // every wave's DMA for step kt has landed (the barrier carries vmcnt(0)) and every
+        // wave is done reading the other stage
+        __syncthreads();
+        if (kt + 1 < nk) issue_stage(kt + 1, (kt + 1) & 1);
+        const unsigned char* As = smem + (kt & 1) * G256_STAGE_BYTES;
+        const unsigned char* Ws = As + G256_OPERAND_BYTES;
+        // register double-buffered fragments: the ds_reads of chunk kk+1 are in flight under
+        // the 8 MFMAs of chunk kk
+        u32x4 fa[2][4], fw[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[0][i] = *(const u32x4*)(As + lds_chunk_off(a_row[i], hi));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fw[0][j] = *(const u32x4*)(Ws + lds_chunk_off(w_row[j], hi));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk < 3) {
+                const int ch = (kk + 1) * 2 + hi;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[nxt][i] = *(const u32x4*)(As + lds_chunk_off(a_row[i], ch));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fw[nxt][j] = *(const u32x4*)(Ws + lds_chunk_off(w_row[j], ch));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mfma_chunk<T>(fa[cur][i], fw[cur][j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue.  The accumulators go through LDS (free now) so that global traffic is
+    // row-contiguous: each wave owns a private 16 KiB region = 64 rows x 64 fp32, filled from
+    // the MFMA layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) and drained
+    // as float4 per lane, 16 lanes per 256-byte row segment.
+    __syncthreads();                                  // all waves are done with the K stages
+    float* region = (float*)(smem + wave * 16384);
+    const GemmEpilogue<T>& e = g.epi;
+    const int c4 = (lane & 15) * 4;
+    const int gcol = n0 + wn * 64 + c4;
+    const bool col_ok = gcol < g.N;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = bias4;
+    if (col_ok) {
+        if (e.bias) bias4 = *(const float4*)(e.bias + gcol);
+        if (e.scale) sc4 = *(const float4*)(e.scale + gcol);
+        if (e.shift) sh4 = *(const float4*)(e.shift + gcol);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    region[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + l31] = acc[2 * p + i2][j][r];
+        for (int t = 0; t < 16; ++t) {
+            const int lrow = t * 4 + (lane >> 4);
+            const int grow = m0 + wm * 128 + p * 64 + lrow;
+            float4 v = *(const float4*)(region + lrow * 64 + c4);
+            if (grow >= g.M || !col_ok) continue;
+            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+            if (e.act == ACT_GELU_TANH) { v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w); }
+            else if (e.act == ACT_GELU_ERF) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+            if (e.residual) {
+                const float4 rr = *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            if (e.scale) { v.x = sc4.x * v.x + sh4.x; v.y = sc4.y * v.y + sh4.y; v.z = sc4.z * v.z + sh4.z; v.w = sc4.w * v.w + sh4.w; }
+            if (gcol < e.split_col) {
+                if (e.out_f32) *(float4*)(e.out_f32 + (size_t)grow * e.ld_f32 + gcol) = v;
+                if (e.out_lo) store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, v);
+            } else if (e.out_f32_b) {
+                *(float4*)(e.out_f32_b + (size_t)grow * e.ld_f32 + (gcol - e.split_col)) = v;
+            }
+        }
+    }
+}
+
+template <typename T>
+inline hipError_t launch_gemm256(const GemmArgs<T>& g, hipStream_t stream) {
+    const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
+    const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
+    if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gemm256_tn_kernel<T>, dim3(tiles_m * tiles_n), dim3(512), G256_LDS_BYTES, stream, g);
+    return hipGetLastError();
+}
+
+}  // namespace zett

@@ -27,6 +27,7 @@
 #include "../../include/zett_hip.h"
 #include "common.hip.h"
 #include "gemm.hip.h"
+#include "gemm256.hip.h"
 #include "rowops.hip.h"
 #include "retok.hip.h"
 
@@ -61,6 +62,7 @@ struct zett_hypernet {
     int64_t max_chunk_tokens = 65536;
     int time_gemm = 0;
     int cls_only_last = 1;
+    int gemm_variant = 0;             // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA
     // workspace
     DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct;
     int32_t* host_pinned = nullptr;
@@ -169,6 +171,8 @@ int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm256_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
     auto* h = new zett_hypernet();
     h->cfg = *cfg;
     h->device = device;
@@ -309,6 +313,9 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
         h->time_gemm = value != 0;
     } else if (k == "cls_only_last_layer") {
         h->cls_only_last = value != 0;
+    } else if (k == "gemm_variant") {
+        if (value < 0 || value > 2) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto), 1 (128x128) or 2 (256x256)");
+        h->gemm_variant = (int)value;
     } else {
         return fail(ZETT_E_INVALID, "unknown option %s", key);
     }
@@ -329,6 +336,7 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
     const zett_config& c = h->cfg;
     if (n_rows < 0 || seq < 1) return fail(ZETT_E_INVALID, "bad surface-form shape [%lld, %d]", (long long)n_rows, seq);
     if (seq + (c.embed_lang ? 1 : 0) > c.max_positions) return fail(ZETT_E_INDEX, "sequence %d exceeds position_embeddings (%d rows)", seq, c.max_positions);
+    if (n_rows == 0) { h->stats = zett_stats{}; return 0; }
     if (!surface_forms || !source_embeddings || !out_in || !out_bias) return fail(ZETT_E_INVALID, "null tensor argument");
     const bool has_out = c.separate_out;
     if (has_out && !out_out) return fail(ZETT_E_INVALID, "out_out is required when separate_out_embeddings is set");
@@ -337,7 +345,6 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
     if (c.embed_lang && (lang_index < 0 || lang_index >= c.n_langs)) return fail(ZETT_E_INDEX, "lang_index %d outside [0,%d)", lang_index, c.n_langs);
     if (n_rows * (int64_t)(seq + 1) >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many positions for one call");
     HIP_TRY(hipSetDevice(h->device));
-    if (n_rows == 0) { h->stats = zett_stats{}; return 0; }
     hipStream_t st = (hipStream_t)stream;
     if (h->precision == ZETT_PREC_BF16)
         return do_forward<bf16_t>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);
@@ -381,7 +388,8 @@ struct Runner {
             h->ev_flops.push_back(fl);
             (void)hipEventRecord(e0, st);
         }
-        hipError_t err = launch_gemm<T>(g, st);
+        const bool big = h->gemm_variant == 2 || (h->gemm_variant == 0 && M > 128 && N > 128);
+        hipError_t err = big ? launch_gemm256<T>(g, st) : launch_gemm<T>(g, st);
         if (h->time_gemm) (void)hipEventRecord(e1, st);
         if (err != hipSuccess) { rc = fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(err)); return; }
         h->stats.executed_flops += fl;
