@@ -1,0 +1,154 @@
+// gemm_bench.hip — standalone microbenchmark / A-B harness for the GEMM kernels.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I zett_amd/csrc tools/gemm_bench.hip -o tools/gemm_bench
+//   ./tools/gemm_bench [M N K]...
+//
+// Random bf16 operands (uniform [-1,1) scaled), every variant checked against the
+// 128x128 register-staged kernel, timings from HIP events over interleaved rounds.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "gemm.hip.h"
+#include "gemm256.hip.h"
+#include "gemm256p.hip.h"
+#include "gemm256r.hip.h"
+
+using namespace zett;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_bf16(bf16_t* p, size_t n, uint32_t seed, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        const float f = ((float)(x & 0xffffff) / 8388608.0f - 1.0f) * scale;
+        p[i] = f32_to_bf16(f);
+    }
+}
+__global__ void fill_f32(float* p, size_t n, uint32_t seed, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = ((float)(x & 0xffffff) / 8388608.0f - 1.0f) * scale;
+    }
+}
+__global__ void max_diff(const bf16_t* a, const bf16_t* b, size_t n, float* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float m = 0.f;
+    for (; i < n; i += stride) m = fmaxf(m, fabsf(bf16_to_f32(a[i]) - bf16_to_f32(b[i])));
+    atomicMax((int*)out, __float_as_int(m));
+}
+
+struct Variant {
+    const char* name;
+    hipError_t (*launch)(const GemmArgs<bf16_t>&, hipStream_t);
+};
+
+int main(int argc, char** argv) {
+    std::vector<std::array<int, 3>> shapes;
+    for (int i = 1; i + 2 < argc; i += 3) shapes.push_back({atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2])});
+    if (shapes.empty())
+        shapes = {{8192, 8192, 8192}, {65536, 12288, 4096}, {65536, 4096, 4096}, {65536, 8192, 4096},
+                  {65536, 4096, 8192}, {29187, 4096, 8192}, {32768, 4096, 4096}, {5111, 4096, 4096}};
+    CK(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    std::vector<Variant> variants = {{"g128", launch_gemm<bf16_t>}, {"g256", launch_gemm256<bf16_t>}};
+    CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    variants.push_back({"g256p", launch_gemm256p<bf16_t, 0>});
+    CK(hipFuncSetAttribute((const void*)gemm256r_tn_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * R_SLOT_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm256r_tn_kernel<bf16_t, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * R_SLOT_BYTES));
+    variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>});
+    variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>});
+    CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
+    CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
+    CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
+    variants.push_back({"g256p_pf2", launch_gemm256p<bf16_t, 0, 2>});
+    variants.push_back({"g256p_pf3", launch_gemm256p<bf16_t, 0, 3>});
+    if (getenv("ABL")) variants.push_back({"nomfma_pf2", launch_gemm256p<bf16_t, 2, 2>});
+    if (getenv("ABL")) {
+        variants.push_back({"p_nodma", launch_gemm256p<bf16_t, 1>});
+        variants.push_back({"p_nomfma", launch_gemm256p<bf16_t, 2>});
+        CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+        CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+        variants.push_back({"nomfma_2xdma", launch_gemm256p<bf16_t, 3>});
+        variants.push_back({"nomfma_halfdma", launch_gemm256p<bf16_t, 4>});
+        CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+        variants.push_back({"mfma_only", launch_gemm256p<bf16_t, 5>});
+        CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+        variants.push_back({"mfma_nobar", launch_gemm256p<bf16_t, 6>});
+    }
+    const char* epi_env = getenv("EPI");     // 0 = bf16 out only, 1 = bias+gelu_erf bf16 out, 2 = bias+residual f32 out
+    const int epi_mode = epi_env ? atoi(epi_env) : 0;
+    const int rounds = getenv("ROUNDS") ? atoi(getenv("ROUNDS")) : 5;
+    for (auto& s : shapes) {
+        const int M = s[0], N = s[1], K = s[2];
+        bf16_t *A, *W, *C0, *C1;
+        float *bias, *res, *cf;
+        CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2));
+        CK(hipMalloc(&C0, (size_t)M * N * 2)); CK(hipMalloc(&C1, (size_t)M * N * 2));
+        CK(hipMalloc(&bias, (size_t)N * 4)); CK(hipMalloc(&res, (size_t)M * N * 4)); CK(hipMalloc(&cf, (size_t)M * N * 4));
+        fill_bf16<<<2048, 256>>>(A, (size_t)M * K, 1, 1.0f);
+        fill_bf16<<<2048, 256>>>(W, (size_t)N * K, 2, 0.05f);
+        fill_f32<<<64, 256>>>(bias, N, 3, 0.1f);
+        fill_f32<<<2048, 256>>>(res, (size_t)M * N, 4, 1.0f);
+        CK(hipDeviceSynchronize());
+        auto make = [&](bf16_t* out) {
+            GemmArgs<bf16_t> g{};
+            g.A = A; g.lda = getenv("LDA0") ? 0 : K; g.W = W; g.ldw = getenv("LDA0") ? 0 : K; g.M = M; g.N = N; g.K = K;
+            g.epi.split_col = 0x7fffffff;
+            if (epi_mode == 0) { g.epi.out_lo = out; g.epi.ld_lo = N; }
+            else if (epi_mode == 1) { g.epi.bias = bias; g.epi.act = ACT_GELU_ERF; g.epi.out_lo = out; g.epi.ld_lo = N; }
+            else { g.epi.bias = bias; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N; g.epi.out_lo = out; g.epi.ld_lo = N; }
+            return g;
+        };
+        float* dmax; CK(hipMalloc(&dmax, 4));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        GemmArgs<bf16_t> gref = make(C0);
+        CK(variants[0].launch(gref, 0)); CK(hipDeviceSynchronize());
+        std::vector<std::vector<float>> times(variants.size());
+        std::vector<float> diffs(variants.size(), 0.f);
+        for (size_t v = 1; v < variants.size(); ++v) {
+            CK(hipMemset(C1, 0xff, (size_t)M * N * 2));
+            GemmArgs<bf16_t> g = make(C1);
+            CK(variants[v].launch(g, 0)); CK(hipDeviceSynchronize());
+            CK(hipMemset(dmax, 0, 4));
+            max_diff<<<1024, 256>>>(C0, C1, (size_t)M * N, dmax);
+            CK(hipMemcpy(&diffs[v], dmax, 4, hipMemcpyDeviceToHost));
+        }
+        for (int r = 0; r < rounds; ++r) {
+            for (size_t v = 0; v < variants.size(); ++v) {
+                GemmArgs<bf16_t> g = make(C1);
+                CK(hipEventRecord(e0, 0));
+                for (int it = 0; it < 3; ++it) CK(variants[v].launch(g, 0));
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                times[v].push_back(ms / 3);
+            }
+        }
+        printf("M=%d N=%d K=%d epi=%d :", M, N, K, epi_mode);
+        for (size_t v = 0; v < variants.size(); ++v) {
+            std::sort(times[v].begin(), times[v].end());
+            const float med = times[v][times[v].size() / 2], best = times[v][0];
+            const double fl = 2.0 * M * N * K;
+            printf("  %s %.0f TF (best %.0f, %.3f ms, maxdiff %.3g)", variants[v].name, fl / med / 1e9, fl / best / 1e9, med, diffs[v]);
+        }
+        printf("\n");
+        fflush(stdout);
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C0)); CK(hipFree(C1)); CK(hipFree(bias)); CK(hipFree(res)); CK(hipFree(cf)); CK(hipFree(dmax));
+    }
+    return 0;
+}
