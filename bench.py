@@ -68,11 +68,9 @@ def cpu_baseline(cfg, weights, ids, src, lang, budget_s=15.0):
     """Time the numpy oracle (as-written reference math) on a bounded row sample."""
     from oracle import hypernet_ref
 
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    torch.set_num_threads(os.cpu_count() or 1)
+    hypernet_ref.set_matmul_backend("torch")      # same as-written math, GEMMs through torch's CPU BLAS
+    threads = torch.get_num_threads()
     w_np = {k: v.float().cpu().numpy() for k, v in weights.items()}
     src_np = src.cpu().numpy()
     probe = min(16, len(ids))
@@ -85,7 +83,8 @@ def cpu_baseline(cfg, weights, ids, src, lang, budget_s=15.0):
     out = hypernet_ref.forward(w_np, cfg, ids[:rows], src_np, lang)
     dt = time.perf_counter() - t0
     return {"value": rows / dt, "unit": "token-embeddings/s", "cores": int(threads), "kind": "port",
-            "sample": f"first {rows} rows of the workload, oracle/hypernet_ref.py (numpy fp32, as-written math), {dt:.1f} s"}, out, rows
+            "sample": f"first {rows} rows of the workload, oracle/hypernet_ref.py (fp32, as-written reference math, "
+                      f"GEMMs on torch CPU BLAS with {threads} threads), {dt:.1f} s"}, out, rows
 
 
 def main():
@@ -196,7 +195,7 @@ def main():
                    "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"]},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak if peak else None, "traffic": None,
-                     "kernel": "zett::gemm_tn_kernel", "launches_per_step": launches / max(args.steps, 1),
+                     "kernel": "zett::gemm256_tn_kernel (256x256 LDS-DMA MFMA GEMM; 128x128 variant for small M/N)", "launches_per_step": launches / max(args.steps, 1),
                      "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
                      "executed_tflop_per_step": gemm_fl / max(args.steps, 1) / 1e12},
         "as_written_tflops": rows * f_ref * args.steps / dt / 1e12,

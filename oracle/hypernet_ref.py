@@ -33,8 +33,26 @@ def _cfg(cfg, name, default=None):
     return getattr(cfg, name, default)
 
 
+_MATMUL_BACKEND = "numpy"
+
+
+def set_matmul_backend(name: str) -> None:
+    """"numpy" (default; what the parity tests use) or "torch": the same fp32 GEMMs through
+    torch's CPU BLAS, which threads far better on many-core hosts — used only by the timed
+    cpu_baseline leg of bench.py."""
+    global _MATMUL_BACKEND
+    assert name in ("numpy", "torch")
+    _MATMUL_BACKEND = name
+
+
 def linear(x, w, b):
     """torch.nn.Linear: x @ w.T + b (fp32)."""
+    if _MATMUL_BACKEND == "torch":
+        import torch
+        x2 = np.ascontiguousarray(x, dtype=F32).reshape(-1, x.shape[-1])
+        y = torch.addmm(torch.from_numpy(np.ascontiguousarray(b, dtype=F32)), torch.from_numpy(x2),
+                        torch.from_numpy(np.ascontiguousarray(w, dtype=F32)).t()).numpy()
+        return y.reshape(x.shape[:-1] + (w.shape[0],))
     return (x @ w.T + b).astype(F32, copy=False)
 
 
