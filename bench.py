@@ -68,9 +68,27 @@ def cpu_baseline(cfg, weights, ids, src, lang, budget_s=15.0):
     """Time the numpy oracle (as-written reference math) on a bounded row sample."""
     from oracle import hypernet_ref
 
-    torch.set_num_threads(os.cpu_count() or 1)
     hypernet_ref.set_matmul_backend("torch")      # same as-written math, GEMMs through torch's CPU BLAS
-    threads = torch.get_num_threads()
+    # pick the thread count that actually gives the best GEMM rate on this host (container CPU quotas
+    # make os.cpu_count() a poor guide): short calibration on an [1024, 4096] x [4096, 4096] product
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    xa, xb = torch.randn(1024, 4096), torch.randn(4096, 4096)
+    best_rate, threads = 0.0, 1
+    for nt in sorted({t for t in (4, 8, 16, 32, 64, 128, avail) if t <= avail}):
+        torch.set_num_threads(nt)
+        torch.mm(xa, xb)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 0.4:
+            torch.mm(xa, xb)
+            reps += 1
+        rate = reps / (time.perf_counter() - t0)
+        if rate > best_rate * 1.05:
+            best_rate, threads = rate, nt
+    torch.set_num_threads(threads)
     w_np = {k: v.float().cpu().numpy() for k, v in weights.items()}
     src_np = src.cpu().numpy()
     probe = min(16, len(ids))
@@ -96,7 +114,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--rows", type=int, default=0, help="override the vocab size of the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
