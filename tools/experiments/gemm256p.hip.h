@@ -21,6 +21,8 @@
 // group 1 reads in tick 2t+1 and multiplies in tick 2t+2; every wave drains its DMA share
 // at the end of the odd ticks.  The K reduction order is fixed (row results do not depend
 // on M or on the position of the row).
+// EXPERIMENT (not part of libzett_hip.so): built only by tools/gemm_bench.hip; measured
+// results and why the product does not use it are in DESIGN.md §4.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[j] + koff), (lds_ptr_t)(sa + j * 8 * GEMM_ROW_BYTES), 16, 0, 0);
-            if (ABL != 4) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[j] + koff), (lds_ptr_t)(sw + j * 8 * GEMM_ROW_BYTES), 16, 0, 0);
+            if (ABL != 4 && ABL != 7) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[j] + koff), (lds_ptr_t)(sw + j * 8 * GEMM_ROW_BYTES), 16, 0, 0);
         }
     };
 

@@ -20,6 +20,8 @@
 // LDS slot image: A rows then W rows, 64 bytes per row, 16-byte chunks XOR-swizzled by
 // (row>>2)&3 (conflict-free for ds_read_b128: a 16-lane group touches 16 distinct slots of
 // the 256-byte bank row); the DMA applies the same XOR to the source chunk of each lane.
+// EXPERIMENT (not part of libzett_hip.so): built only by tools/gemm_bench.hip; measured
+// results and why the product does not use it are in DESIGN.md §4.
 #pragma once
 
 #include <hip/hip_runtime.h>

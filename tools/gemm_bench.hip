@@ -1,6 +1,6 @@
 // gemm_bench.hip — standalone microbenchmark / A-B harness for the GEMM kernels.
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I zett_amd/csrc tools/gemm_bench.hip -o tools/gemm_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I zett_amd/csrc -I tools/experiments tools/gemm_bench.hip -o tools/gemm_bench
 //   ./tools/gemm_bench [M N K]...
 //
 // Random bf16 operands (uniform [-1,1) scaled), every variant checked against the
@@ -18,6 +18,8 @@
 #include "gemm256.hip.h"
 #include "gemm256p.hip.h"
 #include "gemm256r.hip.h"
+#include "gemm256e.hip.h"
+#include "gemm384.hip.h"
 
 using namespace zett;
 
@@ -63,20 +65,32 @@ int main(int argc, char** argv) {
                   {65536, 4096, 8192}, {29187, 4096, 8192}, {32768, 4096, 4096}, {5111, 4096, 4096}};
     CK(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
-    std::vector<Variant> variants = {{"g128", launch_gemm<bf16_t>}, {"g256", launch_gemm256<bf16_t>}};
+    std::vector<Variant> variants = {{"g128", launch_gemm<bf16_t>}, {"g256", launch_gemm256<bf16_t, 0>}};
+    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    variants.push_back({"g256_spread", launch_gemm256<bf16_t, 1>});
+    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    variants.push_back({"spread_ntA", launch_gemm256<bf16_t, 5>});
+    variants.push_back({"spread_ntW", launch_gemm256<bf16_t, 9>});
+    variants.push_back({"spread_ntAW", launch_gemm256<bf16_t, 13>});
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
     variants.push_back({"g256p", launch_gemm256p<bf16_t, 0>});
     CK(hipFuncSetAttribute((const void*)gemm256r_tn_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * R_SLOT_BYTES));
     CK(hipFuncSetAttribute((const void*)gemm256r_tn_kernel<bf16_t, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * R_SLOT_BYTES));
-    variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>});
-    variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>});
+    CK(hipFuncSetAttribute((const void*)gemm256e_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES));
+    variants.push_back({"g256e", launch_gemm256e<bf16_t>});
+    CK(hipFuncSetAttribute((const void*)gemm384_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, G384_LDS_BYTES));
+    variants.push_back({"g384", launch_gemm384<bf16_t>});
+    if (getenv("RING")) { variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>}); variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>}); }
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
-    variants.push_back({"g256p_pf2", launch_gemm256p<bf16_t, 0, 2>});
-    variants.push_back({"g256p_pf3", launch_gemm256p<bf16_t, 0, 3>});
+    if (getenv("PF")) { variants.push_back({"g256p_pf2", launch_gemm256p<bf16_t, 0, 2>}); variants.push_back({"g256p_pf3", launch_gemm256p<bf16_t, 0, 3>}); }
     if (getenv("ABL")) variants.push_back({"nomfma_pf2", launch_gemm256p<bf16_t, 2, 2>});
     if (getenv("ABL")) {
         variants.push_back({"p_nodma", launch_gemm256p<bf16_t, 1>});
@@ -89,6 +103,8 @@ int main(int argc, char** argv) {
         variants.push_back({"mfma_only", launch_gemm256p<bf16_t, 5>});
         CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
         variants.push_back({"mfma_nobar", launch_gemm256p<bf16_t, 6>});
+        CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+        variants.push_back({"full_halfdma", launch_gemm256p<bf16_t, 7>});
     }
     const char* epi_env = getenv("EPI");     // 0 = bf16 out only, 1 = bias+gelu_erf bf16 out, 2 = bias+residual f32 out
     const int epi_mode = epi_env ? atoi(epi_env) : 0;
@@ -97,7 +113,7 @@ int main(int argc, char** argv) {
         const int M = s[0], N = s[1], K = s[2];
         bf16_t *A, *W, *C0, *C1;
         float *bias, *res, *cf;
-        CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2));
+        CK(hipMalloc(&A, ((size_t)M + 512) * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2));
         CK(hipMalloc(&C0, (size_t)M * N * 2)); CK(hipMalloc(&C1, (size_t)M * N * 2));
         CK(hipMalloc(&bias, (size_t)N * 4)); CK(hipMalloc(&res, (size_t)M * N * 4)); CK(hipMalloc(&cf, (size_t)M * N * 4));
         fill_bf16<<<2048, 256>>>(A, (size_t)M * K, 1, 1.0f);

@@ -43,7 +43,9 @@ template <> __device__ __forceinline__ void store_out4<bf16_t>(bf16_t* dst, floa
     *(uint2*)dst = o;
 }
 
-template <typename T>
+// VAR (experiments, tools/gemm_bench): bit 0 = spread the DMA issue over the 4 K chunks of a step,
+// bit 1 = s_setprio(1) around the MFMA groups.  The product uses VAR = 0.
+template <typename T, int VAR = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm256_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // every wave's DMA for step kt has landed (the barrier carries vmcnt(0)) and every
         // wave is done reading the other stage
         __syncthreads();
-        if (kt + 1 < nk) issue_stage(kt + 1, (kt + 1) & 1);
+        const bool more = kt + 1 < nk;
+        if (more && !(VAR & 1)) issue_stage(kt + 1, (kt + 1) & 1);
         const unsigned char* As = smem + (kt & 1) * G256_STAGE_BYTES;
         const unsigned char* Ws = As + G256_OPERAND_BYTES;
         // register double-buffered fragments: the ds_reads of chunk kk+1 are in flight under
@@ -132,6 +135,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
+            if ((VAR & 1) && more) {   // one quarter of the next stage per chunk: A piece kk and W piece kk
+                unsigned char* sa = smem + ((kt + 1) & 1) * G256_STAGE_BYTES + dma_base;
+                const size_t koff = (size_t)(kt + 1) * GEMM_ROW_BYTES;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[kk] + koff), (lds_ptr_t)(sa + kk * 8 * GEMM_ROW_BYTES), 16, 0, (VAR & 4) ? 2 : 0);
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[kk] + koff), (lds_ptr_t)(sa + G256_OPERAND_BYTES + kk * 8 * GEMM_ROW_BYTES), 16, 0, (VAR & 8) ? 2 : 0);
+            }
             if (kk < 3) {
                 const int ch = (kk + 1) * 2 + hi;
 #pragma unroll
@@ -139,10 +148,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fw[nxt][j] = *(const u32x4*)(Ws + lds_chunk_off(w_row[j], ch));
             }
+            if (VAR & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mfma_chunk<T>(fa[cur][i], fw[cur][j], acc[i][j]);
+            if (VAR & 2) __builtin_amdgcn_s_setprio(0);
         }
     }
 
@@ -194,12 +205,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <typename T>
+template <typename T, int VAR = 0>
 inline hipError_t launch_gemm256(const GemmArgs<T>& g, hipStream_t stream) {
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gemm256_tn_kernel<T>, dim3(tiles_m * tiles_n), dim3(512), G256_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm256_tn_kernel<T, VAR>), dim3(tiles_m * tiles_n), dim3(512), G256_LDS_BYTES, stream, g);
     return hipGetLastError();
 }
 

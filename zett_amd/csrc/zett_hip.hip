@@ -28,6 +28,7 @@
 #include "common.hip.h"
 #include "gemm.hip.h"
 #include "gemm256.hip.h"
+#include "gemm384.hip.h"
 #include "rowops.hip.h"
 #include "retok.hip.h"
 
@@ -62,7 +63,7 @@ struct zett_hypernet {
     int64_t max_chunk_tokens = 65536;
     int time_gemm = 0;
     int cls_only_last = 1;
-    int gemm_variant = 0;             // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA
+    int gemm_variant = 0;             // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA, 3 = 384x256 LDS-DMA
     // workspace
     DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct;
     int32_t* host_pinned = nullptr;
@@ -171,8 +172,10 @@ int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm256_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm256_tn_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm384_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, G384_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm384_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, G384_LDS_BYTES));
     auto* h = new zett_hypernet();
     h->cfg = *cfg;
     h->device = device;
@@ -314,7 +317,7 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "cls_only_last_layer") {
         h->cls_only_last = value != 0;
     } else if (k == "gemm_variant") {
-        if (value < 0 || value > 2) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto), 1 (128x128) or 2 (256x256)");
+        if (value < 0 || value > 3) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (384x256)");
         h->gemm_variant = (int)value;
     } else {
         return fail(ZETT_E_INVALID, "unknown option %s", key);
@@ -372,6 +375,8 @@ struct Runner {
         return e;
     }
 
+    long a_rows_readable = 0;   // rows every A operand buffer can be read for (workspace slack)
+
     void gemm(const T* A, int lda, const T* Wp, int ldw, int M, int N, int K, const GemmEpilogue<T>& e) {
         if (rc || M <= 0) return;
         GemmArgs<T> g{A, lda, Wp, ldw, M, N, K, e};
@@ -388,8 +393,22 @@ struct Runner {
             h->ev_flops.push_back(fl);
             (void)hipEventRecord(e0, st);
         }
-        const bool big = h->gemm_variant == 2 || (h->gemm_variant == 0 && M > 128 && N > 128);
-        hipError_t err = big ? launch_gemm256<T>(g, st) : launch_gemm<T>(g, st);
+        // Tile choice.  Small problems: 128x128.  Otherwise 256x256, unless the 384x256 tile
+        // needs fewer rounds over the 256 CUs (it runs ~1.55x as long per tile): wave
+        // quantisation decides, e.g. M = 29 187 or M = 5 111 at N = 4096.  The 384-row kernel
+        // does not clamp rows, so A must have `a_rows_readable` >= tiles*384 rows (every A
+        // operand here is a workspace buffer with that slack) and N must be a multiple of 256.
+        int variant = h->gemm_variant;
+        if (variant == 0) {
+            variant = (M > 128 && N > 128) ? 2 : 1;
+            if (variant == 2 && N % 256 == 0) {
+                const long t256 = (long)((M + 255) / 256) * (N / 256), t384 = (long)((M + 383) / 384) * (N / 256);
+                const double c256 = (double)((t256 + 255) / 256), c384 = 1.55 * (double)((t384 + 255) / 256);
+                if (c384 < c256) variant = 3;
+            }
+        }
+        if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable)) variant = 2;
+        hipError_t err = variant == 3 ? launch_gemm384<T>(g, st) : variant == 2 ? launch_gemm256<T, 1>(g, st) : launch_gemm<T>(g, st);
         if (h->time_gemm) (void)hipEventRecord(e1, st);
         if (err != hipSuccess) { rc = fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(err)); return; }
         h->stats.executed_flops += fl;
@@ -497,15 +516,16 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     const int64_t MC = std::max<int64_t>(std::min<int64_t>(cap, std::max<int64_t>(Ttot, D)), seq + lam);
     const size_t es = sizeof(T);
     const size_t wide = (size_t)std::max(I, 3 * H);
+    const size_t MCS = (size_t)MC + 384;      // slack rows: the 384-row GEMM tile reads whole tiles of A
     if (int rc = h->table.reserve((size_t)D * H * 4)) return rc;
-    if (int rc = h->x0.reserve((size_t)MC * EIN * es)) return rc;
+    if (int rc = h->x0.reserve(MCS * EIN * es)) return rc;
     if (int rc = h->yf.reserve((size_t)MC * H * 4)) return rc;
-    if (int rc = h->yt.reserve((size_t)MC * H * es)) return rc;
-    if (int rc = h->big.reserve((size_t)MC * wide * es)) return rc;
+    if (int rc = h->yt.reserve(MCS * H * es)) return rc;
+    if (int rc = h->big.reserve(MCS * wide * es)) return rc;
     if (int rc = h->pre.reserve((size_t)MC * H * 4)) return rc;
-    if (int rc = h->ctx.reserve((size_t)MC * H * es)) return rc;
+    if (int rc = h->ctx.reserve(MCS * H * es)) return rc;
     if (int rc = h->cf.reserve((size_t)MC * H * 4)) return rc;
-    if (int rc = h->ct.reserve((size_t)MC * H * es)) return rc;
+    if (int rc = h->ct.reserve(MCS * H * es)) return rc;
     float* TBL = h->table.as<float>();
     T* X0 = h->x0.as<T>();
     float* Zf = h->yf.as<float>();
@@ -517,6 +537,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     T* Ct = h->ct.as<T>();
 
     Runner<T> R{h, st};
+    R.a_rows_readable = (long)MCS;
 
     // ---- table: input_projection once per distinct source id (A2-A4) -----------------
     const float* in_w = c.rescale ? R.Wf("in_scaler.w") : nullptr;
