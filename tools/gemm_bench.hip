@@ -64,18 +64,9 @@ int main(int argc, char** argv) {
         shapes = {{8192, 8192, 8192}, {65536, 12288, 4096}, {65536, 4096, 4096}, {65536, 8192, 4096},
                   {65536, 4096, 8192}, {29187, 4096, 8192}, {32768, 4096, 4096}, {5111, 4096, 4096}};
     CK(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
     std::vector<Variant> variants = {{"g128", launch_gemm<bf16_t>}, {"g256", launch_gemm256<bf16_t, 0>}};
-    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
     variants.push_back({"g256_spread", launch_gemm256<bf16_t, 1>});
-    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
-    CK(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
-    variants.push_back({"spread_ntA", launch_gemm256<bf16_t, 5>});
-    variants.push_back({"spread_ntW", launch_gemm256<bf16_t, 9>});
-    variants.push_back({"spread_ntAW", launch_gemm256<bf16_t, 13>});
+    variants.push_back({"spread_skew", launch_gemm256<bf16_t, 17>});
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
@@ -84,7 +75,6 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)gemm256r_tn_kernel<bf16_t, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * R_SLOT_BYTES));
     CK(hipFuncSetAttribute((const void*)gemm256e_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES));
     variants.push_back({"g256e", launch_gemm256e<bf16_t>});
-    CK(hipFuncSetAttribute((const void*)gemm384_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, G384_LDS_BYTES));
     variants.push_back({"g384", launch_gemm384<bf16_t>});
     if (getenv("RING")) { variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>}); variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>}); }
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));

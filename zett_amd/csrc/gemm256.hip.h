@@ -45,7 +45,7 @@ template <> __device__ __forceinline__ void store_out4<bf16_t>(bf16_t* dst, floa
 
 // VAR (experiments, tools/gemm_bench): bit 0 = spread the DMA issue over the 4 K chunks of a step,
 // bit 1 = s_setprio(1) around the MFMA groups.  The product uses VAR = 0.
-template <typename T, int VAR = 0>
+template <typename T, int VAR = 0, int ACT = ACT_NONE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm256_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
@@ -116,6 +116,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < 2; ++j) w_row[j] = wn * 64 + j * 32 + l31;
 
     const int nk = g.K / BK;
+    if ((VAR & 16) && blockIdx.x < 256) {
+        // experiment: skew the first round of workgroups by eighths of a tile time so that the
+        // store bursts of the epilogues of different CUs do not coincide
+        const int delay = ((blockIdx.x >> 3) & 7) * nk * 5;      // in units of 64 cycles: a tile is ~nk*2600 cycles
+        for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     issue_stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         // every wave's DMA for step kt has landed (the barrier carries vmcnt(0)) and every
@@ -175,6 +181,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
+        // the residual rows of this pass are requested first, all at once, so that their
+        // latencies overlap each other and the LDS staging below
+        float4 rr[16];
+        if (e.residual && col_ok) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int lrow = t * 4 + (lane >> 4);
+                const int grow = m0 + wm * 128 + p * 64 + lrow;
+                rr[t] = grow < g.M ? *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -182,18 +199,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     region[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + l31] = acc[2 * p + i2][j][r];
+#pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int lrow = t * 4 + (lane >> 4);
             const int grow = m0 + wm * 128 + p * 64 + lrow;
             float4 v = *(const float4*)(region + lrow * 64 + c4);
             if (grow >= g.M || !col_ok) continue;
             v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-            if (e.act == ACT_GELU_TANH) { v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w); }
-            else if (e.act == ACT_GELU_ERF) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
-            if (e.residual) {
-                const float4 rr = *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol);
-                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-            }
+            if (ACT == ACT_GELU_TANH) { v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w); }
+            else if (ACT == ACT_GELU_ERF) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+            if (e.residual) { v.x += rr[t].x; v.y += rr[t].y; v.z += rr[t].z; v.w += rr[t].w; }
             if (e.scale) { v.x = sc4.x * v.x + sh4.x; v.y = sc4.y * v.y + sh4.y; v.z = sc4.z * v.z + sh4.z; v.w = sc4.w * v.w + sh4.w; }
             if (gcol < e.split_col) {
                 if (e.out_f32) *(float4*)(e.out_f32 + (size_t)grow * e.ld_f32 + gcol) = v;
@@ -205,13 +220,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <typename T, int VAR = 0>
-inline hipError_t launch_gemm256(const GemmArgs<T>& g, hipStream_t stream) {
+template <typename T, int VAR, int ACT>
+inline hipError_t launch_gemm256_act(const GemmArgs<T>& g, hipStream_t stream) {
+    static bool attr_set = false;     // > 64 KiB of dynamic LDS needs the attribute once per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_tn_kernel<T, VAR, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
-    hipLaunchKernelGGL((gemm256_tn_kernel<T, VAR>), dim3(tiles_m * tiles_n), dim3(512), G256_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm256_tn_kernel<T, VAR, ACT>), dim3(tiles_m * tiles_n), dim3(512), G256_LDS_BYTES, stream, g);
     return hipGetLastError();
+}
+
+template <typename T, int VAR = 0>
+inline hipError_t launch_gemm256(const GemmArgs<T>& g, hipStream_t stream) {
+    switch (g.epi.act) {
+        case ACT_GELU_TANH: return launch_gemm256_act<T, VAR, ACT_GELU_TANH>(g, stream);
+        case ACT_GELU_ERF: return launch_gemm256_act<T, VAR, ACT_GELU_ERF>(g, stream);
+        default: return launch_gemm256_act<T, VAR, ACT_NONE>(g, stream);
+    }
 }
 
 }  // namespace zett

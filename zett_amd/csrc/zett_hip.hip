@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <cstdlib>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -71,6 +73,7 @@ struct zett_hypernet {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     std::vector<double> ev_flops;
+    std::vector<std::array<int, 4>> ev_shape;   // M, N, K, variant of each timed launch
     zett_stats stats{};
 };
 
@@ -172,10 +175,6 @@ int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm256_tn_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm256_tn_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm384_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, G384_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm384_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, G384_LDS_BYTES));
     auto* h = new zett_hypernet();
     h->cfg = *cfg;
     h->device = device;
@@ -391,6 +390,7 @@ struct Runner {
             e0 = h->ev[h->ev_used++];
             e1 = h->ev[h->ev_used++];
             h->ev_flops.push_back(fl);
+            h->ev_shape.push_back({M, N, K, 0});
             (void)hipEventRecord(e0, st);
         }
         // Tile choice.  Small problems: 128x128.  Otherwise 256x256, unless the 384x256 tile
@@ -408,6 +408,7 @@ struct Runner {
             }
         }
         if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable)) variant = 2;
+        if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
         hipError_t err = variant == 3 ? launch_gemm384<T>(g, st) : variant == 2 ? launch_gemm256<T, 1>(g, st) : launch_gemm<T>(g, st);
         if (h->time_gemm) (void)hipEventRecord(e1, st);
         if (err != hipSuccess) { rc = fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(err)); return; }
@@ -463,6 +464,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     h->stats.rows = N;
     h->ev_used = 0;
     h->ev_flops.clear();
+    h->ev_shape.clear();
 
     // ---- plan ---------------------------------------------------------------------
     // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] err[1]
@@ -658,6 +660,15 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         }
         h->stats.gemm_ms = ms;
         h->stats.gemm_flops_timed = fl;
+        if (getenv("ZETT_GEMM_LOG")) {
+            for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+                float t = 0.f;
+                (void)hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]);
+                const auto& sh = h->ev_shape[i / 2];
+                fprintf(stderr, "[zett gemm] M=%6d N=%6d K=%5d tile=%s %8.3f ms %7.1f TF\n", sh[0], sh[1], sh[2],
+                        sh[3] == 3 ? "384" : sh[3] == 2 ? "256" : "128", t, h->ev_flops[i / 2] / (t * 1e9));
+            }
+        }
     }
     return 0;
 }
