@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Per-kernel summary of rocprofv3 --pmc counter_collection CSVs (one directory per counter pass).
+
+    python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_MFMA
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
+(MI355X_MICROARCH.md §HBM), so the read figure printed here is FETCH_SIZE * 2 * 1024 bytes; WRITE_SIZE
+is used as reported.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs).
+"""
+import collections
+import csv
+import glob
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name).replace("void ", "").replace("unsigned short", "bf16")
+    return name[:60]
+
+
+def main(dirs):
+    data = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for path in glob.glob(d + "/*counter_collection.csv"):
+            for r in csv.DictReader(open(path)):
+                k = short(r["Kernel_Name"])
+                data[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                data[k]["_dur_" + r["Counter_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    print("| kernel | launches | avg us | HBM read GB/launch (FETCH_SIZE x2) | HBM write GB/launch | read+write GB/s | MFMA util | clock GHz |")
+    print("|---|---|---|---|---|---|---|---|")
+    rows = []
+    for k, v in data.items():
+        if "zett::" not in k:
+            continue
+        n = max(len(x) for x in v.values())
+        def avg(c):
+            return sum(v[c]) / len(v[c]) if c in v and v[c] else None
+        fetch, write = avg("FETCH_SIZE"), avg("WRITE_SIZE")
+        dur = avg("_dur_FETCH_SIZE") or avg("_dur_WRITE_SIZE") or avg("_dur_GRBM_GUI_ACTIVE")
+        rd = None if fetch is None else fetch * 2 * 1024 / 1e9
+        wr = None if write is None else write * 1024 / 1e9
+        util = clk = None
+        if avg("SQ_VALU_MFMA_BUSY_CYCLES") is not None and avg("GRBM_GUI_ACTIVE"):
+            cyc = avg("GRBM_GUI_ACTIVE") / 8
+            util = avg("SQ_VALU_MFMA_BUSY_CYCLES") / (cyc * 1024)
+            clk = cyc / avg("_dur_GRBM_GUI_ACTIVE")
+        bw = None if rd is None or wr is None or not dur else (rd + wr) / (dur * 1e-9)
+        rows.append((-(dur or 0) * n, k, n, dur, rd, wr, bw, util, clk))
+    f = lambda x, fmt: "" if x is None else fmt % x
+    for _, k, n, dur, rd, wr, bw, util, clk in sorted(rows):
+        print(f"| {k} | {n} | {f(dur and dur / 1e3, '%.1f')} | {f(rd, '%.3f')} | {f(wr, '%.3f')} | {f(bw, '%.0f')} | {f(util, '%.3f')} | {f(clk, '%.2f')} |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
