@@ -56,7 +56,7 @@ __device__ __forceinline__ void e_barrier_vm0() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename T>
+template <typename T, int PRIO = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm256e_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
@@ -148,16 +148,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             fb0[kk] = *(const u32x4*)(S + w_off[0] + swz[kk]);
         }
         e_barrier();
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { mfma_chunk<T>(fa[0][kk], fb0[kk], acc[0][0]); mfma_chunk<T>(fa[1][kk], fb0[kk], acc[1][0]); }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         e_barrier();
         // ---- phase 1: (i0,i1) x j1
         if (t + 1 < nk) issue_half(t + 1, 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fb1[kk] = *(const u32x4*)(S + w_off[1] + swz[kk]);
         e_barrier();
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { mfma_chunk<T>(fa[0][kk], fb1[kk], acc[0][1]); mfma_chunk<T>(fa[1][kk], fb1[kk], acc[1][1]); }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         e_barrier();
         // ---- phase 2: (i2,i3) x j1
         if (t + 2 < nk) issue_half(t + 2, 2);
@@ -167,13 +171,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             fa[1][kk] = *(const u32x4*)(S + a_off[3] + swz[kk]);
         }
         e_barrier();
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { mfma_chunk<T>(fa[0][kk], fb1[kk], acc[2][1]); mfma_chunk<T>(fa[1][kk], fb1[kk], acc[3][1]); }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         e_barrier();
         // ---- phase 3: (i2,i3) x j0; the halves of step t+1 must be visible after its LOAD-part barrier
         if (t + 2 < nk) { issue_half(t + 2, 3); e_barrier_vm4(); } else { e_barrier_vm0(); }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { mfma_chunk<T>(fa[0][kk], fb0[kk], acc[2][0]); mfma_chunk<T>(fa[1][kk], fb0[kk], acc[3][0]); }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         e_barrier();
     }
     if (wm == 0) e_barrier();                      // group 0 waits for group 1's last MATH part
@@ -222,12 +230,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <typename T>
+template <typename T, int PRIO = 0>
 inline hipError_t launch_gemm256e(const GemmArgs<T>& g, hipStream_t stream) {
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gemm256e_tn_kernel<T>, dim3(tiles_m * tiles_n), dim3(512), E_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm256e_tn_kernel<T, PRIO>), dim3(tiles_m * tiles_n), dim3(512), E_LDS_BYTES, stream, g);
     return hipGetLastError();
 }
 

@@ -73,8 +73,10 @@ int main(int argc, char** argv) {
     variants.push_back({"g256p", launch_gemm256p<bf16_t, 0>});
     CK(hipFuncSetAttribute((const void*)gemm256r_tn_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * R_SLOT_BYTES));
     CK(hipFuncSetAttribute((const void*)gemm256r_tn_kernel<bf16_t, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * R_SLOT_BYTES));
-    CK(hipFuncSetAttribute((const void*)gemm256e_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES));
-    variants.push_back({"g256e", launch_gemm256e<bf16_t>});
+    CK(hipFuncSetAttribute((const void*)gemm256e_tn_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)gemm256e_tn_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES));
+    variants.push_back({"g256e", launch_gemm256e<bf16_t, 0>});
+    variants.push_back({"g256e_prio", launch_gemm256e<bf16_t, 1>});
     variants.push_back({"g384", launch_gemm384<bf16_t>});
     if (getenv("RING")) { variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>}); variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>}); }
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
