@@ -1,0 +1,93 @@
+"""End-to-end scripts/transfer.py surface on synthetic local checkpoints (no network): a tiny GPT-2
+language model, its byte-level BPE tokenizer as hn tokenizer, a second tokenizer as transfer target.
+Checks the spliced embedding matrix against the oracle (forward + retokenizer) and the reference's
+special-token rule (scripts/transfer.py:274-300)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hypernet_ref, retok_ref
+from tests import util
+from zett_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _train_bpe(lines, size):
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    from transformers import PreTrainedTokenizerFast
+    tok = Tokenizer(models.BPE())
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    tok.train_from_iterator(lines, trainers.BpeTrainer(vocab_size=size, special_tokens=["<|endoftext|>"],
+                                                       initial_alphabet=pre_tokenizers.ByteLevel.alphabet(), show_progress=False))
+    return PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|endoftext|>")
+
+
+def _lines(seed):
+    import glob
+    import random
+    rng = random.Random(seed)
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.__file__), "*.py")))
+    rng.shuffle(files)
+    out = []
+    for f in files[:25]:
+        out += [ln.strip() for ln in open(f, encoding="utf-8", errors="ignore") if len(ln.strip()) > 20]
+    rng.shuffle(out)
+    return out[:3000]
+
+
+def test_transfer_cli_end_to_end(tmp_path):
+    from transformers import AutoModelForCausalLM, AutoTokenizer, GPT2Config, GPT2LMHeadModel
+
+    import zett_amd  # noqa: F401
+    from zett_amd.byte_level import convert_to_byte_level
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    from zett_amd.transfer import main
+
+    src_dir, hn_dir, tgt_dir, out_dir = (str(tmp_path / d) for d in ("lm", "hypernet", "target_tok", "out"))
+    src_tok = _train_bpe(_lines(1), 600)
+    tgt_tok = _train_bpe(_lines(2), 900)
+    tgt_tok.save_pretrained(tgt_dir)
+    torch.manual_seed(0)
+    lm = GPT2LMHeadModel(GPT2Config(vocab_size=len(src_tok), n_embd=64, n_layer=1, n_head=2, n_positions=32))
+    lm.save_pretrained(src_dir)
+    src_tok.save_pretrained(src_dir)
+
+    cfg = dict(synth.workload("tiny")[0], n_embd=64, separate_out_embeddings=False, hn_embed_lang_id=False,
+               original_vocab_size=len(src_tok), hn_n_extra_tokens=0, pad_token_id=src_tok.eos_token_id, vocab_size=len(src_tok))
+    weights = synth.make_weights(cfg, 21)
+    hn = ZettHypernet(ZettHypernetConfig(**cfg))
+    hn.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    hn.save_pretrained(hn_dir)
+    src_tok.save_pretrained(hn_dir)                       # the checkpoint ships its hn tokenizer (transfer.py:153-157)
+
+    main(["--output", out_dir, "--checkpoint_path", hn_dir, "--tokenizer_name", tgt_dir, "--target_model", src_dir,
+          "--model_class", "AutoModelForCausalLM", "--dtype", "float32", "--batch_size", "256"])
+
+    new_tok = AutoTokenizer.from_pretrained(out_dir)
+    new_lm = AutoModelForCausalLM.from_pretrained(out_dir)
+    emb = new_lm.get_input_embeddings().weight.detach().numpy()
+    assert emb.shape == (len(new_tok), 64) and new_lm.config.vocab_size == len(new_tok)
+    assert np.array_equal(new_lm.get_output_embeddings().weight.detach().numpy(), emb)      # GPT-2 ties them
+
+    # expected: oracle retokenizer + oracle forward on the same converted tokenizers
+    hn_tok = convert_to_byte_level(AutoTokenizer.from_pretrained(hn_dir))[0]
+    hn_tok.pad_token = hn_tok.eos_token
+    tgt_conv = convert_to_byte_level(AutoTokenizer.from_pretrained(tgt_dir), make_whitespace_consistent=True,
+                                     match_special_tokens_to=AutoTokenizer.from_pretrained(src_dir))[0]
+    tokens = tgt_conv.convert_ids_to_tokens(range(len(tgt_conv)))
+    assert len(tokens) == len(new_tok)
+    model = retok_ref.model_from_hf_tokenizer(hn_tok)
+    sfm, _ = retok_ref.surface_form_matrix_c(model, tokens, cfg["hn_surface_maxlen"], hn_tok.pad_token_id)
+    source = lm.get_input_embeddings().weight.detach().numpy()
+    want = hypernet_ref.forward(weights, cfg, sfm, source, None)[0]
+    special_id = tgt_conv.get_vocab()["<|endoftext|>"]
+    want[special_id] = source[src_tok.eos_token_id]
+    util.assert_f32_close(emb, want, "spliced input embeddings")
+    assert np.array_equal(emb[special_id], source[src_tok.eos_token_id])
+    assert os.path.exists(os.path.join(out_dir, "bias.safetensors"))
