@@ -90,6 +90,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int dma_base = wave * 32 * GEMM_ROW_BYTES;
     const int nk_total = g.K / BK;
 
+    u32x4 wdummy[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wdummy[j] = u32x4{0, 0, 0, 0};
     auto issue_stage = [&](int kt) {
         if ((ABL == 1 || ABL == 5 || ABL == 6) && kt >= 2) return;
         if (ABL == 3) {   // ablation: twice the DMA traffic per step (second copy re-reads the previous K slice)
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[j] + koff), (lds_ptr_t)(sa + j * 8 * GEMM_ROW_BYTES), 16, 0, 0);
-            if (ABL != 4 && ABL != 7) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[j] + koff), (lds_ptr_t)(sw + j * 8 * GEMM_ROW_BYTES), 16, 0, 0);
+            if (ABL == 9) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(wdummy[j]) : "v"(w_src[j] + koff));
+            if (ABL != 4 && ABL != 7 && ABL != 9) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[j] + koff), (lds_ptr_t)(sw + j * 8 * GEMM_ROW_BYTES), 16, 0, 0);
         }
     };
 
@@ -215,6 +219,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
 
+    if (ABL == 9) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(wdummy[j]));
+    }
     // ---- epilogue: identical to gemm256 (accumulators through a private 16 KiB LDS region per wave)
     float* region = (float*)(smem + wave * 16384);
     const GemmEpilogue<T>& e = g.epi;

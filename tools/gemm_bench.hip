@@ -97,6 +97,8 @@ int main(int argc, char** argv) {
         variants.push_back({"mfma_nobar", launch_gemm256p<bf16_t, 6>});
         CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
         variants.push_back({"full_halfdma", launch_gemm256p<bf16_t, 7>});
+        CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+        variants.push_back({"Adma_Wvgpr", launch_gemm256p<bf16_t, 9>});
     }
     const char* epi_env = getenv("EPI");     // 0 = bf16 out only, 1 = bias+gelu_erf bf16 out, 2 = bias+residual f32 out
     const int epi_mode = epi_env ? atoi(epi_env) : 0;
