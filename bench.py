@@ -40,7 +40,7 @@ sys.path.insert(0, REPO)
 from zett_amd import synth  # noqa: E402
 from zett_amd.dims import HypernetDims, weight_shapes  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
 
 def device_weights(cfg, device, seed=0):
@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="mistral_gpt2_32k", choices=sorted(synth.WORKLOADS))
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--rows", type=int, default=0, help="override the vocab size of the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
@@ -204,12 +204,12 @@ def main():
         "metric": "predicted token-embeddings/sec (full target vocab)",
         "value": value, "unit": "token-embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+        "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"{args.workload}: {rows}-row target vocab, hypernet E={dims.n_embd} E_in={dims.n_in_embd} "
                                f"H={dims.hidden} I={dims.intermediate} heads={dims.heads} layers={dims.layers} "
                                f"L={ids_all.shape[1]}, source_embeddings {src_dtype}",
                    "rows": rows, "rows_per_gpu": hi - lo, "parallelism": f"vocab-row shards x{world} + RCCL all-gather",
-                   "precision": "bf16 MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision == "bf16" else "fp32 MFMA",
+                   "precision": f"{args.precision} MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision != "f32" else "fp32 MFMA",
                    "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"]},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak if peak else None, "traffic": None,

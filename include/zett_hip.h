@@ -44,8 +44,12 @@ enum zett_dtype { ZETT_F32 = 0, ZETT_F16 = 1, ZETT_BF16 = 2 };
  *   BF16: bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16); LayerNorm,
  *         softmax, GELU, residual stream and outputs in fp32.  (The reference CLI
  *         defaults to bf16 end to end: scripts/transfer.py:41,145-151.)
- *   F32 : exact fp32 (v_mfma_f32_32x32x2_f32), the hf_hypernet arithmetic. */
-enum zett_precision { ZETT_PREC_BF16 = 0, ZETT_PREC_F32 = 1 };
+ *   F32 : exact fp32 (v_mfma_f32_32x32x2_f32), the hf_hypernet arithmetic.
+ *   F16 : IEEE-half operands, fp32 accumulate (v_mfma_f32_32x32x16_f16): the speed of BF16 with
+ *         8x smaller operand rounding (11 instead of 8 significand bits); operands must stay
+ *         inside the half range (|x| < 65504), which LayerNorm'd activations and embedding-scale
+ *         weights do. */
+enum zett_precision { ZETT_PREC_BF16 = 0, ZETT_PREC_F32 = 1, ZETT_PREC_F16 = 2 };
 
 /* Shape / flag block.  Mirrors the fields of ZettHypernetConfig that the forward
  * reads (hf_hypernet/configuration_hypernet.py:3-56 plus the fields train.py

@@ -32,7 +32,7 @@ def _eq(a, b):
     return all((x is None and y is None) or torch.equal(x, y) for x, y in zip(a, b))
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f32"])
+@pytest.mark.parametrize("precision", ["bf16", "f16", "f32"])
 def test_row_order_shard_and_chunk_independence_tiny(precision):
     cfg, *_ = synth.workload("tiny")
     eng = _engine(cfg, 1, precision)

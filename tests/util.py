@@ -14,6 +14,8 @@ GOLDEN = os.path.join(HERE, "golden")
 F32_ABS = 1e-4            # f32 mode: max|y^ - y| <= 1e-4 * max(1, ||y_row||_inf)
 BF16_COS = 0.9995         # bf16-MFMA mode: row cosine
 BF16_REL_L2 = 1e-2        # bf16-MFMA mode: ||y^ - y||_2 / ||y||_2
+F16_COS = 0.99999         # f16-MFMA mode (11-bit significands): 8x tighter than bf16
+F16_REL_L2 = 2.5e-3
 
 
 def golden_cases(pattern="fwd_*.npz"):
@@ -47,7 +49,7 @@ def assert_f32_close(got, want, what):
     assert worst <= F32_ABS, f"{what}: max scaled abs err {worst:.3e} > {F32_ABS:.1e}"
 
 
-def assert_bf16_close(got, want, what):
+def assert_bf16_close(got, want, what, cos_min=BF16_COS, rel_max=BF16_REL_L2):
     assert np.isfinite(got).all(), f"{what}: non-finite values"
     g = got.astype(np.float64)
     w = want.astype(np.float64)
@@ -55,8 +57,12 @@ def assert_bf16_close(got, want, what):
         g, w = g[None, :], w[None, :]
     cos = (g * w).sum(-1) / (np.linalg.norm(g, axis=-1) * np.linalg.norm(w, axis=-1) + 1e-30)
     rel = np.linalg.norm(g - w) / (np.linalg.norm(w) + 1e-30)
-    assert cos.min() >= BF16_COS, f"{what}: min row cosine {cos.min():.6f} < {BF16_COS}"
-    assert rel <= BF16_REL_L2, f"{what}: rel-L2 {rel:.3e} > {BF16_REL_L2:.1e}"
+    assert cos.min() >= cos_min, f"{what}: min row cosine {cos.min():.6f} < {cos_min}"
+    assert rel <= rel_max, f"{what}: rel-L2 {rel:.3e} > {rel_max:.1e}"
+
+
+def assert_f16_close(got, want, what):
+    assert_bf16_close(got, want, what, cos_min=F16_COS, rel_max=F16_REL_L2)
 
 
 def hip_model(cfg, weights, precision):

@@ -28,6 +28,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 typedef uint16_t bf16_t;   // storage type of bf16 activations / weights
+typedef _Float16 f16_t;    // IEEE half: the third operand type (ZETT_PREC_F16)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round to nearest even, NaN kept quiet
@@ -35,6 +37,26 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round to nearest e
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
+}
+
+// fp32 -> operand type of a GEMM (round to nearest even)
+template <typename T> __device__ __forceinline__ T to_lo(float v);
+template <> __device__ __forceinline__ float to_lo<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t to_lo<bf16_t>(float v) { return f32_to_bf16(v); }
+template <> __device__ __forceinline__ f16_t to_lo<f16_t>(float v) { return (f16_t)v; }
+template <typename T> __device__ __forceinline__ uint32_t pack2_lo(float a, float b);      // two 16-bit operands in a dword
+template <> __device__ __forceinline__ uint32_t pack2_lo<bf16_t>(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+template <> __device__ __forceinline__ uint32_t pack2_lo<f16_t>(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 v = {(f16_t)a, (f16_t)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <typename T> __device__ __forceinline__ void unpack2_lo(uint32_t u, float& a, float& b);
+template <> __device__ __forceinline__ void unpack2_lo<bf16_t>(uint32_t u, float& a, float& b) { a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u); }
+template <> __device__ __forceinline__ void unpack2_lo<f16_t>(uint32_t u, float& a, float& b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 v = __builtin_bit_cast(h2, u);
+    a = (float)v[0]; b = (float)v[1];
 }
 
 enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2 };
@@ -110,6 +132,10 @@ template <>
 __device__ __forceinline__ void mfma_chunk<bf16_t>(const u32x4& a, const u32x4& b, f32x16& acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                   acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mfma_chunk<f16_t>(const u32x4& a, const u32x4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ void mfma_chunk<float>(const u32x4& a, const u32x4& b, f32x16& acc) {
@@ -251,8 +277,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
                 if (col < e.split_col) {
                     if (e.out_f32) e.out_f32[(size_t)row * e.ld_f32 + col] = v;
                     if (e.out_lo) {
-                        if constexpr (sizeof(T) == 2) e.out_lo[(size_t)row * e.ld_lo + col] = f32_to_bf16(v);
-                        else e.out_lo[(size_t)row * e.ld_lo + col] = v;
+                        e.out_lo[(size_t)row * e.ld_lo + col] = to_lo<T>(v);
                     }
                 } else if (e.out_f32_b) {
                     e.out_f32_b[(size_t)row * e.ld_f32 + (col - e.split_col)] = v;

@@ -37,10 +37,10 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 template <typename T> __device__ __forceinline__ void store_out4(T* dst, float4 v);
 template <> __device__ __forceinline__ void store_out4<float>(float* dst, float4 v) { *(float4*)dst = v; }
 template <> __device__ __forceinline__ void store_out4<bf16_t>(bf16_t* dst, float4 v) {
-    uint2 o;
-    o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-    o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-    *(uint2*)dst = o;
+    *(uint2*)dst = make_uint2(pack2_lo<bf16_t>(v.x, v.y), pack2_lo<bf16_t>(v.z, v.w));
+}
+template <> __device__ __forceinline__ void store_out4<f16_t>(f16_t* dst, float4 v) {
+    *(uint2*)dst = make_uint2(pack2_lo<f16_t>(v.x, v.y), pack2_lo<f16_t>(v.z, v.w));
 }
 
 // VAR (experiments, tools/gemm_bench): bit 0 = spread the DMA issue over the 4 K chunks of a step,

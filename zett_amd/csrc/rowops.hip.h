@@ -145,10 +145,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /* [4] */) {
 template <typename T> __device__ __forceinline__ void store_lo4(T* dst, float4 v);
 template <> __device__ __forceinline__ void store_lo4<float>(float* dst, float4 v) { *(float4*)dst = v; }
 template <> __device__ __forceinline__ void store_lo4<bf16_t>(bf16_t* dst, float4 v) {
-    uint2 o;
-    o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-    o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-    *(uint2*)dst = o;
+    *(uint2*)dst = make_uint2(pack2_lo<bf16_t>(v.x, v.y), pack2_lo<bf16_t>(v.z, v.w));
+}
+template <> __device__ __forceinline__ void store_lo4<f16_t>(f16_t* dst, float4 v) {
+    *(uint2*)dst = make_uint2(pack2_lo<f16_t>(v.x, v.y), pack2_lo<f16_t>(v.z, v.w));
 }
 
 template <int SRC_DTYPE> __device__ __forceinline__ float4 load_src4(const void* base, size_t elem);
@@ -310,26 +310,23 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
     const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
-template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&o)[8]) {
+template <typename T> __device__ __forceinline__ void load8_16bit(const T* p, float (&o)[8]) {
     const uint4 u = *(const uint4*)p;
-    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
-    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
-    o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
-    o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+    unpack2_lo<T>(u.x, o[0], o[1]); unpack2_lo<T>(u.y, o[2], o[3]);
+    unpack2_lo<T>(u.z, o[4], o[5]); unpack2_lo<T>(u.w, o[6], o[7]);
 }
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&o)[8]) { load8_16bit<bf16_t>(p, o); }
+template <> __device__ __forceinline__ void load8<f16_t>(const f16_t* p, float (&o)[8]) { load8_16bit<f16_t>(p, o); }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&o)[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&o)[8]) {
     *(float4*)p = make_float4(o[0], o[1], o[2], o[3]);
     *(float4*)(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
 }
-template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&o)[8]) {
-    uint4 u;
-    u.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-    u.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
-    u.z = (uint32_t)f32_to_bf16(o[4]) | ((uint32_t)f32_to_bf16(o[5]) << 16);
-    u.w = (uint32_t)f32_to_bf16(o[6]) | ((uint32_t)f32_to_bf16(o[7]) << 16);
-    *(uint4*)p = u;
+template <typename T> __device__ __forceinline__ void store8_16bit(T* p, const float (&o)[8]) {
+    *(uint4*)p = make_uint4(pack2_lo<T>(o[0], o[1]), pack2_lo<T>(o[2], o[3]), pack2_lo<T>(o[4], o[5]), pack2_lo<T>(o[6], o[7]));
 }
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&o)[8]) { store8_16bit<bf16_t>(p, o); }
+template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&o)[8]) { store8_16bit<f16_t>(p, o); }
 
 // qkv: [T, 3H] (q | k | v), ctx: [T or rows, H].  cls_only: compute query 0 only and
 // write it at ctx[row_local] (compact [rows, H] output for the last layer).
@@ -437,12 +434,13 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
 }
 
 // dtype conversion used when weights are uploaded
-__global__ void convert_f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+template <typename T>
+__global__ void convert_f32_to_lo_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
-    for (; i + 3 < n; i += stride) store_lo4<bf16_t>(out + i, *(const float4*)(in + i));
+    for (; i + 3 < n; i += stride) store_lo4<T>(out + i, *(const float4*)(in + i));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (size_t j = n & ~(size_t)3; j < n; ++j) out[j] = f32_to_bf16(in[j]);
+        for (size_t j = n & ~(size_t)3; j < n; ++j) out[j] = to_lo<T>(in[j]);
     }
 }
 template <int SRC_DTYPE>

@@ -79,7 +79,7 @@ struct zett_hypernet {
 
 namespace {
 
-size_t elt_size(int precision) { return precision == ZETT_PREC_BF16 ? 2 : 4; }
+size_t elt_size(int precision) { return precision == ZETT_PREC_F32 ? 4 : 2; }
 
 bool is_gemm_weight(const std::string& n) {
     static const char* suffixes[] = {"input_projection.0.weight", "dense1.weight", "dense2.weight",
@@ -143,7 +143,7 @@ int validate_config(const zett_config& c, int precision) {
     if (c.hidden % c.heads) return fail(ZETT_E_INVALID, "hidden %d not divisible by heads %d", c.hidden, c.heads);
     const int d = c.hidden / c.heads;
     if (d < 8 || d > 512 || (d & (d - 1))) return fail(ZETT_E_INVALID, "head_dim %d unsupported (need a power of two in [8,512])", d);
-    const int kq = precision == ZETT_PREC_BF16 ? 64 : 32;
+    const int kq = precision == ZETT_PREC_F32 ? 32 : 64;
     for (int k : {c.n_in_embd, c.hidden, c.intermediate})
         if (k % kq) return fail(ZETT_E_INVALID, "contraction width %d is not a multiple of %d", k, kq);
     if (c.n_embd % 4) return fail(ZETT_E_INVALID, "n_embd must be a multiple of 4");
@@ -167,7 +167,7 @@ int zett_abi_version(void) { return ZETT_ABI_VERSION; }
 
 int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet** out) {
     if (!cfg || !out) return fail(ZETT_E_INVALID, "null argument");
-    if (precision != ZETT_PREC_BF16 && precision != ZETT_PREC_F32) return fail(ZETT_E_INVALID, "unknown precision %d", precision);
+    if (precision != ZETT_PREC_BF16 && precision != ZETT_PREC_F32 && precision != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "unknown precision %d", precision);
     if (int rc = validate_config(*cfg, precision)) return rc;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -175,6 +175,7 @@ int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     auto* h = new zett_hypernet();
     h->cfg = *cfg;
     h->device = device;
@@ -259,7 +260,10 @@ int zett_finalize(zett_hypernet* h) {
         if (h->precision == ZETT_PREC_F32) { t.lo = t.f32; continue; }
         HIP_TRY(hipMalloc(&t.lo, t.numel * 2));
         const int blocks = (int)std::min<size_t>((t.numel / 4 + 255) / 256 + 1, 65535);
-        hipLaunchKernelGGL(convert_f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, 0, t.f32, (bf16_t*)t.lo, t.numel);
+        if (h->precision == ZETT_PREC_F16)
+            hipLaunchKernelGGL(convert_f32_to_lo_kernel<f16_t>, dim3(blocks), dim3(256), 0, 0, t.f32, (f16_t*)t.lo, t.numel);
+        else
+            hipLaunchKernelGGL(convert_f32_to_lo_kernel<bf16_t>, dim3(blocks), dim3(256), 0, 0, t.f32, (bf16_t*)t.lo, t.numel);
     }
     HIP_TRY(hipDeviceSynchronize());
     // fused QKV operand per layer: rows [q | k | v]
@@ -295,7 +299,7 @@ int zett_finalize(zett_hypernet* h) {
         }
     }
     // the fp32 originals of bf16 GEMM operands are no longer needed
-    if (h->precision == ZETT_PREC_BF16) {
+    if (h->precision != ZETT_PREC_F32) {
         for (auto& kv : h->w) {
             Tensor& t = kv.second;
             if (is_gemm_weight(kv.first) && t.f32) { (void)hipFree(t.f32); t.f32 = nullptr; }
@@ -348,6 +352,8 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
     if (n_rows * (int64_t)(seq + 1) >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many positions for one call");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
+    if (h->precision == ZETT_PREC_F16)
+        return do_forward<f16_t>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);
     if (h->precision == ZETT_PREC_BF16)
         return do_forward<bf16_t>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);
     return do_forward<float>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);

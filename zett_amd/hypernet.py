@@ -31,7 +31,8 @@ from .dims import PROJECTOR_LN_EPS, ROBERTA_LN_EPS, ROBERTA_MAX_POSITIONS, Hyper
 
 _TORCH_TO_ZETT = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
 _PRECISIONS = {"bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16, "f32": _lib.PREC_F32,
-               "fp32": _lib.PREC_F32, "float32": _lib.PREC_F32}
+               "fp32": _lib.PREC_F32, "float32": _lib.PREC_F32, "f16": _lib.PREC_F16, "fp16": _lib.PREC_F16,
+               "float16": _lib.PREC_F16}
 
 
 def _backbone_settings(name_or_path: str) -> Tuple[int, float]:
@@ -165,7 +166,7 @@ class ZettHypernet(PreTrainedModel):
         max_pos, ln_eps = _backbone_settings(getattr(config, "hn_model_name_or_path", "roberta-base"))
         self._ln_eps_encoder = ln_eps
         self.dims = HypernetDims.from_config(config, max_positions=max_pos)
-        # arithmetic of the dense contractions: "bf16" (MFMA bf16, fp32 accumulate) or "f32"
+        # arithmetic of the dense contractions: "bf16" / "f16" (MFMA, fp32 accumulate) or "f32"
         self.precision = os.environ.get("ZETT_PRECISION", getattr(config, "zett_precision", None) or "bf16")
         for name, shape in weight_shapes(self.dims).items():
             _attach(self, name, nn.Parameter(torch.empty(shape, dtype=torch.float32), requires_grad=False))

@@ -173,7 +173,7 @@ def main(argv=None):
         lang_index = torch.tensor(langs.index(args.lang_code), dtype=torch.int32)
 
     hypernet = AutoModel.from_pretrained(args.checkpoint_path).to(device)
-    hypernet.precision = {"bfloat16": "bf16", "float32": "f32", "float16": "bf16"}.get(args.dtype, "bf16")
+    hypernet.precision = {"bfloat16": "bf16", "float32": "f32", "float16": "f16"}.get(args.dtype, "bf16")
 
     source_tokenizer = AutoTokenizer.from_pretrained(args.target_model)
     hn_tokenizer = type(source_tokenizer).from_pretrained(args.checkpoint_path)
