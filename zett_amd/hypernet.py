@@ -174,6 +174,20 @@ class ZettHypernet(PreTrainedModel):
         self._reset_parameters()
         self.post_init()
 
+    @classmethod
+    def from_flax_checkpoint(cls, checkpoint_path: str) -> "ZettHypernet":
+        """Load ``config.json`` + ``flax_model.msgpack`` (the reference's canonical checkpoint format,
+        scripts/transfer.py:131,145-151) without jax / flax."""
+        from .flax_io import load_flax_checkpoint
+        config = ZettHypernetConfig.from_pretrained(checkpoint_path)
+        model = cls(config)
+        state = {k: torch.from_numpy(v) for k, v in load_flax_checkpoint(os.path.join(checkpoint_path, "flax_model.msgpack")).items()}
+        missing, unexpected = model.load_state_dict(state, strict=False)
+        missing = [m for m in missing if m != "model.embeddings.word_embeddings.weight"]
+        if missing or unexpected:
+            raise ValueError(f"flax checkpoint does not match the config: missing {missing}, unexpected {list(unexpected)}")
+        return model
+
     # ---- parameter initialisation (same distributions as the torch modules of the reference)
     def _reset_parameters(self) -> None:
         with torch.no_grad():
