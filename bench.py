@@ -197,6 +197,17 @@ def main():
     achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.precision]
 
+    # HBM traffic of the dominant kernel comes from PMC counters, which cannot be read from inside this
+    # process: the figure is the one measured by the committed rocprofv3 passes (profiles/r1c_pmc.md,
+    # tools/pmc_summary.py --json) for this same command, and only quoted for the workload it was taken on.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        if args.workload == "mistral_gpt2_32k" and args.precision == "bf16" and world == 1 and not args.rows:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+
     from oracle.hypernet_ref import flops_per_row
     f_ref = flops_per_row(cfg, ids_all.shape[1])
 
@@ -212,7 +223,7 @@ def main():
                    "precision": f"{args.precision} MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision != "f32" else "fp32 MFMA",
                    "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"]},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak if peak else None, "traffic": None,
+                     "frac": achieved / peak if peak else None, "traffic": traffic,
                      "kernel": "zett::gemm256_tn_kernel (256x256 LDS-DMA MFMA GEMM; 128x128 variant for small M/N)", "launches_per_step": launches / max(args.steps, 1),
                      "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
                      "executed_tflop_per_step": gemm_fl / max(args.steps, 1) / 1e12},

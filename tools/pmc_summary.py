@@ -47,10 +47,21 @@ def main(dirs):
             clk = cyc / avg("_dur_GRBM_GUI_ACTIVE")
         bw = None if rd is None or wr is None or not dur else (rd + wr) / (dur * 1e-9)
         rows.append((-(dur or 0) * n, k, n, dur, rd, wr, bw, util, clk))
+    if "--json" in sys.argv:     # launch-weighted HBM bytes per GEMM launch, for bench.py's roofline.traffic
+        import json
+        tot_b = tot_n = 0.0
+        for _, k, n, dur, rd, wr, bw, util, clk in rows:
+            if "gemm" in k and rd is not None and wr is not None:
+                tot_b += (rd + wr) * 1e9 * n
+                tot_n += n
+        out = {"kernel": "zett::gemm*_tn_kernel (all instances, launch-weighted)", "hbm_bytes_per_launch": tot_b / max(tot_n, 1),
+               "launches": int(tot_n), "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)",
+               "workload": "bench.py default (mistral_gpt2_32k, bf16)"}
+        json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
     f = lambda x, fmt: "" if x is None else fmt % x
     for _, k, n, dur, rd, wr, bw, util, clk in sorted(rows):
         print(f"| {k} | {n} | {f(dur and dur / 1e3, '%.1f')} | {f(rd, '%.3f')} | {f(wr, '%.3f')} | {f(bw, '%.0f')} | {f(util, '%.3f')} | {f(clk, '%.2f')} |")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    main([a for i, a in enumerate(sys.argv[1:]) if a != "--json" and (i == 0 or sys.argv[i] != "--json")])
