@@ -45,6 +45,13 @@ __device__ __forceinline__ void e_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+// barrier first, LDS-read wait after it: the fragment reads issued before the barrier complete while
+// the wave waits for the other group (safe where the slots being read are not refilled for >= 2 barriers)
+__device__ __forceinline__ void e_barrier_then_wait() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ void e_barrier_vm4() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -147,21 +154,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             fa[1][kk] = *(const u32x4*)(S + a_off[1] + swz[kk]);
             fb0[kk] = *(const u32x4*)(S + w_off[0] + swz[kk]);
         }
-        e_barrier();
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 2) e_barrier_then_wait(); else e_barrier();
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { mfma_chunk<T>(fa[0][kk], fb0[kk], acc[0][0]); mfma_chunk<T>(fa[1][kk], fb0[kk], acc[1][0]); }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         e_barrier();
         // ---- phase 1: (i0,i1) x j1
         if (t + 1 < nk) issue_half(t + 1, 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fb1[kk] = *(const u32x4*)(S + w_off[1] + swz[kk]);
         e_barrier();
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { mfma_chunk<T>(fa[0][kk], fb1[kk], acc[0][1]); mfma_chunk<T>(fa[1][kk], fb1[kk], acc[1][1]); }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         e_barrier();
         // ---- phase 2: (i2,i3) x j1
         if (t + 2 < nk) issue_half(t + 2, 2);
@@ -170,18 +177,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             fa[0][kk] = *(const u32x4*)(S + a_off[2] + swz[kk]);
             fa[1][kk] = *(const u32x4*)(S + a_off[3] + swz[kk]);
         }
-        e_barrier();
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 2) e_barrier_then_wait(); else e_barrier();
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { mfma_chunk<T>(fa[0][kk], fb1[kk], acc[2][1]); mfma_chunk<T>(fa[1][kk], fb1[kk], acc[3][1]); }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         e_barrier();
         // ---- phase 3: (i2,i3) x j0; the halves of step t+1 must be visible after its LOAD-part barrier
         if (t + 2 < nk) { issue_half(t + 2, 3); e_barrier_vm4(); } else { e_barrier_vm0(); }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { mfma_chunk<T>(fa[0][kk], fb0[kk], acc[2][0]); mfma_chunk<T>(fa[1][kk], fb0[kk], acc[3][0]); }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         e_barrier();
     }
     if (wm == 0) e_barrier();                      // group 0 waits for group 1's last MATH part

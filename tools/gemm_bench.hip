@@ -76,7 +76,8 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)gemm256e_tn_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)gemm256e_tn_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES));
     variants.push_back({"g256e", launch_gemm256e<bf16_t, 0>});
-    variants.push_back({"g256e_prio", launch_gemm256e<bf16_t, 1>});
+    CK(hipFuncSetAttribute((const void*)gemm256e_tn_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES));
+    variants.push_back({"g256e_latewait", launch_gemm256e<bf16_t, 2>});
     variants.push_back({"g384", launch_gemm384<bf16_t>});
     if (getenv("RING")) { variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>}); variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>}); }
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
