@@ -238,3 +238,45 @@ def test_predict_sharded_gloo(tmp_path, world):
     res = json.load(open(out))
     assert res["ok"], "all-gathered shards differ from the single-process result"
     assert res["shapes"] == [[37, 64], [37, 64], [37]]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hf_hypernet"), reason="reference only exists in the build container")
+def test_install_remote_code_routes_reference_checkpoint(tmp_path):
+    """AutoModel(..., trust_remote_code=True) on a reference-written checkpoint returns the zett_amd class."""
+    code = f"""
+import sys, json, torch, os
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, {REPO!r})
+from hf_hypernet.configuration_hypernet import ZettHypernetConfig
+from hf_hypernet.modeling_hypernet import ZettHypernet
+from zett_amd import synth
+rb = os.path.join({str(tmp_path)!r}, "rb"); os.makedirs(rb)
+json.dump({{"model_type": "roberta", "max_position_embeddings": 514, "type_vocab_size": 1, "layer_norm_eps": 1e-5,
+           "hidden_act": "gelu", "vocab_size": 50265, "pad_token_id": 1}}, open(os.path.join(rb, "config.json"), "w"))
+cfg, *_ = synth.workload("tiny")
+ZettHypernetConfig.register_for_auto_class()
+ZettHypernet.register_for_auto_class("AutoModel")
+m = ZettHypernet(ZettHypernetConfig(**dict(cfg, hn_model_name_or_path=rb)))
+m.load_state_dict({{k: torch.from_numpy(v) for k, v in synth.make_weights(cfg, 8).items()}})
+m.save_pretrained(os.path.join({str(tmp_path)!r}, "ckpt"))
+"""
+    subprocess.run([sys.executable, "-c", code], check=True, cwd="/tmp")
+    ckpt = os.path.join(tmp_path, "ckpt")
+    import zett_amd
+    zett_amd.install_remote_code(ckpt)
+    check = f"""
+import sys; sys.path.insert(0, {REPO!r})
+import torch
+from transformers import AutoModel
+from zett_amd import synth
+m = AutoModel.from_pretrained({ckpt!r}, trust_remote_code=True)
+assert type(m).__name__ == "ZettHypernet" and "zett_amd" in sys.modules, type(m)
+from zett_amd.hypernet import ZettHypernet
+assert isinstance(m, ZettHypernet) or type(m).__module__.endswith("modeling_hypernet")
+cfg, *_ = synth.workload("tiny")
+for k, v in synth.make_weights(cfg, 8).items():
+    assert torch.equal(m.state_dict()[k], torch.from_numpy(v)), k
+assert hasattr(m, "engine")
+print("ok")
+"""
+    out = subprocess.run([sys.executable, "-c", check], check=True, cwd="/tmp", capture_output=True, text=True)
+    assert "ok" in out.stdout

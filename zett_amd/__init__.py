@@ -34,3 +34,30 @@ def __getattr__(name):
 
 
 _register()
+
+
+def install_remote_code(checkpoint_dir: str) -> None:
+    """Make ``AutoModel.from_pretrained(checkpoint_dir, trust_remote_code=True)`` return the HIP-backed
+    hypernetwork for a checkpoint written by the reference.
+
+    Reference checkpoints carry ``auto_map`` entries that point at ``configuration_hypernet.py`` /
+    ``modeling_hypernet.py`` inside the checkpoint directory (scripts/convert_to_pt.py:26-27,49), i.e. at
+    the reference's own torch implementation.  This writes two shim modules of those names that re-export
+    the zett_amd classes, leaving weights and config untouched.
+    """
+    import json
+    import os
+
+    shims = {
+        "configuration_hypernet.py": "from zett_amd.config import ZettHypernetConfig  # noqa: F401\n",
+        "modeling_hypernet.py": "from zett_amd.hypernet import ZettHypernet  # noqa: F401\n",
+    }
+    for name, body in shims.items():
+        with open(os.path.join(checkpoint_dir, name), "w") as f:
+            f.write('"""Shim written by zett_amd.install_remote_code: routes the checkpoint\'s auto_map to zett_amd."""\n' + body)
+    cfg_path = os.path.join(checkpoint_dir, "config.json")
+    with open(cfg_path) as f:
+        cfg = json.load(f)
+    cfg["auto_map"] = {"AutoConfig": "configuration_hypernet.ZettHypernetConfig", "AutoModel": "modeling_hypernet.ZettHypernet"}
+    with open(cfg_path, "w") as f:
+        json.dump(cfg, f, indent=2)
