@@ -61,6 +61,27 @@ def test_row_order_shard_and_chunk_independence_tiny(precision):
             torch.testing.assert_close(a, b, rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("precision,name,rows", [("bf16", "tiny", 3000), ("f16", "tiny", 3000), ("f32", "tiny", 1500),
+                                                  ("bf16", "tinyllama_neox", 6000)])
+def test_gemm_tile_variants_bit_identical(precision, name, rows):
+    """The four GEMM kernels (128x128 register-staged, 256x256 LDS-DMA, 384x256 LDS-DMA, 256x256
+    four-wave register-staged) share one K reduction order: forcing any of them through
+    zett_set_option("gemm_variant") must not change a single bit of the outputs."""
+    cfg, _, src_dtype, hist = synth.workload(name)
+    eng = _engine(cfg, 2, precision)
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 2, dtype=src_dtype)).cuda()
+    ids = synth.make_surface_forms(cfg, rows, seed=2, hist=hist, n_special=2)
+    lang = 1 if cfg.get("hn_embed_lang_id") else -1
+    auto = _run(eng, ids, src, lang)
+    assert all(t is None or bool(torch.isfinite(t).all()) for t in auto)
+    for variant in (1, 2, 3, 4):
+        eng.set_option("gemm_variant", variant)
+        assert _eq(_run(eng, ids, src, lang), auto), f"gemm_variant {variant}"
+    eng.set_option("gemm_variant", 0)
+    with pytest.raises(ValueError):
+        eng.set_option("gemm_variant", 5)
+
+
 def test_pad_content_independence():
     """Changing the pad token's source embedding must change nothing for rows with a visible key."""
     cfg, *_ = synth.workload("tiny")

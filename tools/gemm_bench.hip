@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "gemm.hip.h"
@@ -19,6 +20,10 @@
 #include "gemm256p.hip.h"
 #include "gemm256r.hip.h"
 #include "gemm256e.hip.h"
+#include "gemm256s.hip.h"
+#include "gemm4w.hip.h"
+#include "gemm256l.hip.h"
+#include "gemm4r.hip.h"
 #include "gemm384.hip.h"
 
 using namespace zett;
@@ -79,6 +84,10 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)gemm256e_tn_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES));
     variants.push_back({"g256e_latewait", launch_gemm256e<bf16_t, 2>});
     variants.push_back({"g384", launch_gemm384<bf16_t>});
+    variants.push_back({"g256s", launch_gemm256s<bf16_t>});
+    variants.push_back({"g4w", launch_gemm4w<bf16_t>});
+    variants.push_back({"g256l", launch_gemm256l<bf16_t>});
+    variants.push_back({"g4r", launch_gemm4r<bf16_t>});
     if (getenv("RING")) { variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>}); variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>}); }
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
@@ -101,7 +110,14 @@ int main(int argc, char** argv) {
         CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
         variants.push_back({"Adma_Wvgpr", launch_gemm256p<bf16_t, 9>});
     }
-    const char* epi_env = getenv("EPI");     // 0 = bf16 out only, 1 = bias+gelu_erf bf16 out, 2 = bias+residual f32 out
+    if (const char* only = getenv("ONLY")) {      // comma-separated names; the reference variant 0 always stays
+        std::vector<Variant> kept = {variants[0]};
+        std::string o = std::string(",") + only + ",";
+        for (size_t v = 1; v < variants.size(); ++v)
+            if (o.find(std::string(",") + variants[v].name + ",") != std::string::npos) kept.push_back(variants[v]);
+        variants = kept;
+    }
+    const char* epi_env = getenv("EPI");     // 0 = bf16 out only, 1 = bias+gelu_erf bf16 out, 2 = bias+residual f32 out, 3 = bias+gelu_tanh, 4 = bias+scale/shift f32+bf16 out
     const int epi_mode = epi_env ? atoi(epi_env) : 0;
     const int rounds = getenv("ROUNDS") ? atoi(getenv("ROUNDS")) : 5;
     for (auto& s : shapes) {
@@ -122,6 +138,8 @@ int main(int argc, char** argv) {
             g.epi.split_col = 0x7fffffff;
             if (epi_mode == 0) { g.epi.out_lo = out; g.epi.ld_lo = N; }
             else if (epi_mode == 1) { g.epi.bias = bias; g.epi.act = ACT_GELU_ERF; g.epi.out_lo = out; g.epi.ld_lo = N; }
+            else if (epi_mode == 3) { g.epi.bias = bias; g.epi.act = ACT_GELU_TANH; g.epi.out_lo = out; g.epi.ld_lo = N; }
+            else if (epi_mode == 4) { g.epi.bias = bias; g.epi.scale = res; g.epi.shift = bias; g.epi.out_f32 = cf; g.epi.ld_f32 = N; g.epi.out_lo = out; g.epi.ld_lo = N; }
             else { g.epi.bias = bias; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N; g.epi.out_lo = out; g.epi.ld_lo = N; }
             return g;
         };

@@ -32,11 +32,8 @@ typedef _Float16 f16_t;    // IEEE half: the third operand type (ZETT_PREC_F16)
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round to nearest even, NaN kept quiet
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round to nearest even: v_cvt_pk_bf16_f32 on gfx950
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 
 // fp32 -> operand type of a GEMM (round to nearest even)
@@ -45,7 +42,12 @@ template <> __device__ __forceinline__ float to_lo<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t to_lo<bf16_t>(float v) { return f32_to_bf16(v); }
 template <> __device__ __forceinline__ f16_t to_lo<f16_t>(float v) { return (f16_t)v; }
 template <typename T> __device__ __forceinline__ uint32_t pack2_lo(float a, float b);      // two 16-bit operands in a dword
-template <> __device__ __forceinline__ uint32_t pack2_lo<bf16_t>(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+template <> __device__ __forceinline__ uint32_t pack2_lo<bf16_t>(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));      // one v_cvt_pk_bf16_f32
+}
 template <> __device__ __forceinline__ uint32_t pack2_lo<f16_t>(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) _Float16 h2;
     const h2 v = {(f16_t)a, (f16_t)b};
@@ -64,26 +66,55 @@ enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2 };
 // GELUs of the epilogues.  Written with v_exp_f32 / v_rcp_f32 based forms (absolute error
 // ~1e-7, i.e. fp32 round-off class) instead of the libm tanhf / erff call sequences, which
 // cost 4-5x as many VALU instructions in an epilogue that has to process 128 values per lane.
+//
+// Every epilogue formula is written with explicit fused multiply-adds under
+// `#pragma clang fp contract(off)`: HIP's default -ffp-contract=fast lets the backend fuse a
+// multiply and an add wherever it sees fit, and it chooses differently for the scalar
+// epilogue of the 128x128 kernel and the float4 (packed-math) epilogues of the large tiles.
+// The kernels must agree bit for bit (the tile is chosen per launch from M, so a vocabulary
+// shard and the whole vocabulary can take different kernels for the same row).
 __device__ __forceinline__ float gelu_tanh_f(float x) {   // F.gelu(approximate="tanh")
-    const float c = 0.7978845608028654f;
-    const float u = c * (x + 0.044715f * x * x * x);
+#pragma clang fp contract(off)
+    const float x3 = (x * x) * x;
+    const float u2 = 1.5957691216057308f * __builtin_fmaf(0.044715f, x3, x);        // 2 * sqrt(2/pi) * (x + 0.044715 x^3)
     // tanh(u) = 1 - 2 / (1 + exp(2u)); exp overflow -> tanh = 1, underflow -> -1
-    const float t = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * u));
-    return 0.5f * x * (1.0f + t);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u2 * 1.4426950408889634f));
+    return (0.5f * x) * (1.0f + t);
 }
 __device__ __forceinline__ float erf_as_f(float x) {      // Abramowitz & Stegun 7.1.26, |err| <= 1.5e-7
+#pragma clang fp contract(off)
     const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
     float p = 1.061405429f;
-    p = fmaf(p, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float y = 1.0f - p * t * __expf(-ax * ax);
+    p = __builtin_fmaf(p, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float ex = __builtin_amdgcn_exp2f((ax * ax) * -1.4426950408889634f);      // exp(-x^2)
+    const float y = __builtin_fmaf(-(p * t), ex, 1.0f);
     return copysignf(y, x);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) {    // F.gelu (erf form)
-    return x * 0.5f * (1.0f + erf_as_f(x * 0.70710678118654752440f));
+#pragma clang fp contract(off)
+    return (x * 0.5f) * (1.0f + erf_as_f(x * 0.70710678118654752440f));
+}
+
+// One output element of every GEMM epilogue (see GemmEpilogue below): the single definition all
+// tile variants call, component by component.
+template <int ACT>
+__device__ __forceinline__ float epi_value(float acc, float bias, bool has_res, float res, bool has_scale, float sc, float sh) {
+#pragma clang fp contract(off)
+    float v = acc + bias;
+    if (ACT == 1) v = gelu_tanh_f(v);
+    else if (ACT == 2) v = gelu_erf_f(v);
+    if (has_res) v = v + res;
+    if (has_scale) v = __builtin_fmaf(sc, v, sh);
+    return v;
+}
+template <int ACT>
+__device__ __forceinline__ float4 epi_value4(float4 a, float4 bias, bool has_res, float4 res, bool has_scale, float4 sc, float4 sh) {
+    return make_float4(epi_value<ACT>(a.x, bias.x, has_res, res.x, has_scale, sc.x, sh.x), epi_value<ACT>(a.y, bias.y, has_res, res.y, has_scale, sc.y, sh.y),
+                       epi_value<ACT>(a.z, bias.z, has_res, res.z, has_scale, sc.z, sh.z), epi_value<ACT>(a.w, bias.w, has_res, res.w, has_scale, sc.w, sh.w));
 }
 
 // Row-wise epilogue description (all pointers device, nullable unless noted).
@@ -118,6 +149,7 @@ struct GemmArgs {
 
 constexpr int GEMM_BM = 128;
 constexpr int GEMM_BN = 128;
+constexpr int GEMM_WAIT_VMCNT0 = 0x0F70;            // s_waitcnt vmcnt(0) expcnt(7) lgkmcnt(15) (gfx9 encoding)
 constexpr int GEMM_ROW_BYTES = 128;                 // K bytes per tile row
 constexpr int GEMM_TILE_BYTES = GEMM_BM * GEMM_ROW_BYTES;   // 16 KiB per operand tile
 
@@ -269,11 +301,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (row >= g.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (e.act == ACT_GELU_TANH) v = gelu_tanh_f(v);
-                else if (e.act == ACT_GELU_ERF) v = gelu_erf_f(v);
-                if (e.residual) v += e.residual[(size_t)row * e.ld_res + col];
-                if (e.scale) v = sc * v + sh;
+                const float res = e.residual ? e.residual[(size_t)row * e.ld_res + col] : 0.f;
+                const bool hr = e.residual != nullptr, hs = e.scale != nullptr;
+                const float v = e.act == ACT_GELU_TANH ? epi_value<ACT_GELU_TANH>(acc[i][j][r], bias, hr, res, hs, sc, sh)
+                              : e.act == ACT_GELU_ERF ? epi_value<ACT_GELU_ERF>(acc[i][j][r], bias, hr, res, hs, sc, sh)
+                                                      : epi_value<ACT_NONE>(acc[i][j][r], bias, hr, res, hs, sc, sh);
                 if (col < e.split_col) {
                     if (e.out_f32) e.out_f32[(size_t)row * e.ld_f32 + col] = v;
                     if (e.out_lo) {

@@ -29,7 +29,7 @@ constexpr int G384_W_BYTES = G384_BN * GEMM_ROW_BYTES;            // 32 KiB
 constexpr int G384_STAGE_BYTES = G384_A_BYTES + G384_W_BYTES;     // 80 KiB
 constexpr int G384_LDS_BYTES = 2 * G384_STAGE_BYTES;              // 160 KiB
 
-template <typename T, int ACT = ACT_NONE>
+template <typename T, int ACT = ACT_NONE, bool RES = false>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm384_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
@@ -139,15 +139,14 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        // the residual rows of this pass are requested first, all at once, so that their
-        // latencies overlap each other and the LDS staging below
-        float4 rr[8];
-        if (e.residual && col_ok) {
+        // residual rows first (all at once), LDS staging, one explicit vmcnt(0), then a drain
+        // without any load in it: see the epilogue of gemm256.hip.h for why
+        float4 o[8];
+        if (RES) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const int lrow = t * 4 + (lane >> 4);
-                const int grow = m0 + wm * 128 + i * 32 + lrow;
-                rr[t] = grow < g.M ? *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int grow = m0 + wm * 128 + i * 32 + t * 4 + (lane >> 4);
+                o[t] = (grow < g.M && col_ok) ? *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
@@ -155,40 +154,45 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 region[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + l31] = acc[i][j][r];
+        if (RES || i == 0) __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int lrow = t * 4 + (lane >> 4);
-            const int grow = m0 + wm * 128 + i * 32 + lrow;
             float4 v = *(const float4*)(region + lrow * 64 + c4);
+            o[t] = epi_value4<ACT>(v, bias4, RES, RES ? o[t] : make_float4(0.f, 0.f, 0.f, 0.f), e.scale != nullptr, sc4, sh4);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int grow = m0 + wm * 128 + i * 32 + t * 4 + (lane >> 4);
             if (grow >= g.M || !col_ok) continue;
-            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-            if (ACT == ACT_GELU_TANH) { v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w); }
-            else if (ACT == ACT_GELU_ERF) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
-            if (e.residual) { v.x += rr[t].x; v.y += rr[t].y; v.z += rr[t].z; v.w += rr[t].w; }
-            if (e.scale) { v.x = sc4.x * v.x + sh4.x; v.y = sc4.y * v.y + sh4.y; v.z = sc4.z * v.z + sh4.z; v.w = sc4.w * v.w + sh4.w; }
             if (gcol < e.split_col) {
-                if (e.out_f32) *(float4*)(e.out_f32 + (size_t)grow * e.ld_f32 + gcol) = v;
-                if (e.out_lo) store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, v);
+                if (e.out_f32) *(float4*)(e.out_f32 + (size_t)grow * e.ld_f32 + gcol) = o[t];
+                if (e.out_lo) store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, o[t]);
             } else if (e.out_f32_b) {
-                *(float4*)(e.out_f32_b + (size_t)grow * e.ld_f32 + (gcol - e.split_col)) = v;
+                *(float4*)(e.out_f32_b + (size_t)grow * e.ld_f32 + (gcol - e.split_col)) = o[t];
             }
         }
     }
 }
 
-template <typename T, int ACT>
-inline hipError_t launch_gemm384_act(const GemmArgs<T>& g, hipStream_t stream) {
+template <typename T, int ACT, bool RES>
+inline hipError_t launch_gemm384_inst(const GemmArgs<T>& g, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm384_tn_kernel<T, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, G384_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm384_tn_kernel<T, ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G384_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int tiles_m = (g.M + G384_BM - 1) / G384_BM;
     const int tiles_n = (g.N + G384_BN - 1) / G384_BN;
     if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
-    hipLaunchKernelGGL((gemm384_tn_kernel<T, ACT>), dim3(tiles_m * tiles_n), dim3(768), G384_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm384_tn_kernel<T, ACT, RES>), dim3(tiles_m * tiles_n), dim3(768), G384_LDS_BYTES, stream, g);
     return hipGetLastError();
+}
+
+template <typename T, int ACT>
+inline hipError_t launch_gemm384_act(const GemmArgs<T>& g, hipStream_t stream) {
+    return g.epi.residual ? launch_gemm384_inst<T, ACT, true>(g, stream) : launch_gemm384_inst<T, ACT, false>(g, stream);
 }
 
 template <typename T>

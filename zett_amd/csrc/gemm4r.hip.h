@@ -1,0 +1,288 @@
+// gemm4r.hip.h — 256x256 MFMA GEMM for long K on gfx950: FOUR waves (one per SIMD), each owning a
+// 128x128 quadrant of the tile (4x4 MFMA tiles of 32x32 = 256 accumulator registers; the
+// unified 512-entry register file holds them at one wave per SIMD), operands staged
+// global_load_dwordx4 -> VGPRs -> ds_write_b128.
+//
+//   C[M,N] = epilogue( A[M,K] · W[N,K]ᵀ )      (contract and epilogue of gemm.hip.h)
+//
+// Why not LDS-DMA here: a 1 KiB LDS-DMA request blocks the issue port of its SIMD for ~52-60
+// cycles (tools/experiments/gemm4w.hip.h: 16 requests = 830 of the 3040 cycles of a K step; the
+// same total whether eight waves, four waves or dedicated loader waves issue them), which a
+// 32-cycle MFMA cannot cover.  A global_load_dwordx4 and a ds_write_b128 are ordinary issue slots
+// that fit in the shadow of an MFMA, and with one wave per SIMD there is room for the 64
+// staging registers of a whole K step, so a load has a full K step to land.  A wave also reads
+// a third fewer fragment bytes per MFMA than in gemm256.hip.h (4 A + 4 W for 16 MFMAs).
+// Measured against gemm256.hip.h: +6-8 % at K >= 3072, +8-12 % with the fp32 residual
+// epilogue; slower below K ~ 2500 without residual (longer prologue), where the caller keeps
+// the eight-wave kernel.  The chip is power-limited in this regime: of the 19 %
+// of cycles saved, about a third comes back as throughput, the rest as lower clock.
+//
+// Per K step t and wave: 64 MFMAs in four groups (kk = 0..3), one MFMA per scheduling region
+// so that every other instruction sits in the shadow of one.  Group 0 writes the A rows of step
+// t+1 (in registers since step t-1) to the other LDS stage and reloads those registers with step
+// t+2; group 1 does the same for W; between group 2 and 3 sits the only barrier of the step
+// (every wave's reads of stage t and writes of stage t+1 are complete); group 3 reads the first
+// fragments of step t+1.  LDS image and swizzle as in gemm256.hip.h (the swizzle is applied on
+// the ds_write address; the global reads are plain 128-byte rows).  The K reduction order per
+// accumulator is the same as in the other kernels, so results are bit-identical to them.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "gemm256.hip.h"
+
+namespace zett {
+
+constexpr int G4R_WAIT_LGKM0 = 0xC07F;     // s_waitcnt lgkmcnt(0), vmcnt/expcnt untouched
+
+__device__ unsigned long long g4r_trace[4096 * 4 * 8];    // [block][wave]{loop, -, barrier wait, steps, realtime} (G4R_TRACE builds)
+
+template <typename T, int ACT = ACT_NONE, bool RES = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4r_tn_kernel(GemmArgs<T> g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
+
+    const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
+    const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
+    const int nwg = tiles_m * tiles_n;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    constexpr int GROUP_M = 8;
+    const int group_size = GROUP_M * tiles_n;
+    const int first_m = (wg / group_size) * GROUP_M;
+    const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+    const int tm = first_m + (wg % group_size) % gm;
+    const int tn = (wg % group_size) / gm;
+    const int m0 = tm * G256_BM, n0 = tn * G256_BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..3
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // staging plan: wave w moves rows w*64 + j*8 + lane/8 (j = 0..7) of each operand, 16-byte
+    // chunk lane%8: uniform base pointer + 32-bit lane offset (rows past the edge are clamped)
+    const unsigned char* a_base = (const unsigned char*)(g.A + (size_t)m0 * g.lda);
+    const unsigned char* w_base = (const unsigned char*)(g.W + (size_t)n0 * g.ldw);
+    uint32_t a_voff[8], w_voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = wave * 64 + j * 8 + (lane >> 3);
+        int ar = row; ar = m0 + ar < g.M ? ar : g.M - 1 - m0;
+        int wr = row; wr = n0 + wr < g.N ? wr : g.N - 1 - n0;
+        a_voff[j] = (uint32_t)ar * (uint32_t)g.lda * (uint32_t)sizeof(T) + (lane & 7) * 16;
+        w_voff[j] = (uint32_t)wr * (uint32_t)g.ldw * (uint32_t)sizeof(T) + (lane & 7) * 16;
+    }
+    // ds_write address of piece j inside an operand image: row*128 + ((chunk ^ swz(row)) << 4);
+    // swz(row) = (row>>1)&7 flips bit 2 between even and odd j
+    int st_off[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int row = wave * 64 + par * 8 + (lane >> 3);
+        st_off[par] = row * GEMM_ROW_BYTES + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    u32x4 ra[8], rw[8];
+    auto load_a = [&](int kt, int j) { ra[j] = *(const u32x4*)(a_base + (size_t)kt * GEMM_ROW_BYTES + a_voff[j]); };
+    auto load_w = [&](int kt, int j) { rw[j] = *(const u32x4*)(w_base + (size_t)kt * GEMM_ROW_BYTES + w_voff[j]); };
+    auto store_a = [&](int stage, int j) { *(u32x4*)(smem + stage * G256_STAGE_BYTES + st_off[j & 1] + (j >> 1) * 16 * GEMM_ROW_BYTES) = ra[j]; };
+    auto store_w = [&](int stage, int j) { *(u32x4*)(smem + stage * G256_STAGE_BYTES + G256_OPERAND_BYTES + st_off[j & 1] + (j >> 1) * 16 * GEMM_ROW_BYTES) = rw[j]; };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int swz = (l31 >> 1) & 7;
+    int a_off[4], w_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int c = ((kk * 2 + hi) ^ swz) << 4;
+        a_off[kk] = (wm * 128 + l31) * GEMM_ROW_BYTES + c;
+        w_off[kk] = G256_OPERAND_BYTES + (wn * 128 + l31) * GEMM_ROW_BYTES + c;
+    }
+    u32x4 fa[2][4], fw[2][4];
+    auto read_frag = [&](int stage, int kk, int set, int q) {     // q = 0..3: A fragment q, 4..7: W fragment q-4
+        const unsigned char* S = smem + stage * G256_STAGE_BYTES;
+        if (q < 4) fa[set][q] = *(const u32x4*)(S + a_off[kk] + q * 32 * GEMM_ROW_BYTES);
+        else fw[set][q - 4] = *(const u32x4*)(S + w_off[kk] + (q - 4) * 32 * GEMM_ROW_BYTES);
+    };
+    auto mfma_one = [&](int set, int m) { mfma_chunk<T>(fa[set][m >> 2], fw[set][m & 3], acc[m >> 2][m & 3]); };
+
+    const int nk = g.K / BK;
+    // ---- prologue: step 0 through registers into stage 0, step 1 into registers
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { load_a(0, j); load_w(0, j); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { store_a(0, j); store_w(0, j); }
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { load_a(1, j); load_w(1, j); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) read_frag(0, 0, 0, q);
+
+    unsigned long long tr_b = 0; (void)tr_b;
+    const unsigned long long tr_start = __builtin_readcyclecounter(), tr_rt0 = wall_clock64(); (void)tr_start; (void)tr_rt0;
+    auto step = [&](int kt, auto more_c, auto more2_c) {
+        constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
+        const int cur = kt & 1;
+        // group 0: fragments of kk=1; A rows of step kt+1 -> stage cur^1, reload with step kt+2.
+        // One MFMA per scheduling region so that every filler sits in the shadow of an MFMA.
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            mfma_one(0, 2 * q);
+            read_frag(cur, 1, 1, q);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_one(0, 2 * q + 1);
+            if (more) store_a(cur ^ 1, q);
+            if (more2) load_a(kt + 2, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // group 1: fragments of kk=2; W rows likewise
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            mfma_one(1, 2 * q);
+            read_frag(cur, 2, 0, q);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_one(1, 2 * q + 1);
+            if (more) store_w(cur ^ 1, q);
+            if (more2) load_w(kt + 2, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // group 2: fragments of kk=3
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            mfma_one(0, 2 * q);
+            read_frag(cur, 3, 1, q);
+            mfma_one(0, 2 * q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // every read of stage cur and every write of stage cur^1 by this wave is complete
+#ifdef G4R_TRACE
+        __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
+        const unsigned long long c1 = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+        tr_b += __builtin_readcyclecounter() - c1;
+#else
+        __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
+        __builtin_amdgcn_s_barrier();
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // group 3: first fragments of step kt+1
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            mfma_one(1, 2 * q);
+            if (more) read_frag(cur ^ 1, 0, 0, q);
+            mfma_one(1, 2 * q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    typedef std::integral_constant<bool, true> yes_t;
+    typedef std::integral_constant<bool, false> no_t;
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) step(kt, yes_t{}, yes_t{});
+    if (kt + 1 < nk) { step(kt, yes_t{}, no_t{}); ++kt; }
+    step(kt, no_t{}, no_t{});
+#ifdef G4R_TRACE
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = g4r_trace + (blockIdx.x * 4 + wave) * 8;
+        o[0] = __builtin_readcyclecounter() - tr_start; o[1] = 0; o[2] = tr_b; o[3] = nk; o[4] = wall_clock64() - tr_rt0;
+    }
+#endif
+
+    // ---- epilogue: each wave stages its 128x128 quadrant through a private 32 KiB LDS region
+    // (64 rows x 128 fp32), two passes, drained as float4 per lane (two rows per instruction).
+    __syncthreads();
+    float* region = (float*)(smem + wave * 32768);
+    const GemmEpilogue<T>& e = g.epi;
+    const int c4 = l31 * 4;
+    const int gcol = n0 + wn * 128 + c4;
+    const bool col_ok = gcol < g.N;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = bias4;
+    if (col_ok) {
+        if (e.bias) bias4 = *(const float4*)(e.bias + gcol);
+        if (e.scale) sc4 = *(const float4*)(e.scale + gcol);
+        if (e.shift) sh4 = *(const float4*)(e.shift + gcol);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float4 o[32];
+        if (RES) {
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                const int grow = m0 + wm * 128 + p * 64 + t * 2 + hi;
+                o[t] = (grow < g.M && col_ok) ? *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    region[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 128 + j * 32 + l31] = acc[2 * p + i2][j][r];
+        if (RES || p == 0) __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const int lrow = t * 2 + hi;
+            float4 v = *(const float4*)(region + lrow * 128 + c4);
+            o[t] = epi_value4<ACT>(v, bias4, RES, RES ? o[t] : make_float4(0.f, 0.f, 0.f, 0.f), e.scale != nullptr, sc4, sh4);
+        }
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const int grow = m0 + wm * 128 + p * 64 + t * 2 + hi;
+            if (grow >= g.M || !col_ok) continue;
+            if (gcol < e.split_col) {
+                if (e.out_f32) *(float4*)(e.out_f32 + (size_t)grow * e.ld_f32 + gcol) = o[t];
+                if (e.out_lo) store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, o[t]);
+            } else if (e.out_f32_b) {
+                *(float4*)(e.out_f32_b + (size_t)grow * e.ld_f32 + (gcol - e.split_col)) = o[t];
+            }
+        }
+    }
+}
+
+template <typename T, int ACT, bool RES>
+inline hipError_t launch_gemm4r_inst(const GemmArgs<T>& g, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm4r_tn_kernel<T, ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
+    const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
+    if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
+    hipLaunchKernelGGL((gemm4r_tn_kernel<T, ACT, RES>), dim3(tiles_m * tiles_n), dim3(256), G256_LDS_BYTES, stream, g);
+    return hipGetLastError();
+}
+
+template <typename T, int ACT>
+inline hipError_t launch_gemm4r_act(const GemmArgs<T>& g, hipStream_t stream) {
+    return g.epi.residual ? launch_gemm4r_inst<T, ACT, true>(g, stream) : launch_gemm4r_inst<T, ACT, false>(g, stream);
+}
+
+template <typename T>
+inline hipError_t launch_gemm4r(const GemmArgs<T>& g, hipStream_t stream) {
+    switch (g.epi.act) {
+        case ACT_GELU_TANH: return launch_gemm4r_act<T, ACT_GELU_TANH>(g, stream);
+        case ACT_GELU_ERF: return launch_gemm4r_act<T, ACT_GELU_ERF>(g, stream);
+        default: return launch_gemm4r_act<T, ACT_NONE>(g, stream);
+    }
+}
+
+}  // namespace zett

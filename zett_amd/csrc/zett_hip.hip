@@ -24,6 +24,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/zett_hip.h"
@@ -31,6 +32,7 @@
 #include "gemm.hip.h"
 #include "gemm256.hip.h"
 #include "gemm384.hip.h"
+#include "gemm4r.hip.h"
 #include "rowops.hip.h"
 #include "retok.hip.h"
 
@@ -65,7 +67,7 @@ struct zett_hypernet {
     int64_t max_chunk_tokens = 65536;
     int time_gemm = 0;
     int cls_only_last = 1;
-    int gemm_variant = 0;             // 0 auto, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA, 3 = 384x256 LDS-DMA
+    int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 LDS-DMA, 3 = 384x256 LDS-DMA, 4 = 256x256 four-wave
     // workspace
     DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct;
     int32_t* host_pinned = nullptr;
@@ -320,7 +322,7 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "cls_only_last_layer") {
         h->cls_only_last = value != 0;
     } else if (k == "gemm_variant") {
-        if (value < 0 || value > 3) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (384x256)");
+        if (value < 0 || value > 4) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto), 1 (128x128), 2 (256x256), 3 (384x256) or 4 (256x256 four-wave)");
         h->gemm_variant = (int)value;
     } else {
         return fail(ZETT_E_INVALID, "unknown option %s", key);
@@ -382,6 +384,11 @@ struct Runner {
 
     long a_rows_readable = 0;   // rows every A operand buffer can be read for (workspace slack)
 
+    static hipError_t launch_4r(const GemmArgs<T>& g, hipStream_t s) {
+        if constexpr (std::is_same<T, float>::value) return hipErrorInvalidValue;
+        else return launch_gemm4r<T>(g, s);
+    }
+
     void gemm(const T* A, int lda, const T* Wp, int ldw, int M, int N, int K, const GemmEpilogue<T>& e) {
         if (rc || M <= 0) return;
         GemmArgs<T> g{A, lda, Wp, ldw, M, N, K, e};
@@ -399,23 +406,32 @@ struct Runner {
             h->ev_shape.push_back({M, N, K, 0});
             (void)hipEventRecord(e0, st);
         }
-        // Tile choice.  Small problems: 128x128.  Otherwise 256x256, unless the 384x256 tile
-        // needs fewer rounds over the 256 CUs (it runs ~1.55x as long per tile): wave
-        // quantisation decides, e.g. M = 29 187 or M = 5 111 at N = 4096.  The 384-row kernel
-        // does not clamp rows, so A must have `a_rows_readable` >= tiles*384 rows (every A
-        // operand here is a workspace buffer with that slack) and N must be a multiple of 256.
+        // Tile choice.  Small problems: 128x128.  Otherwise a 256x256 tile — the four-wave
+        // register-staged kernel when K is long or the epilogue carries the fp32 residual, the
+        // eight-wave LDS-DMA kernel otherwise (tools/gemm_bench: crossover near K = 2500) — unless
+        // the 384x256 tile needs fewer rounds over the 256 CUs (it runs ~1.55x as long per
+        // tile; ~1.9x with a residual, whose four epilogue passes each wait for the stores of the
+        // previous one): wave quantisation decides, e.g. M = 5 111 at N = 4096.  The 384-row
+        // kernel does not clamp rows, so A must have `a_rows_readable` >= tiles*384 rows (every
+        // A operand here is a workspace buffer with that slack) and N must be a multiple of 256.
+        // The four-wave kernel exists for the 16-bit operand types only (fp32 is not staged-bound).
+        constexpr bool has_4r = !std::is_same<T, float>::value;
         int variant = h->gemm_variant;
         if (variant == 0) {
             variant = (M > 128 && N > 128) ? 2 : 1;
-            if (variant == 2 && N % 256 == 0) {
+            if (variant == 2 && has_4r && (K >= 2560 || (e.residual && K >= 1024))) variant = 4;
+            if (variant != 1 && N % 256 == 0) {
                 const long t256 = (long)((M + 255) / 256) * (N / 256), t384 = (long)((M + 383) / 384) * (N / 256);
-                const double c256 = (double)((t256 + 255) / 256), c384 = 1.55 * (double)((t384 + 255) / 256);
+                const double c256 = (double)((t256 + 255) / 256), c384 = (e.residual ? 1.9 : 1.55) * (double)((t384 + 255) / 256);
                 if (c384 < c256) variant = 3;
             }
         }
         if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable)) variant = 2;
+        if (variant == 4 && !has_4r) variant = 2;
         if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
-        hipError_t err = variant == 3 ? launch_gemm384<T>(g, st) : variant == 2 ? launch_gemm256<T, 1>(g, st) : launch_gemm<T>(g, st);
+        hipError_t err;
+        if (variant == 4) err = launch_4r(g, st);
+        else err = variant == 3 ? launch_gemm384<T>(g, st) : variant == 2 ? launch_gemm256<T, 1>(g, st) : launch_gemm<T>(g, st);
         if (h->time_gemm) (void)hipEventRecord(e1, st);
         if (err != hipSuccess) { rc = fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(err)); return; }
         h->stats.executed_flops += fl;
@@ -672,7 +688,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 (void)hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]);
                 const auto& sh = h->ev_shape[i / 2];
                 fprintf(stderr, "[zett gemm] M=%6d N=%6d K=%5d tile=%s %8.3f ms %7.1f TF\n", sh[0], sh[1], sh[2],
-                        sh[3] == 3 ? "384" : sh[3] == 2 ? "256" : "128", t, h->ev_flops[i / 2] / (t * 1e9));
+                        sh[3] == 4 ? "4r " : sh[3] == 3 ? "384" : sh[3] == 2 ? "256" : "128", t, h->ev_flops[i / 2] / (t * 1e9));
             }
         }
     }
