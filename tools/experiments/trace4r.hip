@@ -18,6 +18,12 @@ int main(int argc, char** argv) {
     fill<<<2048, 256>>>(A, (size_t)M * K, 1); fill<<<2048, 256>>>(W, (size_t)N * K, 2);
     GemmArgs<bf16_t> g{}; g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K; g.epi.split_col = 0x7fffffff;
     g.epi.out_lo = C; g.epi.ld_lo = N;
+    if (argc > 4 && atoi(argv[4]) == 2) {
+        float *res, *cf, *bias;
+        CK(hipMalloc(&res, (size_t)M * N * 4)); CK(hipMalloc(&cf, (size_t)M * N * 4)); CK(hipMalloc(&bias, N * 4));
+        CK(hipMemset(res, 0, (size_t)M * N * 4)); CK(hipMemset(bias, 0, N * 4));
+        g.epi.bias = bias; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N;
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) CK(launch_gemm4r<bf16_t>(g, 0));
     CK(hipEventRecord(e0, 0));
@@ -33,6 +39,11 @@ int main(int argc, char** argv) {
     const double steps = tr[3];
     printf("shader clock during the K loops: %.0f MHz (s_memtime ticks per 10 ns s_memrealtime tick x 100)\n", loop / rt * 100.0);
     printf("per K step (shader clocks, mean over %d waves): loop %.0f  vmcnt-wait %.0f  barrier-wait %.0f  (64 MFMAs = 2048 clk at full rate)\n", n, loop / n / steps, wv / n / steps, wb / n / steps);
+    {   // per-tile timeline of CU slots: prologue, K loop, epilogue (10 ns ticks), and the gap to the next workgroup on the same CU is not visible here
+        double pro = 0, lp = 0, epi = 0; int m = 0;
+        for (int b = 0; b < tiles && b < 4096; ++b) { const unsigned long long* o = &tr[(b * 4) * 8]; pro += o[5]; lp += o[4]; epi += (double)o[7] - (double)o[6] - (double)o[5] - (double)o[4]; ++m; }
+        printf("per tile (us): prologue %.2f  K loop %.2f  epilogue %.2f   (kernel %.3f ms over %.1f tile rounds = %.2f us per round)\n", pro / m / 100, lp / m / 100, epi / m / 100, ms, tiles / 256.0, ms * 1000 / (tiles / 256.0));
+    }
     for (int b : {0, 1, 300}) for (int w = 0; w < 4; ++w) { const unsigned long long* o = &tr[(b * 4 + w) * 8]; printf("  block %d wave %d: loop/step %.0f vm %.0f bar %.0f\n", b, w, o[0] / steps, o[1] / steps, o[2] / steps); }
     return 0;
 }

@@ -43,6 +43,88 @@ template <> __device__ __forceinline__ void store_out4<f16_t>(f16_t* dst, float4
     *(uint2*)dst = make_uint2(pack2_lo<f16_t>(v.x, v.y), pack2_lo<f16_t>(v.z, v.w));
 }
 
+template <typename T> __device__ __forceinline__ void store_out8(T* dst, float4 a, float4 b);
+template <> __device__ __forceinline__ void store_out8<float>(float* dst, float4 a, float4 b) { *(float4*)dst = a; *(float4*)(dst + 4) = b; }
+template <> __device__ __forceinline__ void store_out8<bf16_t>(bf16_t* dst, float4 a, float4 b) {
+    *(uint4*)dst = make_uint4(pack2_lo<bf16_t>(a.x, a.y), pack2_lo<bf16_t>(a.z, a.w), pack2_lo<bf16_t>(b.x, b.y), pack2_lo<bf16_t>(b.z, b.w));
+}
+template <> __device__ __forceinline__ void store_out8<f16_t>(f16_t* dst, float4 a, float4 b) {
+    *(uint4*)dst = make_uint4(pack2_lo<f16_t>(a.x, a.y), pack2_lo<f16_t>(a.z, a.w), pack2_lo<f16_t>(b.x, b.y), pack2_lo<f16_t>(b.z, b.w));
+}
+
+// Epilogue drain shared by the large-tile kernels.  One wave has staged ROWS x COLS fp32
+// accumulators (row stride COLS floats) in its private LDS region; every lane takes EIGHT
+// consecutive columns of a row, so the 16-bit output is one global_store_dwordx4 per lane and
+// instruction: stores are issue-bound (a wave instruction costs about the same whatever its
+// width; MI355X_MICROARCH.md "store tail"), and with four columns per lane the bf16 output of a
+// 256x256 tile took 10 us.  The two 16-byte LDS reads of a lane are ordered so that the lane
+// groups of ds_read_b128 hit 16 distinct bank quads (rows are a multiple of 256 bytes apart):
+// the second half first for odd rows (COLS = 64) / for the upper half of the row (COLS = 128).
+//
+// Order of a pass: residual rows requested first, all at once (load_res), the caller stages the
+// accumulators, one explicit vmcnt(0), then a drain without any load in it.  Loads and stores
+// share the vmcnt counter: a wait for a residual value placed between stores also waits for
+// every earlier store to be acknowledged — one full write latency per row group, which the
+// first version of this epilogue paid (11 us per tile).
+template <typename T, int ACT, bool RES, int ROWS, int COLS>
+struct EpiDrain {
+    static constexpr int LPR = COLS / 8;       // lanes per row
+    static constexpr int RPI = 64 / LPR;       // rows per wave instruction
+    static constexpr int NIT = ROWS / RPI;     // instructions per pass
+
+    static __device__ __forceinline__ void load_res(const GemmArgs<T>& g, int row0, int gcol, bool col_ok, int lane, float4 (&oa)[NIT], float4 (&ob)[NIT]) {
+        if (!RES) return;
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int grow = row0 + t * RPI + lane / LPR;
+            const bool ok = grow < g.M && col_ok;
+            const float* src = g.epi.residual + (size_t)grow * g.epi.ld_res + gcol;
+            oa[t] = ok ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
+            ob[t] = ok ? *(const float4*)(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    static __device__ __forceinline__ void drain(const GemmArgs<T>& g, const float* region, int row0, int gcol, bool col_ok, int lane,
+                                                 const float4 (&bias8)[2], const float4 (&sc8)[2], const float4 (&sh8)[2], float4 (&oa)[NIT], float4 (&ob)[NIT]) {
+        const GemmEpilogue<T>& e = g.epi;
+        const int idx = lane % LPR;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool has_scale = e.scale != nullptr;
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int lrow = t * RPI + lane / LPR;
+            const int sw = COLS == 128 ? (idx >> 3) : (lrow & 1);
+            const float* src = region + lrow * COLS + idx * 8;
+            const float4 first = *(const float4*)(src + 4 * sw), second = *(const float4*)(src + 4 * (sw ^ 1));
+            const float4 lo = sw ? second : first, hi = sw ? first : second;
+            oa[t] = epi_value4<ACT>(lo, bias8[0], RES, RES ? oa[t] : zero, has_scale, sc8[0], sh8[0]);
+            ob[t] = epi_value4<ACT>(hi, bias8[1], RES, RES ? ob[t] : zero, has_scale, sc8[1], sh8[1]);
+        }
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int grow = row0 + t * RPI + lane / LPR;
+            if (grow >= g.M || !col_ok) continue;
+            if (gcol < e.split_col) {
+                if (e.out_f32) { float* d = e.out_f32 + (size_t)grow * e.ld_f32 + gcol; *(float4*)d = oa[t]; *(float4*)(d + 4) = ob[t]; }
+                if (e.out_lo) store_out8<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, oa[t], ob[t]);
+            } else if (e.out_f32_b) {
+                float* d = e.out_f32_b + (size_t)grow * e.ld_f32 + (gcol - e.split_col);
+                *(float4*)d = oa[t]; *(float4*)(d + 4) = ob[t];
+            }
+        }
+    }
+
+    // bias / scale / shift of the lane's eight columns
+    static __device__ __forceinline__ void load_cols(const GemmEpilogue<T>& e, int gcol, bool col_ok, float4 (&bias8)[2], float4 (&sc8)[2], float4 (&sh8)[2]) {
+        bias8[0] = bias8[1] = sh8[0] = sh8[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sc8[0] = sc8[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (!col_ok) return;
+        if (e.bias) { bias8[0] = *(const float4*)(e.bias + gcol); bias8[1] = *(const float4*)(e.bias + gcol + 4); }
+        if (e.scale) { sc8[0] = *(const float4*)(e.scale + gcol); sc8[1] = *(const float4*)(e.scale + gcol + 4); }
+        if (e.shift) { sh8[0] = *(const float4*)(e.shift + gcol); sh8[1] = *(const float4*)(e.shift + gcol + 4); }
+    }
+};
+
 // VAR (experiments, tools/gemm_bench): bit 0 = spread the DMA issue over the 4 K chunks of a step,
 // bit 1 = s_setprio(1) around the MFMA groups.  The product uses VAR = 0.
 template <typename T, int VAR = 0, int ACT = ACT_NONE, bool RES = false>
@@ -165,36 +247,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- epilogue.  The accumulators go through LDS (free now) so that global traffic is
     // row-contiguous: each wave owns a private 16 KiB region = 64 rows x 64 fp32, filled from
-    // the MFMA layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) and drained
-    // as float4 per lane, 16 lanes per 256-byte row segment.
+    // the MFMA layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) and drained by
+    // EpiDrain, eight columns per lane.
     __syncthreads();                                  // all waves are done with the K stages
     float* region = (float*)(smem + wave * 16384);
-    const GemmEpilogue<T>& e = g.epi;
-    const int c4 = (lane & 15) * 4;
-    const int gcol = n0 + wn * 64 + c4;
+    typedef EpiDrain<T, ACT, RES, 64, 64> Drain;
+    const int gcol = n0 + wn * 64 + (lane % Drain::LPR) * 8;
     const bool col_ok = gcol < g.N;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = bias4;
-    if (col_ok) {
-        if (e.bias) bias4 = *(const float4*)(e.bias + gcol);
-        if (e.scale) sc4 = *(const float4*)(e.scale + gcol);
-        if (e.shift) sh4 = *(const float4*)(e.shift + gcol);
-    }
+    float4 bias8[2], sc8[2], sh8[2];
+    Drain::load_cols(g.epi, gcol, col_ok, bias8, sc8, sh8);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        // The residual rows of this pass are requested first, all at once, so that their
-        // latencies overlap each other and the LDS staging below.  The drain is split in two
-        // straight-line phases — (A) LDS -> registers with bias/activation/residual/scale,
-        // (B) nothing but stores — because loads and stores share the vmcnt counter: a wait for a
-        // residual value placed between stores also waits for every earlier store to be
-        // acknowledged, i.e. one full write latency per row group (measured: 11 us per tile).
-        float4 o[16];
-        if (RES) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int grow = m0 + wm * 128 + p * 64 + t * 4 + (lane >> 4);
-                o[t] = (grow < g.M && col_ok) ? *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        float4 oa[Drain::NIT], ob[Drain::NIT];
+        const int row0 = m0 + wm * 128 + p * 64;
+        Drain::load_res(g, row0, gcol, col_ok, lane, oa, ob);
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -202,26 +268,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     region[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + l31] = acc[2 * p + i2][j][r];
-        // every load of the epilogue (bias/scale/shift, this pass's residual rows) is complete
-        // from here on: the compiler then needs no vmcnt wait inside the store sequence
         if (RES || p == 0) __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int lrow = t * 4 + (lane >> 4);
-            float4 v = *(const float4*)(region + lrow * 64 + c4);
-            o[t] = epi_value4<ACT>(v, bias4, RES, RES ? o[t] : make_float4(0.f, 0.f, 0.f, 0.f), e.scale != nullptr, sc4, sh4);
-        }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int grow = m0 + wm * 128 + p * 64 + t * 4 + (lane >> 4);
-            if (grow >= g.M || !col_ok) continue;
-            if (gcol < e.split_col) {
-                if (e.out_f32) *(float4*)(e.out_f32 + (size_t)grow * e.ld_f32 + gcol) = o[t];
-                if (e.out_lo) store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, o[t]);
-            } else if (e.out_f32_b) {
-                *(float4*)(e.out_f32_b + (size_t)grow * e.ld_f32 + (gcol - e.split_col)) = o[t];
-            }
-        }
+        Drain::drain(g, region, row0, gcol, col_ok, lane, bias8, sc8, sh8, oa, ob);
     }
 }
 

@@ -124,54 +124,26 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 
     // ---- epilogue: accumulators through a private 8 KiB LDS region per wave (32 rows x 64 fp32),
-    // four passes (one per 32-row MFMA tile row), drained as float4 per lane.
+    // four passes (one per 32-row MFMA tile row), drained by EpiDrain (gemm256.hip.h).
     __syncthreads();
     float* region = (float*)(smem + wave * 8192);
-    const GemmEpilogue<T>& e = g.epi;
-    const int c4 = (lane & 15) * 4;
-    const int gcol = n0 + wn * 64 + c4;
+    typedef EpiDrain<T, ACT, RES, 32, 64> Drain;
+    const int gcol = n0 + wn * 64 + (lane % Drain::LPR) * 8;
     const bool col_ok = gcol < g.N;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = bias4;
-    if (col_ok) {
-        if (e.bias) bias4 = *(const float4*)(e.bias + gcol);
-        if (e.scale) sc4 = *(const float4*)(e.scale + gcol);
-        if (e.shift) sh4 = *(const float4*)(e.shift + gcol);
-    }
+    float4 bias8[2], sc8[2], sh8[2];
+    Drain::load_cols(g.epi, gcol, col_ok, bias8, sc8, sh8);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        // residual rows first (all at once), LDS staging, one explicit vmcnt(0), then a drain
-        // without any load in it: see the epilogue of gemm256.hip.h for why
-        float4 o[8];
-        if (RES) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int grow = m0 + wm * 128 + i * 32 + t * 4 + (lane >> 4);
-                o[t] = (grow < g.M && col_ok) ? *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        float4 oa[Drain::NIT], ob[Drain::NIT];
+        const int row0 = m0 + wm * 128 + i * 32;
+        Drain::load_res(g, row0, gcol, col_ok, lane, oa, ob);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 region[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + l31] = acc[i][j][r];
         if (RES || i == 0) __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int lrow = t * 4 + (lane >> 4);
-            float4 v = *(const float4*)(region + lrow * 64 + c4);
-            o[t] = epi_value4<ACT>(v, bias4, RES, RES ? o[t] : make_float4(0.f, 0.f, 0.f, 0.f), e.scale != nullptr, sc4, sh4);
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int grow = m0 + wm * 128 + i * 32 + t * 4 + (lane >> 4);
-            if (grow >= g.M || !col_ok) continue;
-            if (gcol < e.split_col) {
-                if (e.out_f32) *(float4*)(e.out_f32 + (size_t)grow * e.ld_f32 + gcol) = o[t];
-                if (e.out_lo) store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, o[t]);
-            } else if (e.out_f32_b) {
-                *(float4*)(e.out_f32_b + (size_t)grow * e.ld_f32 + (gcol - e.split_col)) = o[t];
-            }
-        }
+        Drain::drain(g, region, row0, gcol, col_ok, lane, bias8, sc8, sh8, oa, ob);
     }
 }
 

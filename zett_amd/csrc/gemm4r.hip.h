@@ -45,6 +45,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
 
+#ifdef G4R_TRACE
+    const unsigned long long tr_entry = wall_clock64();
+#endif
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     const int nwg = tiles_m * tiles_n;
@@ -200,34 +203,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef G4R_TRACE
     if (lane == 0 && blockIdx.x < 4096) {
         unsigned long long* o = g4r_trace + (blockIdx.x * 4 + wave) * 8;
-        o[0] = __builtin_readcyclecounter() - tr_start; o[1] = 0; o[2] = tr_b; o[3] = nk; o[4] = wall_clock64() - tr_rt0;
+        o[0] = __builtin_readcyclecounter() - tr_start; o[1] = 0; o[2] = tr_b; o[3] = nk; o[4] = wall_clock64() - tr_rt0; o[5] = tr_rt0 - tr_entry; o[6] = tr_entry;
     }
 #endif
 
     // ---- epilogue: each wave stages its 128x128 quadrant through a private 32 KiB LDS region
-    // (64 rows x 128 fp32), two passes, drained as float4 per lane (two rows per instruction).
+    // (64 rows x 128 fp32), two passes, drained by EpiDrain (gemm256.hip.h).
     __syncthreads();
     float* region = (float*)(smem + wave * 32768);
-    const GemmEpilogue<T>& e = g.epi;
-    const int c4 = l31 * 4;
-    const int gcol = n0 + wn * 128 + c4;
+    typedef EpiDrain<T, ACT, RES, 64, 128> Drain;
+    const int gcol = n0 + wn * 128 + (lane % Drain::LPR) * 8;
     const bool col_ok = gcol < g.N;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = bias4;
-    if (col_ok) {
-        if (e.bias) bias4 = *(const float4*)(e.bias + gcol);
-        if (e.scale) sc4 = *(const float4*)(e.scale + gcol);
-        if (e.shift) sh4 = *(const float4*)(e.shift + gcol);
-    }
+    float4 bias8[2], sc8[2], sh8[2];
+    Drain::load_cols(g.epi, gcol, col_ok, bias8, sc8, sh8);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        float4 o[32];
-        if (RES) {
-#pragma unroll
-            for (int t = 0; t < 32; ++t) {
-                const int grow = m0 + wm * 128 + p * 64 + t * 2 + hi;
-                o[t] = (grow < g.M && col_ok) ? *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        float4 oa[Drain::NIT], ob[Drain::NIT];
+        const int row0 = m0 + wm * 128 + p * 64;
+        Drain::load_res(g, row0, gcol, col_ok, lane, oa, ob);
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -236,24 +229,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int r = 0; r < 16; ++r)
                     region[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 128 + j * 32 + l31] = acc[2 * p + i2][j][r];
         if (RES || p == 0) __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            const int lrow = t * 2 + hi;
-            float4 v = *(const float4*)(region + lrow * 128 + c4);
-            o[t] = epi_value4<ACT>(v, bias4, RES, RES ? o[t] : make_float4(0.f, 0.f, 0.f, 0.f), e.scale != nullptr, sc4, sh4);
-        }
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            const int grow = m0 + wm * 128 + p * 64 + t * 2 + hi;
-            if (grow >= g.M || !col_ok) continue;
-            if (gcol < e.split_col) {
-                if (e.out_f32) *(float4*)(e.out_f32 + (size_t)grow * e.ld_f32 + gcol) = o[t];
-                if (e.out_lo) store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, o[t]);
-            } else if (e.out_f32_b) {
-                *(float4*)(e.out_f32_b + (size_t)grow * e.ld_f32 + (gcol - e.split_col)) = o[t];
-            }
-        }
+        Drain::drain(g, region, row0, gcol, col_ok, lane, bias8, sc8, sh8, oa, ob);
     }
+#ifdef G4R_TRACE
+    if (lane == 0 && blockIdx.x < 4096) g4r_trace[(blockIdx.x * 4 + wave) * 8 + 7] = wall_clock64();
+#endif
 }
 
 template <typename T, int ACT, bool RES>

@@ -427,6 +427,10 @@ struct Runner {
             }
         }
         if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable)) variant = 2;
+        // the large tiles drain eight columns per lane with 16-byte accesses
+        const bool wide_ok = N % 8 == 0 && (!e.out_lo || e.ld_lo % 8 == 0) && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0) &&
+                             (e.split_col >= N || e.split_col % 8 == 0);
+        if (variant != 1 && !wide_ok) variant = 1;
         if (variant == 4 && !has_4r) variant = 2;
         if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
         hipError_t err;
