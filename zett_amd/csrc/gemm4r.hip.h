@@ -38,16 +38,11 @@ namespace zett {
 
 constexpr int G4R_WAIT_LGKM0 = 0xC07F;     // s_waitcnt lgkmcnt(0), vmcnt/expcnt untouched
 
-__device__ unsigned long long g4r_trace[4096 * 4 * 8];    // [block][wave]{loop, -, barrier wait, steps, realtime} (G4R_TRACE builds)
-
 template <typename T, int ACT = ACT_NONE, bool RES = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4r_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
 
-#ifdef G4R_TRACE
-    const unsigned long long tr_entry = wall_clock64();
-#endif
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     const int nwg = tiles_m * tiles_n;
@@ -138,8 +133,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int q = 0; q < 8; ++q) read_frag(0, 0, 0, q);
 
-    unsigned long long tr_b = 0; (void)tr_b;
-    const unsigned long long tr_start = __builtin_readcyclecounter(), tr_rt0 = wall_clock64(); (void)tr_start; (void)tr_rt0;
     auto step = [&](int kt, auto more_c, auto more2_c) {
         constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
         const int cur = kt & 1;
@@ -175,15 +168,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
         }
         // every read of stage cur and every write of stage cur^1 by this wave is complete
-#ifdef G4R_TRACE
-        __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
-        const unsigned long long c1 = __builtin_readcyclecounter();
-        __builtin_amdgcn_s_barrier();
-        tr_b += __builtin_readcyclecounter() - c1;
-#else
-        __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
-        __builtin_amdgcn_s_barrier();
-#endif
         __builtin_amdgcn_sched_barrier(0);
         // group 3: first fragments of step kt+1
 #pragma unroll
@@ -200,12 +184,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (; kt + 2 < nk; ++kt) step(kt, yes_t{}, yes_t{});
     if (kt + 1 < nk) { step(kt, yes_t{}, no_t{}); ++kt; }
     step(kt, no_t{}, no_t{});
-#ifdef G4R_TRACE
-    if (lane == 0 && blockIdx.x < 4096) {
-        unsigned long long* o = g4r_trace + (blockIdx.x * 4 + wave) * 8;
-        o[0] = __builtin_readcyclecounter() - tr_start; o[1] = 0; o[2] = tr_b; o[3] = nk; o[4] = wall_clock64() - tr_rt0; o[5] = tr_rt0 - tr_entry; o[6] = tr_entry;
-    }
-#endif
 
     // ---- epilogue: each wave stages its 128x128 quadrant through a private 32 KiB LDS region
     // (64 rows x 128 fp32), two passes, drained by EpiDrain (gemm256.hip.h).
@@ -231,9 +209,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (RES || p == 0) __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
         Drain::drain(g, region, row0, gcol, col_ok, lane, bias8, sc8, sh8, oa, ob);
     }
-#ifdef G4R_TRACE
-    if (lane == 0 && blockIdx.x < 4096) g4r_trace[(blockIdx.x * 4 + wave) * 8 + 7] = wall_clock64();
-#endif
 }
 
 template <typename T, int ACT, bool RES>
