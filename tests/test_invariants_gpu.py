@@ -82,6 +82,23 @@ def test_gemm_tile_variants_bit_identical(precision, name, rows):
         eng.set_option("gemm_variant", 5)
 
 
+def test_repeated_launches_identical_bits_small_grids():
+    """Race screen: few workgroups and long K (a 32-row batch of the TinyLlama-shape hypernet) leave
+    the waves of a workgroup free to drift apart; a missing barrier in a K loop shows up as runs
+    that differ from each other (it did, once: tools/determinism_check.py).  Every tile variant,
+    12 launches each, all bits equal to the first launch and to the automatic choice."""
+    cfg, _, src_dtype, hist = synth.workload("tinyllama_neox")
+    eng = _engine(cfg, 3, "bf16")
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 3, dtype=src_dtype)).cuda()
+    ids = synth.make_surface_forms(cfg, 32, seed=3, hist=hist, n_special=1)
+    auto = _run(eng, ids, src, -1)
+    for variant in (0, 2, 3, 4):
+        eng.set_option("gemm_variant", variant)
+        for it in range(12):
+            assert _eq(_run(eng, ids, src, -1), auto), f"gemm_variant {variant}, launch {it}"
+    eng.set_option("gemm_variant", 0)
+
+
 def test_pad_content_independence():
     """Changing the pad token's source embedding must change nothing for rows with a visible key."""
     cfg, *_ = synth.workload("tiny")

@@ -1,0 +1,27 @@
+"""Run the same forward repeatedly and compare bits (race detector).  GPU box: python tools/determinism_check.py"""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+from tests import util
+from zett_amd import synth
+
+for fixture, precision in [("fwd_real_xlmr_gpt2", "f16"), ("fwd_real_xlmr_gpt2", "bf16"), ("fwd_real_tinyllama_neox", "bf16")]:
+    case = util.load_case(f"tests/golden/{fixture}.npz")
+    w = synth.make_weights(case["cfg"], case["seed"])
+    src = synth.make_source_embeddings(case["cfg"], case["seed"], dtype=case["src_dtype"])
+    model = util.hip_model(case["cfg"], w, precision)
+    for variant in (0, 1, 2, 4):
+        import torch
+        model.engine(torch.device("cuda:0")).set_option("gemm_variant", variant)
+        ref = util.hip_forward(model, case["ids"], src, case["lang"])
+        bad = 0
+        worst = 1.0
+        for it in range(30):
+            out = util.hip_forward(model, case["ids"], src, case["lang"])
+            same = all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(out, ref))
+            bad += not same
+            g, wv = out[0].astype(np.float64), case["pred_in"].astype(np.float64)
+            cos = (g * wv).sum(-1) / (np.linalg.norm(g, axis=-1) * np.linalg.norm(wv, axis=-1))
+            worst = min(worst, cos.min())
+        print(fixture, precision, "variant", variant, "runs differing from the first:", bad, "of 30; worst row cosine vs golden", round(worst, 7), flush=True)
+    del model

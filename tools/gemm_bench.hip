@@ -152,10 +152,15 @@ int main(int argc, char** argv) {
         for (size_t v = 1; v < variants.size(); ++v) {
             CK(hipMemset(C1, 0xff, (size_t)M * N * 2));
             GemmArgs<bf16_t> g = make(C1);
-            CK(variants[v].launch(g, 0)); CK(hipDeviceSynchronize());
-            CK(hipMemset(dmax, 0, 4));
-            max_diff<<<1024, 256>>>(C0, C1, (size_t)M * N, dmax);
-            CK(hipMemcpy(&diffs[v], dmax, 4, hipMemcpyDeviceToHost));
+            const int stress = getenv("STRESS") ? atoi(getenv("STRESS")) : 1;      // repeat launch + compare (race hunting)
+            for (int it = 0; it < stress; ++it) {
+                if (it) CK(hipMemset(C1, 0xff, (size_t)M * N * 2));
+                CK(variants[v].launch(g, 0)); CK(hipDeviceSynchronize());
+                CK(hipMemset(dmax, 0, 4));
+                max_diff<<<1024, 256>>>(C0, C1, (size_t)M * N, dmax);
+                float d; CK(hipMemcpy(&d, dmax, 4, hipMemcpyDeviceToHost));
+                diffs[v] = std::max(diffs[v], d);
+            }
         }
         for (int r = 0; r < rounds; ++r) {
             for (size_t v = 0; v < variants.size(); ++v) {

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the MI355X box (through gpurun): the bench lines, the rocprofv3 kernel-trace/stats pass
+# and the three PMC passes whose summaries are committed under profiles/ (named per round).
+#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r1d'
+set -u
+tag=${1:-rX}
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+bench="python $GRAFT_REPO_ROOT/bench.py"
+$bench 2>/dev/null | tail -1 > $out/bench_default.json
+for w in xlmr_gpt2 tinyllama_neox mistral_neox llama3_256k; do $bench --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_$w.json; done
+$bench --precision f32 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_default_f32.json
+$bench --precision f16 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_default_f16.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o $tag -- $bench --steps 3 --warmup 1 --no-cpu-baseline > $out/prof_bench.json 2> $out/prof.err
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  d=$out/pmc_$(echo $c | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o t -- $bench --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $d.err
+done
+ZETT_GEMM_LOG=1 $bench --steps 1 --warmup 1 --no-cpu-baseline 2> $out/gemm_launch_log.txt > /dev/null
+find $out -name "*.db" -delete; find $out -name "*agent_info*" -delete
+du -sh $out

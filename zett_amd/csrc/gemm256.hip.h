@@ -66,7 +66,8 @@ template <> __device__ __forceinline__ void store_out8<f16_t>(f16_t* dst, float4
 // share the vmcnt counter: a wait for a residual value placed between stores also waits for
 // every earlier store to be acknowledged — one full write latency per row group, which the
 // first version of this epilogue paid (11 us per tile).
-template <typename T, int ACT, bool RES, int ROWS, int COLS>
+// SCALE = false: the caller guarantees epi.scale == nullptr (saves the 16 scale/shift registers).
+template <typename T, int ACT, bool RES, int ROWS, int COLS, bool SCALE = true>
 struct EpiDrain {
     static constexpr int LPR = COLS / 8;       // lanes per row
     static constexpr int RPI = 64 / LPR;       // rows per wave instruction
@@ -89,7 +90,7 @@ struct EpiDrain {
         const GemmEpilogue<T>& e = g.epi;
         const int idx = lane % LPR;
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool has_scale = e.scale != nullptr;
+        const bool has_scale = SCALE && e.scale != nullptr;
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
             const int lrow = t * RPI + lane / LPR;
@@ -120,8 +121,8 @@ struct EpiDrain {
         sc8[0] = sc8[1] = make_float4(1.f, 1.f, 1.f, 1.f);
         if (!col_ok) return;
         if (e.bias) { bias8[0] = *(const float4*)(e.bias + gcol); bias8[1] = *(const float4*)(e.bias + gcol + 4); }
-        if (e.scale) { sc8[0] = *(const float4*)(e.scale + gcol); sc8[1] = *(const float4*)(e.scale + gcol + 4); }
-        if (e.shift) { sh8[0] = *(const float4*)(e.shift + gcol); sh8[1] = *(const float4*)(e.shift + gcol + 4); }
+        if (SCALE && e.scale) { sc8[0] = *(const float4*)(e.scale + gcol); sc8[1] = *(const float4*)(e.scale + gcol + 4); }
+        if (SCALE && e.shift) { sh8[0] = *(const float4*)(e.shift + gcol); sh8[1] = *(const float4*)(e.shift + gcol + 4); }
     }
 };
 

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // four passes (one per 32-row MFMA tile row), drained by EpiDrain (gemm256.hip.h).
     __syncthreads();
     float* region = (float*)(smem + wave * 8192);
-    typedef EpiDrain<T, ACT, RES, 32, 64> Drain;
+    typedef EpiDrain<T, ACT, RES, 32, 64, false> Drain;      // no scale/shift: launch_gemm384 refuses such epilogues
     const int gcol = n0 + wn * 64 + (lane % Drain::LPR) * 8;
     const bool col_ok = gcol < g.N;
     float4 bias8[2], sc8[2], sh8[2];
@@ -155,6 +155,7 @@ inline hipError_t launch_gemm384_inst(const GemmArgs<T>& g, hipStream_t stream) 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    if (g.epi.scale || g.epi.shift) return hipErrorInvalidValue;      // register budget: see EpiDrain<..., SCALE = false>
     const int tiles_m = (g.M + G384_BM - 1) / G384_BM;
     const int tiles_n = (g.N + G384_BN - 1) / G384_BN;
     if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;

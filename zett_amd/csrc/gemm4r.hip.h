@@ -168,6 +168,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
         }
         // every read of stage cur and every write of stage cur^1 by this wave is complete
+        __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // group 3: first fragments of step kt+1
 #pragma unroll

@@ -410,23 +410,25 @@ struct Runner {
         // register-staged kernel when K is long or the epilogue carries the fp32 residual, the
         // eight-wave LDS-DMA kernel otherwise (tools/gemm_bench: crossover near K = 2500) — unless
         // the 384x256 tile needs fewer rounds over the 256 CUs (it runs ~1.55x as long per
-        // tile; ~1.9x with a residual, whose four epilogue passes each wait for the stores of the
-        // previous one): wave quantisation decides, e.g. M = 5 111 at N = 4096.  The 384-row
-        // kernel does not clamp rows, so A must have `a_rows_readable` >= tiles*384 rows (every
-        // A operand here is a workspace buffer with that slack) and N must be a multiple of 256.
-        // The four-wave kernel exists for the 16-bit operand types only (fp32 is not staged-bound).
+        // tile): wave quantisation decides, e.g. M = 5 111 at N = 4096.  The 384-row kernel has no
+        // registers to spare for a residual or scale/shift epilogue (168 per wave: it would spill
+        // into the store sequence) and does not clamp rows, so A must have `a_rows_readable` >=
+        // tiles*384 rows (every A operand here is a workspace buffer with that slack) and N must
+        // be a multiple of 256.  The four-wave kernel exists for the 16-bit operand types only
+        // (fp32 is not staging-bound).
         constexpr bool has_4r = !std::is_same<T, float>::value;
         int variant = h->gemm_variant;
         if (variant == 0) {
             variant = (M > 128 && N > 128) ? 2 : 1;
             if (variant == 2 && has_4r && (K >= 2560 || (e.residual && K >= 1024))) variant = 4;
-            if (variant != 1 && N % 256 == 0) {
+            // (in fp32 mode a tile takes 16x as long and the residual epilogue's spills do not matter)
+            if (variant != 1 && N % 256 == 0 && !e.scale && (!e.residual || !has_4r)) {
                 const long t256 = (long)((M + 255) / 256) * (N / 256), t384 = (long)((M + 383) / 384) * (N / 256);
-                const double c256 = (double)((t256 + 255) / 256), c384 = (e.residual ? 1.9 : 1.55) * (double)((t384 + 255) / 256);
+                const double c256 = (double)((t256 + 255) / 256), c384 = 1.55 * (double)((t384 + 255) / 256);
                 if (c384 < c256) variant = 3;
             }
         }
-        if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable)) variant = 2;
+        if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift)) variant = 2;
         // the large tiles drain eight columns per lane with 16-byte accesses
         const bool wide_ok = N % 8 == 0 && (!e.out_lo || e.ld_lo % 8 == 0) && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0) &&
                              (e.split_col >= N || e.split_col % 8 == 0);
