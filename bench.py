@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="override the vocab size of the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--serial-allgather", action="store_true",
+                    help="N > 1: wait for the all-gather of a step before the next forward starts (default: the RCCL "
+                         "all-gather of step i runs on its own stream under the forward of step i+1, outputs double-buffered)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,11 +129,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    # ZETT_BENCH_ONE_DEVICE=1 (test hook): every rank uses cuda:0 and the collectives go through gloo, so
+    # that the N > 1 control flow can be exercised on a 1-GPU box; never set for a measurement.
+    one_device = os.environ.get("ZETT_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from zett_amd.hypernet import HipEngine
     from zett_amd.sharding import all_gather_rows, shard_bounds
@@ -157,19 +168,48 @@ def main():
     src = torch.from_numpy(synth.make_source_embeddings(cfg, seed=0, dtype=src_dtype)).to(device)
     per = shard_bounds(rows, world, 0)[1]      # rows of the largest shard (all-gather pads to it)
 
+    def gather_async(local):
+        """One RCCL all-gather of a row shard into a fresh [world*per, ...] buffer; returns (full, work)."""
+        if local.shape[0] != per:                      # short last shard: pad to the nominal height
+            pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=device)
+            local = torch.cat([local, pad], dim=0)
+        local = local.contiguous()
+        full = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=device)
+        return full, dist.all_gather_into_tensor(full, local, async_op=True), local
+
+    in_flight = []          # [(fulls, works, locals)] of the previous step (N > 1, overlapped mode)
+
+    def finish(entry):
+        for w in entry[1]:
+            w.wait()        # makes the compute stream wait for the collective; does not block the host
+        return tuple(None if f is None else f[:rows] for f in entry[0])
+
     def step():
         o_in, o_out, o_bias = engine.forward(ids, src, -1 if lang is None else lang)
-        if world > 1:
-            o_in = all_gather_rows(o_in, rows, per)
-            o_bias = all_gather_rows(o_bias, rows, per)
-            if o_out is not None:
-                o_out = all_gather_rows(o_out, rows, per)
-        return o_in, o_out, o_bias
+        if world == 1:
+            return o_in, o_out, o_bias
+        fulls, works, keep = [], [], []
+        for t in (o_in, o_out, o_bias):
+            if t is None:
+                fulls.append(None)
+                continue
+            f, w, loc = gather_async(t)
+            fulls.append(f); works.append(w); keep.append(loc)
+        entry = (fulls, works, keep)
+        if args.serial_allgather:
+            return finish(entry)
+        prev = in_flight.pop() if in_flight else None
+        in_flight.append(entry)
+        return finish(prev) if prev is not None else None
+
+    def drain():
+        return finish(in_flight.pop()) if in_flight else None
 
     gemm_ms = gemm_fl = 0.0
     launches = 0
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,6 +221,9 @@ def main():
         gemm_ms += st["gemm_ms"]
         gemm_fl += st["gemm_flops_timed"]
         launches += st["gemm_launches"]
+    last = drain()          # the all-gather of the last step is inside the timed region
+    if last is not None:
+        out = last
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -190,6 +233,11 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # untimed: the gathered matrix must hold this rank's rows bit for bit (rows are shard-independent)
+        chk = engine.forward(ids, src, -1 if lang is None else lang)
+        for full, loc in zip(out, chk):
+            if full is not None and not torch.equal(full[lo:hi], loc):
+                raise SystemExit(f"rank {rank}: all-gathered rows [{lo}, {hi}) differ from the local forward")
     st = engine.stats()
 
     ms_per_step = dt / args.steps * 1e3
@@ -215,11 +263,11 @@ def main():
         "metric": "predicted token-embeddings/sec (full target vocab)",
         "value": value, "unit": "token-embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic",
+        "dtype": args.precision, "data": "synthetic" + (" [TEST HOOK: all ranks on one device, gloo]" if one_device else ""),
         "config": {"workload": f"{args.workload}: {rows}-row target vocab, hypernet E={dims.n_embd} E_in={dims.n_in_embd} "
                                f"H={dims.hidden} I={dims.intermediate} heads={dims.heads} layers={dims.layers} "
                                f"L={ids_all.shape[1]}, source_embeddings {src_dtype}",
-                   "rows": rows, "rows_per_gpu": hi - lo, "parallelism": f"vocab-row shards x{world} + RCCL all-gather",
+                   "rows": rows, "rows_per_gpu": hi - lo, "parallelism": f"vocab-row shards x{world} + RCCL all-gather" + ("" if world == 1 else (" (after each forward)" if args.serial_allgather else " (step i's gather on the RCCL stream under the forward of step i+1; last one inside the timed region)")),
                    "precision": f"{args.precision} MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision != "f32" else "fp32 MFMA",
                    "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"]},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
