@@ -195,6 +195,118 @@ def forward(W, cfg, target_surface_forms, source_embeddings, lang_index=None):
     return (pred_in.astype(F32), None if pred_out is None else pred_out.astype(F32), bias)
 
 
+def _heads(W, cfg, cls):
+    """Output heads, rescalers and bias head on the CLS states (modeling_hypernet.py:231-265)."""
+    e = int(_cfg(cfg, "n_embd"))
+    separate = bool(_cfg(cfg, "separate_out_embeddings", False))
+    pred = linear(projector_block(cls, W, "output_projection.0."),
+                  W["output_projection.1.weight"], W["output_projection.1.bias"])
+    if _cfg(cfg, "hn_single_head", False):
+        pred_in = pred[..., :e]
+        pred_out = pred[..., e:] if separate else None
+    else:
+        pred_in = pred
+        pred_out = None
+        if separate:
+            pred_out = linear(projector_block(cls, W, "output_projection_out.0."),
+                              W["output_projection_out.1.weight"], W["output_projection_out.1.bias"])
+    if _cfg(cfg, "hn_rescale_embeddings", False):
+        pred_in = W["scaler.w"].reshape(-1) * pred_in + W["scaler.b"].reshape(-1)
+        if pred_out is not None:
+            pred_out = W["out_scaler.w"].reshape(-1) * pred_out + W["out_scaler.b"].reshape(-1)
+    if _cfg(cfg, "hn_predict_bias", False):
+        bias = (cls @ W["bias_projection.weight"][0] + W["bias_projection.bias"][0]).astype(F32)
+    else:
+        bias = np.zeros((cls.shape[0],), dtype=F32)
+    return (pred_in.astype(F32), None if pred_out is None else pred_out.astype(F32), bias)
+
+
+def forward_levers(W, cfg, target_surface_forms, source_embeddings, lang_index=None):
+    """The same function as forward(), computed with the three exact levers the HIP path uses
+    (DESIGN.md §2): (L1) positions that are pad, are not position 0 and are not the language token
+    never influence the CLS state of a row with at least one visible key, so they are dropped;
+    (L2) the input projection depends on the source id only, so it is evaluated once per DISTINCT
+    id; (L3) only position 0 of the last layer is read, so its attention output, FFN and
+    LayerNorms are evaluated for position 0 only.  Rows whose keys are all masked keep every
+    position (uniform attention over all of them, the eager / Flax behaviour).
+
+    Test infrastructure like the rest of this file: it is (a) a CPU proof that the levers are exact
+    (tests compare it with forward()), (b) the "equally optimised CPU path" of SURVEY.md §8d that
+    bench.py times beside the as-written one, so that the GPU speed-up is not credited with
+    algorithmic gains.
+    """
+    if not _cfg(cfg, "hn_embed_using_source_embeddings", False):
+        raise NotImplementedError()
+    ids = np.asarray(target_surface_forms).astype(np.int64)
+    n, seq = ids.shape
+    pad = int(_cfg(cfg, "pad_token_id"))
+    has_lang = bool(_cfg(cfg, "hn_embed_lang_id", False))
+    hdim = int(_cfg(cfg, "hn_hidden_size"))
+    layers = int(_cfg(cfg, "hn_n_layers", 3))
+    heads = int(_cfg(cfg, "hn_num_attention_heads") or hdim // 64)
+    d = hdim // heads
+    scaling = F32(d ** -0.5)
+
+    visible = ids != pad                                     # key mask of the surface positions
+    all_masked = ~visible.any(axis=1) & (not has_lang)       # uniform rows: keep everything
+    keep = visible.copy()
+    keep[:, 0] = True                                        # the CLS query
+    keep[all_masked] = True
+
+    # L2: one input projection per distinct kept id
+    uniq, inverse = np.unique(ids[keep], return_inverse=True)
+    table = embed_inputs(W, cfg, uniq[None, :], source_embeddings)[0]
+    table = linear(table, W["input_projection.0.weight"], W["input_projection.0.bias"])
+    table = projector_block(table, W, "input_projection.1.")
+    slot = np.full(ids.shape, -1, dtype=np.int64)
+    slot[keep] = inverse
+
+    p = "model.embeddings."
+    tt = W[p + "token_type_embeddings.weight"][0]
+    pos_emb = W[p + "position_embeddings.weight"]
+    lang_vec = None
+    if has_lang:
+        lang_vec = W["lang_embeddings.weight"][int(lang_index)].astype(F32)   # the cancel trick nets out to lang + nothing
+
+    out_cls = np.zeros((n, hdim), dtype=F32)
+    kept_len = keep.sum(axis=1)
+    for k in np.unique(kept_len):                            # L1: dense batches of rows with k kept positions
+        rows = np.nonzero(kept_len == k)[0]
+        m = len(rows)
+        pos = np.stack([np.nonzero(keep[r])[0] for r in rows])          # [m, k] original positions, ascending (0 first)
+        x = table[slot[rows[:, None], pos]] + tt + pos_emb[pos]
+        key_ok = visible[rows[:, None], pos] | all_masked[rows][:, None]
+        if has_lang:                                         # extra token: embedding = lang (+type+pos of slot seq, cancelled)
+            x = np.concatenate([x, np.broadcast_to(lang_vec[None, None, :], (m, 1, hdim))], axis=1)
+            key_ok = np.concatenate([key_ok, np.ones((m, 1), dtype=bool)], axis=1)
+        z = layer_norm(x, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], ROBERTA_LN_EPS)
+        kk = z.shape[1]
+        # a row with every key masked attends uniformly (finfo.min on all keys)
+        bias = np.where(key_ok, F32(0.0), np.finfo(F32).min).astype(F32)[:, None, None, :]
+        for layer in range(layers):
+            last = layer == layers - 1
+            lpfx = f"model.encoder.layer.{layer}."
+            a = lpfx + "attention.self."
+            zq = z[:, :1] if last else z                      # L3: only the CLS query in the last layer
+            q = linear(zq, W[a + "query.weight"], W[a + "query.bias"]).reshape(m, zq.shape[1], heads, d).transpose(0, 2, 1, 3)
+            kx = linear(z, W[a + "key.weight"], W[a + "key.bias"]).reshape(m, kk, heads, d).transpose(0, 2, 1, 3)
+            v = linear(z, W[a + "value.weight"], W[a + "value.bias"]).reshape(m, kk, heads, d).transpose(0, 2, 1, 3)
+            sc = (q @ kx.transpose(0, 1, 3, 2)).astype(F32) * scaling + bias
+            sc = sc - sc.max(axis=-1, keepdims=True)
+            ex = np.exp(sc).astype(F32)
+            prob = ex / ex.sum(axis=-1, keepdims=True, dtype=F32)
+            ctx = (prob @ v).astype(F32).transpose(0, 2, 1, 3).reshape(m, zq.shape[1], hdim)
+            o = lpfx + "attention.output."
+            z1 = layer_norm(linear(ctx, W[o + "dense.weight"], W[o + "dense.bias"]) + zq,
+                            W[o + "LayerNorm.weight"], W[o + "LayerNorm.bias"], ROBERTA_LN_EPS)
+            inter = gelu_erf(linear(z1, W[lpfx + "intermediate.dense.weight"], W[lpfx + "intermediate.dense.bias"]))
+            o = lpfx + "output."
+            z = layer_norm(linear(inter, W[o + "dense.weight"], W[o + "dense.bias"]) + z1,
+                           W[o + "LayerNorm.weight"], W[o + "LayerNorm.bias"], ROBERTA_LN_EPS)
+        out_cls[rows] = z[:, 0]
+    return _heads(W, cfg, out_cls)
+
+
 def flops_per_row(cfg, seq):
     """As-written algorithmic FLOPs per target row (SURVEY.md §8d F_ref)."""
     e = int(_cfg(cfg, "n_embd"))

@@ -58,3 +58,25 @@ def test_retok_keyerror_on_non_byte_char():
     model = retok_ref.model_from_tokenizer_json({"model": g["model"]}, g["special_tokens"], g["special_ids"])
     with pytest.raises(KeyError):
         retok_ref.surface_form_matrix_c(model, ["ok", "not byte level: ▁"], 7, 0)
+
+
+@pytest.mark.parametrize("path", util.golden_cases("fwd_tiny_*.npz") + util.golden_cases("fwd_real_xlmr*.npz"),
+                         ids=lambda p: p.split("/")[-1][:-4])
+def test_exact_levers_equal_as_written(path):
+    """oracle.forward_levers (pad skipping, per-distinct-id input projection, CLS-only last layer —
+    the algebra the HIP path executes) is the same function as the as-written forward:
+    checked on every flag combination, L = 1/15/24, all-pad rows, fallback ids, language token."""
+    from oracle import hypernet_ref
+    case = util.load_case(path)
+    w = synth.make_weights(case["cfg"], case["seed"])
+    src = synth.make_source_embeddings(case["cfg"], case["seed"], dtype=case["src_dtype"])
+    got = hypernet_ref.forward_levers(w, case["cfg"], case["ids"], src, case["lang"])
+    for g, name in zip(got, ("pred_in", "pred_out", "bias")):
+        want = case[name]
+        if want is None:
+            assert g is None
+            continue
+        if name == "bias" and not case["cfg"].get("hn_predict_bias"):
+            assert (g == 0).all()
+            continue
+        np.testing.assert_allclose(g, want, rtol=0, atol=2e-5, err_msg=f"{case['name']} {name}")
