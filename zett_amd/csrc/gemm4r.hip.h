@@ -1,14 +1,15 @@
 // gemm4r.hip.h — 256x256 MFMA GEMM for long K on gfx950: FOUR waves (one per SIMD), each owning a
 // 128x128 quadrant of the tile (4x4 MFMA tiles of 32x32 = 256 accumulator registers; the
 // unified 512-entry register file holds them at one wave per SIMD), operands staged
-// global_load_dwordx4 -> VGPRs -> ds_write_b128.
+// buffer_load_dwordx4 -> VGPRs -> ds_write_b128.
 //
 //   C[M,N] = epilogue( A[M,K] · W[N,K]ᵀ )      (contract and epilogue of gemm.hip.h)
 //
 // Why not LDS-DMA here: a 1 KiB LDS-DMA request blocks the issue port of its SIMD for ~52-60
 // cycles (tools/experiments/gemm4w.hip.h: 16 requests = 830 of the 3040 cycles of a K step; the
 // same total whether eight waves, four waves or dedicated loader waves issue them), which a
-// 32-cycle MFMA cannot cover.  A global_load_dwordx4 and a ds_write_b128 are ordinary issue slots
+// 32-cycle MFMA cannot cover.  A buffer_load_dwordx4 (descriptor and K-step offset in SGPRs, 32-bit
+// lane offset: no vector-ALU address arithmetic) and a ds_write_b128 are ordinary issue slots
 // that fit in the shadow of an MFMA, and with one wave per SIMD there is room for the 64
 // staging registers of a whole K step, so a load has a full K step to land.  A wave also reads
 // a third fewer fragment bytes per MFMA than in gemm256.hip.h (4 A + 4 W for 16 MFMAs).
@@ -35,6 +36,8 @@
 #include "gemm256.hip.h"
 
 namespace zett {
+
+constexpr int G4R_RSRC_WORD3 = 0x00020000;   // raw buffer, DATA_FORMAT_32 (gfx9 resource word 3)
 
 constexpr int G4R_WAIT_LGKM0 = 0xC07F;     // s_waitcnt lgkmcnt(0), vmcnt/expcnt untouched
 
@@ -87,8 +90,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         st_off[par] = row * GEMM_ROW_BYTES + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
     }
     u32x4 ra[8], rw[8];
-    auto load_a = [&](int kt, int j) { ra[j] = *(const u32x4*)(a_base + (size_t)kt * GEMM_ROW_BYTES + a_voff[j]); };
-    auto load_w = [&](int kt, int j) { rw[j] = *(const u32x4*)(w_base + (size_t)kt * GEMM_ROW_BYTES + w_voff[j]); };
+    // buffer loads: resource descriptor of the tile's operand panel in SGPRs, 32-bit lane offset,
+    // K-step offset as the scalar offset operand -> no address arithmetic on the vector ALU
+    // (global_load would re-add the step offset to sixteen 64-bit addresses per K step)
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, (short)0, 0x7fffffff, G4R_RSRC_WORD3);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, (short)0, 0x7fffffff, G4R_RSRC_WORD3);
+    auto load_a = [&](int kt, int j) { ra[j] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[j], kt * GEMM_ROW_BYTES, 0); };
+    auto load_w = [&](int kt, int j) { rw[j] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[j], kt * GEMM_ROW_BYTES, 0); };
     auto store_a = [&](int stage, int j) { *(u32x4*)(smem + stage * G256_STAGE_BYTES + st_off[j & 1] + (j >> 1) * 16 * GEMM_ROW_BYTES) = ra[j]; };
     auto store_w = [&](int stage, int j) { *(u32x4*)(smem + stage * G256_STAGE_BYTES + G256_OPERAND_BYTES + st_off[j & 1] + (j >> 1) * 16 * GEMM_ROW_BYTES) = rw[j]; };
 

@@ -408,7 +408,7 @@ struct Runner {
         }
         // Tile choice.  Small problems: 128x128.  Otherwise a 256x256 tile — the four-wave
         // register-staged kernel when K is long or the epilogue carries the fp32 residual, the
-        // eight-wave LDS-DMA kernel otherwise (tools/gemm_bench: crossover near K = 2500) — unless
+        // eight-wave LDS-DMA kernel otherwise (tools/gemm_bench: crossover near K = 2000) — unless
         // the 384x256 tile needs fewer rounds over the 256 CUs (it runs ~1.55x as long per
         // tile): wave quantisation decides, e.g. M = 5 111 at N = 4096.  The 384-row kernel has no
         // registers to spare for a residual or scale/shift epilogue (168 per wave: it would spill
@@ -420,7 +420,7 @@ struct Runner {
         int variant = h->gemm_variant;
         if (variant == 0) {
             variant = (M > 128 && N > 128) ? 2 : 1;
-            if (variant == 2 && has_4r && (K >= 2560 || (e.residual && K >= 1024))) variant = 4;
+            if (variant == 2 && has_4r && (K >= 2048 || (e.residual && K >= 1024))) variant = 4;
             // (in fp32 mode a tile takes 16x as long and the residual epilogue's spills do not matter)
             if (variant != 1 && N % 256 == 0 && !e.scale && (!e.residual || !has_4r)) {
                 const long t256 = (long)((M + 255) / 256) * (N / 256), t384 = (long)((M + 383) / 384) * (N / 256);
