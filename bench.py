@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="override the vocab size of the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force one GEMM tile variant (zett_set_option gemm_variant); 0 = per-launch choice")
     ap.add_argument("--serial-allgather", action="store_true",
                     help="N > 1: wait for the all-gather of a step before the next forward starts (default: the RCCL "
                          "all-gather of step i runs on its own stream under the forward of step i+1, outputs double-buffered)")
@@ -167,6 +168,8 @@ def main():
     engine = HipEngine(dims, 1e-5, device, args.precision)
     engine.load_weights(weights)
     engine.set_option("time_gemm", 1)
+    if args.gemm_variant:
+        engine.set_option("gemm_variant", args.gemm_variant)
     if rank != 0 or args.no_cpu_baseline or world > 1:
         weights_keep = None
     else:
@@ -274,7 +277,7 @@ def main():
         "metric": "predicted token-embeddings/sec (full target vocab)",
         "value": value, "unit": "token-embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic" + (" [TEST HOOK: all ranks on one device, gloo]" if one_device else ""),
+        "dtype": args.precision, "data": "synthetic" + (" [TEST HOOK: all ranks on one device, gloo]" if one_device else "") + (f" [A/B: gemm_variant {args.gemm_variant} forced]" if args.gemm_variant else ""),
         "config": {"workload": f"{args.workload}: {rows}-row target vocab, hypernet E={dims.n_embd} E_in={dims.n_in_embd} "
                                f"H={dims.hidden} I={dims.intermediate} heads={dims.heads} layers={dims.layers} "
                                f"L={ids_all.shape[1]}, source_embeddings {src_dtype}",

@@ -280,3 +280,23 @@ print("ok")
 """
     out = subprocess.run([sys.executable, "-c", check], check=True, cwd="/tmp", capture_output=True, text=True)
     assert "ok" in out.stdout
+
+
+def test_no_product_kernel_uses_scratch(tmp_path):
+    """Every kernel of libzett_hip.so must fit its registers: a spilled GEMM epilogue once returned wrong
+    tiles on the first launches of a process (gemm384 with a residual epilogue), and scratch reloads
+    sit behind vmcnt(0) waits inside store sequences.  hipcc's resource-usage remarks, device-only
+    compile of the one translation unit."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(REPO, "zett_amd", "csrc", "zett_hip.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only", src,
+                          "-o", str(tmp_path / "z.o"), "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    assert len(names) == len(scratch) and len(names) > 50
+    bad = [(n, s) for n, s in zip(names, scratch) if s]
+    assert not bad, bad

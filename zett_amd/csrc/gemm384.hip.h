@@ -155,7 +155,7 @@ inline hipError_t launch_gemm384_inst(const GemmArgs<T>& g, hipStream_t stream) 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (g.epi.scale || g.epi.shift) return hipErrorInvalidValue;      // register budget: see EpiDrain<..., SCALE = false>
+    if (g.epi.scale || g.epi.shift) return hipErrorInvalidValue;      // register budget: EpiDrain<..., SCALE = false>
     const int tiles_m = (g.M + G384_BM - 1) / G384_BM;
     const int tiles_n = (g.N + G384_BN - 1) / G384_BN;
     if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
@@ -163,9 +163,13 @@ inline hipError_t launch_gemm384_inst(const GemmArgs<T>& g, hipStream_t stream) 
     return hipGetLastError();
 }
 
+// Residual epilogues are refused: at 168 VGPRs per wave the residual drain spills to scratch, and a
+// spilled epilogue of this kernel returned wrong tiles on the first launches of a process (f16,
+// N = 768; tools/gemm_bench STRESS runs) — no instantiation with scratch is ever launched.
 template <typename T, int ACT>
 inline hipError_t launch_gemm384_act(const GemmArgs<T>& g, hipStream_t stream) {
-    return g.epi.residual ? launch_gemm384_inst<T, ACT, true>(g, stream) : launch_gemm384_inst<T, ACT, false>(g, stream);
+    if (g.epi.residual) return hipErrorInvalidValue;
+    return launch_gemm384_inst<T, ACT, false>(g, stream);
 }
 
 template <typename T>

@@ -33,6 +33,7 @@
 #include "gemm256.hip.h"
 #include "gemm384.hip.h"
 #include "gemm4r.hip.h"
+#include "gemm8r.hip.h"
 #include "rowops.hip.h"
 #include "retok.hip.h"
 
@@ -67,7 +68,8 @@ struct zett_hypernet {
     int64_t max_chunk_tokens = 65536;
     int time_gemm = 0;
     int cls_only_last = 1;
-    int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 LDS-DMA, 3 = 384x256 LDS-DMA, 4 = 256x256 four-wave
+    int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
+                                      // 4 = 256x256 register-staged (4 waves), 5 = 256x256 LDS-DMA
     // workspace
     DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct;
     int32_t* host_pinned = nullptr;
@@ -322,7 +324,7 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "cls_only_last_layer") {
         h->cls_only_last = value != 0;
     } else if (k == "gemm_variant") {
-        if (value < 0 || value > 4) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto), 1 (128x128), 2 (256x256), 3 (384x256) or 4 (256x256 four-wave)");
+        if (value < 0 || value > 5) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto) or 1..5 (128x128, 256x256 register-staged, 384x256, 256x256 four-wave, 256x256 LDS-DMA)");
         h->gemm_variant = (int)value;
     } else {
         return fail(ZETT_E_INVALID, "unknown option %s", key);
@@ -406,38 +408,41 @@ struct Runner {
             h->ev_shape.push_back({M, N, K, 0});
             (void)hipEventRecord(e0, st);
         }
-        // Tile choice.  Small problems: 128x128.  Otherwise a 256x256 tile — the four-wave
-        // register-staged kernel when K is long or the epilogue carries the fp32 residual, the
-        // eight-wave LDS-DMA kernel otherwise (tools/gemm_bench: crossover near K = 2000) — unless
-        // the 384x256 tile needs fewer rounds over the 256 CUs (it runs ~1.55x as long per
-        // tile): wave quantisation decides, e.g. M = 5 111 at N = 4096.  The 384-row kernel has no
-        // registers to spare for a residual or scale/shift epilogue (168 per wave: it would spill
-        // into the store sequence) and does not clamp rows, so A must have `a_rows_readable` >=
-        // tiles*384 rows (every A operand here is a workspace buffer with that slack) and N must
-        // be a multiple of 256.  The four-wave kernel exists for the 16-bit operand types only
-        // (fp32 is not staging-bound).
-        constexpr bool has_4r = !std::is_same<T, float>::value;
+        // Tile choice.  Small problems: 128x128.  Otherwise the 256x256 register-staged eight-wave
+        // kernel (gemm8r), unless the 384x256 LDS-DMA tile needs fewer rounds over the 256 CUs (it
+        // runs ~1.7x as long per tile): wave quantisation decides, e.g. M = 5 111 at N = 4096.
+        // The 384-row kernel has no registers to spare for a residual or scale/shift epilogue
+        // (168 per wave: it would spill to scratch, and no kernel with scratch is ever launched)
+        // and does not clamp rows, so A must have
+        // `a_rows_readable` >= tiles*384 rows (every A operand here is a workspace buffer with
+        // that slack) and N must be a multiple of 256.  The four-wave kernel (4, 16-bit types
+        // only) and the LDS-DMA kernel (5) stay selectable: the steps that led to gemm8r, within
+        // 2-12 % of it, bit-identical.
+        constexpr bool is_f32 = std::is_same<T, float>::value;
         int variant = h->gemm_variant;
         if (variant == 0) {
             variant = (M > 128 && N > 128) ? 2 : 1;
-            if (variant == 2 && has_4r && (K >= 2048 || (e.residual && K >= 1024))) variant = 4;
-            // (in fp32 mode a tile takes 16x as long and the residual epilogue's spills do not matter)
-            if (variant != 1 && N % 256 == 0 && !e.scale && (!e.residual || !has_4r)) {
+            if (variant != 1 && N % 256 == 0 && !e.scale && !e.residual) {
                 const long t256 = (long)((M + 255) / 256) * (N / 256), t384 = (long)((M + 383) / 384) * (N / 256);
-                const double c256 = (double)((t256 + 255) / 256), c384 = 1.55 * (double)((t384 + 255) / 256);
+                const double c256 = (double)((t256 + 255) / 256), c384 = 1.7 * (double)((t384 + 255) / 256);
                 if (c384 < c256) variant = 3;
             }
         }
-        if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift)) variant = 2;
+        if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift || e.residual)) variant = 2;
+        if (variant == 4 && is_f32) variant = 2;
         // the large tiles drain eight columns per lane with 16-byte accesses
         const bool wide_ok = N % 8 == 0 && (!e.out_lo || e.ld_lo % 8 == 0) && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0) &&
                              (e.split_col >= N || e.split_col % 8 == 0);
         if (variant != 1 && !wide_ok) variant = 1;
-        if (variant == 4 && !has_4r) variant = 2;
         if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
         hipError_t err;
-        if (variant == 4) err = launch_4r(g, st);
-        else err = variant == 3 ? launch_gemm384<T>(g, st) : variant == 2 ? launch_gemm256<T, 1>(g, st) : launch_gemm<T>(g, st);
+        switch (variant) {
+            case 5: err = launch_gemm256<T, 1>(g, st); break;
+            case 4: err = launch_4r(g, st); break;
+            case 3: err = launch_gemm384<T>(g, st); break;
+            case 2: err = launch_gemm8r<T>(g, st); break;
+            default: err = launch_gemm<T>(g, st); break;
+        }
         if (h->time_gemm) (void)hipEventRecord(e1, st);
         if (err != hipSuccess) { rc = fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(err)); return; }
         h->stats.executed_flops += fl;
@@ -694,7 +699,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 (void)hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]);
                 const auto& sh = h->ev_shape[i / 2];
                 fprintf(stderr, "[zett gemm] M=%6d N=%6d K=%5d tile=%s %8.3f ms %7.1f TF\n", sh[0], sh[1], sh[2],
-                        sh[3] == 4 ? "4r " : sh[3] == 3 ? "384" : sh[3] == 2 ? "256" : "128", t, h->ev_flops[i / 2] / (t * 1e9));
+                        sh[3] == 5 ? "dma" : sh[3] == 4 ? "4r " : sh[3] == 3 ? "384" : sh[3] == 2 ? "8r " : "128", t, h->ev_flops[i / 2] / (t * 1e9));
             }
         }
     }
