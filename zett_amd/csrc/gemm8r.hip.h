@@ -139,20 +139,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if ((q & 1) && more2) load_a(kt + 2, q >> 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // group 1: fragments of kk=2; W rows likewise
+        // group 1: fragments of kk=2; W rows of step kt+1 -> stage cur^1
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             mfma_one(1, q);
             if (q < 6) read_frag(cur, 2, 0, q);
             if ((q & 1) && more) store_w(cur ^ 1, q >> 1);
-            if ((q & 1) && more2) load_w(kt + 2, q >> 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // group 2: fragments of kk=3
+        // group 2: fragments of kk=3; the W staging registers are reloaded with step kt+2
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             mfma_one(0, q);
             if (q < 6) read_frag(cur, 3, 1, q);
+            if ((q & 1) && more2) load_w(kt + 2, q >> 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         // every read of stage cur and every write of stage cur^1 by this wave is complete
