@@ -260,7 +260,7 @@ def main():
     peak = PEAK_TFLOPS[args.precision]
 
     # HBM traffic of the dominant kernel comes from PMC counters, which cannot be read from inside this
-    # process: the figure is the one measured by the committed rocprofv3 passes (profiles/r1d_pmc.md,
+    # process: the figure is the one measured by the committed rocprofv3 passes (profiles/r1e_pmc.md,
     # tools/pmc_summary.py --json) for this same command, and only quoted for the workload it was taken on.
     traffic = None
     try:
@@ -286,7 +286,7 @@ def main():
                    "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"]},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak if peak else None, "traffic": traffic,
-                     "kernel": "zett::gemm4r_tn_kernel (256x256 four-wave register-staged MFMA GEMM; 16-bit modes, long K) with the gemm256/gemm384/gemm tile variants for short K, fp32 and small shapes: all GEMM launches, FLOP-weighted", "launches_per_step": launches / max(args.steps, 1),
+                     "kernel": "zett::gemm8r_tn_kernel (256x256 register-staged MFMA GEMM) with the 384x256 and 128x128 tile variants where wave quantisation / small shapes call for them: all GEMM launches, FLOP-weighted", "launches_per_step": launches / max(args.steps, 1),
                      "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
                      "executed_tflop_per_step": gemm_fl / max(args.steps, 1) / 1e12},
         "as_written_tflops": rows * f_ref * args.steps / dt / 1e12,
