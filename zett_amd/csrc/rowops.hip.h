@@ -219,17 +219,21 @@ struct LnEmbed {
 
 constexpr int LN_MAX_VEC = 8;   // 8 float4 x 256 threads = 8192 columns in registers
 
-template <typename T, bool EMBED>
+// TPR = threads per row: 256 (one workgroup per row, two LDS reductions) for wide rows, 64 (one wave per
+// row, four rows per workgroup, shuffle reductions only) for H <= 2048, where a 256-thread group would
+// leave lanes idle and spend its time in the two barriers.
+template <typename T, bool EMBED, int TPR = 256>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ in, int ld_in, int rows, int H,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps,
                                                              float* __restrict__ out_f32, T* __restrict__ out_lo,
                                                              LnEmbed emb, int tok0) {
     __shared__ float red[4];
-    const int r = blockIdx.x;
-    if (r >= rows) return;
+    const int r = blockIdx.x * (256 / TPR) + (int)threadIdx.x / TPR;
+    if (r >= rows) return;                 // TPR = 64: whole waves leave, and no barrier follows
     const int nvec = H >> 2;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x % TPR;
+    auto row_sum = [&](float x_) { return TPR == 256 ? block_sum_256(x_, red) : wave_sum(x_); };
     const float* x = nullptr;
     const float* posr = nullptr;
     bool is_lang = false;
@@ -258,26 +262,26 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAX_VEC; ++j) {
-        const int idx = tid + 256 * j;
+        const int idx = tid + TPR * j;
         if (idx < nvec) { v[j] = load(idx); s += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
     }
-    for (int idx = tid + 256 * LN_MAX_VEC; idx < nvec; idx += 256) { const float4 a = load(idx); s += (a.x + a.y) + (a.z + a.w); }
-    const float mean = block_sum_256(s, red) / (float)H;
+    for (int idx = tid + TPR * LN_MAX_VEC; idx < nvec; idx += TPR) { const float4 a = load(idx); s += (a.x + a.y) + (a.z + a.w); }
+    const float mean = row_sum(s) / (float)H;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAX_VEC; ++j) {
-        const int idx = tid + 256 * j;
+        const int idx = tid + TPR * j;
         if (idx < nvec) {
             const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
             q += (a * a + b * b) + (c * c + d * d);
         }
     }
-    for (int idx = tid + 256 * LN_MAX_VEC; idx < nvec; idx += 256) {
+    for (int idx = tid + TPR * LN_MAX_VEC; idx < nvec; idx += TPR) {
         const float4 t = load(idx);
         const float a = t.x - mean, b = t.y - mean, c = t.z - mean, d = t.w - mean;
         q += (a * a + b * b) + (c * c + d * d);
     }
-    const float var = block_sum_256(q, red) / (float)H;
+    const float var = row_sum(q) / (float)H;
     const float rstd = 1.0f / sqrtf(var + eps);
     auto emit = [&](int idx, float4 a) {
         const float4 g = *(const float4*)(gamma + idx * 4), b = *(const float4*)(beta + idx * 4);
@@ -289,10 +293,10 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     };
 #pragma unroll
     for (int j = 0; j < LN_MAX_VEC; ++j) {
-        const int idx = tid + 256 * j;
+        const int idx = tid + TPR * j;
         if (idx < nvec) emit(idx, v[j]);
     }
-    for (int idx = tid + 256 * LN_MAX_VEC; idx < nvec; idx += 256) emit(idx, load(idx));
+    for (int idx = tid + TPR * LN_MAX_VEC; idx < nvec; idx += TPR) emit(idx, load(idx));
 }
 
 // ---------------------------------------------------------------------------

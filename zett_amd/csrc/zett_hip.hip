@@ -457,8 +457,12 @@ struct Runner {
 
     void layernorm(const float* in, int rows, const float* gamma, const float* beta, float eps, float* of, T* ol) {
         if (rc || rows <= 0) return;
-        hipLaunchKernelGGL((layernorm_rows_kernel<T, false>), dim3(rows), dim3(256), 0, st, in, h->cfg.hidden, rows,
-                           h->cfg.hidden, gamma, beta, eps, of, ol, LnEmbed{}, 0);
+        if (h->cfg.hidden <= 2048)       // a wave per row, four rows per workgroup
+            hipLaunchKernelGGL((layernorm_rows_kernel<T, false, 64>), dim3((rows + 3) / 4), dim3(256), 0, st, in, h->cfg.hidden, rows,
+                               h->cfg.hidden, gamma, beta, eps, of, ol, LnEmbed{}, 0);
+        else
+            hipLaunchKernelGGL((layernorm_rows_kernel<T, false, 256>), dim3(rows), dim3(256), 0, st, in, h->cfg.hidden, rows,
+                               h->cfg.hidden, gamma, beta, eps, of, ol, LnEmbed{}, 0);
         check("layernorm");
     }
 
@@ -606,9 +610,14 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
 
         LnEmbed emb{TBL, p.tok_slot, p.tok_pos, R.Wf("model.embeddings.token_type_embeddings.weight"),
                     R.Wf("model.embeddings.position_embeddings.weight"), lang_vec, seq};
-        hipLaunchKernelGGL((layernorm_rows_kernel<T, true>), dim3(m), dim3(256), 0, st, (const float*)nullptr, H, m, H,
-                           R.Wf("model.embeddings.LayerNorm.weight"), R.Wf("model.embeddings.LayerNorm.bias"),
-                           c.ln_eps_encoder, Zf, Zt, emb, tok0);
+        if (H <= 2048)
+            hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 64>), dim3((m + 3) / 4), dim3(256), 0, st, (const float*)nullptr, H, m, H,
+                               R.Wf("model.embeddings.LayerNorm.weight"), R.Wf("model.embeddings.LayerNorm.bias"),
+                               c.ln_eps_encoder, Zf, Zt, emb, tok0);
+        else
+            hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 256>), dim3(m), dim3(256), 0, st, (const float*)nullptr, H, m, H,
+                               R.Wf("model.embeddings.LayerNorm.weight"), R.Wf("model.embeddings.LayerNorm.bias"),
+                               c.ln_eps_encoder, Zf, Zt, emb, tok0);
         R.check("embed_layernorm");
 
         int zrows = m;            // rows of the current hidden state (m packed, or `rows` once compact)
