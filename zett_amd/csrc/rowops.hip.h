@@ -358,19 +358,8 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
     for (int qi = 0; qi < nq; ++qi) {
         float q[8];
         load8<T>(qkv + (size_t)(t0 + qi) * ld + ccol, q);
-        float mx = -INFINITY;
-        for (int kj = t0; kj < t1; ++kj) {
-            if (!uniform && !tok_key[tok0 + kj]) continue;
-            float k[8];
-            load8<T>(qkv + (size_t)kj * ld + H + ccol, k);
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) s = fmaf(q[c], k[c], s);
-            for (int off = 1; off < lph; off <<= 1) s += __shfl_xor(s, off, 64);
-            s = uniform ? 0.f : s * scaling;
-            mx = fmaxf(mx, s);
-        }
-        float l = 0.f, acc[8];
+        // one pass over the keys with a running maximum (online softmax): K and V are read once
+        float mx = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = 0.f;
         for (int kj = t0; kj < t1; ++kj) {
@@ -383,10 +372,13 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
             for (int c = 0; c < 8; ++c) s = fmaf(q[c], k[c], s);
             for (int off = 1; off < lph; off <<= 1) s += __shfl_xor(s, off, 64);
             s = uniform ? 0.f : s * scaling;
-            const float p = expf(s - mx);
-            l += p;
+            const float nm = fmaxf(mx, s);
+            const float corr = expf(mx - nm);          // first key: exp(-inf) = 0 on an all-zero state
+            const float p = expf(s - nm);
+            l = fmaf(l, corr, p);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = fmaf(p, v[c], acc[c]);
+            for (int c = 0; c < 8; ++c) acc[c] = fmaf(acc[c], corr, p * v[c]);
+            mx = nm;
         }
         const float inv = 1.0f / l;
 #pragma unroll
