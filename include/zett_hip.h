@@ -129,7 +129,8 @@ int zett_get_stats(const zett_hypernet* h, zett_stats* out);
  * GEMM launch with HIP events on the launch stream and report the sum in
  * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "gemm_variant"
  * (0 = choose per launch, 1 = 128x128, 2 = 256x256 register-staged eight-wave,
- * 3 = 384x256 LDS-DMA, 4 = 256x256 register-staged four-wave, 5 = 256x256 LDS-DMA;
+ * 3 = 384x256 LDS-DMA, 4 = 256x256 register-staged four-wave, 5 = 256x256 LDS-DMA,
+ * 6 = as 2 on 16x16x32 MFMAs;
  * all produce identical bits; a forced
  * variant falls back to 2 where its preconditions do not hold). */
 int zett_set_option(zett_hypernet* h, const char* key, int64_t value);

@@ -34,6 +34,7 @@
 #include "gemm384.hip.h"
 #include "gemm4r.hip.h"
 #include "gemm8r.hip.h"
+#include "gemm8x.hip.h"
 #include "rowops.hip.h"
 #include "retok.hip.h"
 
@@ -69,7 +70,7 @@ struct zett_hypernet {
     int time_gemm = 0;
     int cls_only_last = 1;
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
-                                      // 4 = 256x256 register-staged (4 waves), 5 = 256x256 LDS-DMA
+                                      // 4 = 256x256 register-staged (4 waves), 5 = 256x256 LDS-DMA, 6 = as 2 on 16x16x32 MFMAs
     // workspace
     DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct;
     int32_t* host_pinned = nullptr;
@@ -324,7 +325,7 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "cls_only_last_layer") {
         h->cls_only_last = value != 0;
     } else if (k == "gemm_variant") {
-        if (value < 0 || value > 5) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto) or 1..5 (128x128, 256x256 register-staged, 384x256, 256x256 four-wave, 256x256 LDS-DMA)");
+        if (value < 0 || value > 6) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto) or 1..6 (128x128, 256x256 register-staged, 384x256, 256x256 four-wave, 256x256 LDS-DMA, 256x256 register-staged on 16x16x32 MFMAs)");
         h->gemm_variant = (int)value;
     } else {
         return fail(ZETT_E_INVALID, "unknown option %s", key);
@@ -386,6 +387,11 @@ struct Runner {
 
     long a_rows_readable = 0;   // rows every A operand buffer can be read for (workspace slack)
 
+    static hipError_t launch_16(const GemmArgs<T>& g, hipStream_t s) {
+        if constexpr (std::is_same<T, float>::value) return hipErrorInvalidValue;
+        else return launch_gemm8x<T>(g, s);
+    }
+
     static hipError_t launch_4r(const GemmArgs<T>& g, hipStream_t s) {
         if constexpr (std::is_same<T, float>::value) return hipErrorInvalidValue;
         else return launch_gemm4r<T>(g, s);
@@ -429,7 +435,10 @@ struct Runner {
             }
         }
         if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift || e.residual)) variant = 2;
-        if (variant == 4 && is_f32) variant = 2;
+        // long K without a residual: the same kernel on 16x16x32 MFMAs (less accumulator traffic per FLOP
+        // inside the power envelope: +3-6 %; identical bits)
+        if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= 2048 && !e.residual) variant = 6;
+        if ((variant == 4 || variant == 6) && is_f32) variant = 2;
         // the large tiles drain eight columns per lane with 16-byte accesses
         const bool wide_ok = N % 8 == 0 && (!e.out_lo || e.ld_lo % 8 == 0) && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0) &&
                              (e.split_col >= N || e.split_col % 8 == 0);
@@ -437,6 +446,7 @@ struct Runner {
         if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
         hipError_t err;
         switch (variant) {
+            case 6: err = launch_16(g, st); break;
             case 5: err = launch_gemm256<T, 1>(g, st); break;
             case 4: err = launch_4r(g, st); break;
             case 3: err = launch_gemm384<T>(g, st); break;
@@ -708,7 +718,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 (void)hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]);
                 const auto& sh = h->ev_shape[i / 2];
                 fprintf(stderr, "[zett gemm] M=%6d N=%6d K=%5d tile=%s %8.3f ms %7.1f TF\n", sh[0], sh[1], sh[2],
-                        sh[3] == 5 ? "dma" : sh[3] == 4 ? "4r " : sh[3] == 3 ? "384" : sh[3] == 2 ? "8r " : "128", t, h->ev_flops[i / 2] / (t * 1e9));
+                        sh[3] == 6 ? "8x " : sh[3] == 5 ? "dma" : sh[3] == 4 ? "4r " : sh[3] == 3 ? "384" : sh[3] == 2 ? "8r " : "128", t, h->ev_flops[i / 2] / (t * 1e9));
             }
         }
     }
