@@ -4,8 +4,8 @@
 // Why: a register-only loop of the 16x16x32 shape sustains 2.2 PFLOP/s inside the chip's power envelope
 // against 1.97 for 32x32x16 on the same random operands (tools/experiments/mfma_power.hip) — half the
 // accumulator traffic per FLOP — and the GEMM is power-limited.  In the full kernel that is
-// +3 % at K = 4096..8192 and +6 % at 8192^3, and -4 % at K = 1024 (more, shorter MFMA groups around the
-// barrier), so the caller takes it for K >= 2048 without a residual epilogue.
+// +2 % at K = 4096..8192 and +4 % at 8192^3, and -1..-4 % at K <= 2048 (more, shorter MFMA groups around the
+// barrier), so the caller takes it for K >= 4096 without a residual epilogue.
 //
 // Both MFMA shapes accumulate the K products in ascending K order inside one fp32 chain, so this kernel
 // returns the same bits as the 32x32x16 kernels (tile-variant test, fp32 outputs included).
@@ -13,7 +13,7 @@
 // K step of a wave: 2 K blocks (32 wide) x 4 sub-blocks; a sub-block is 8 MFMAs on the A fragments of two
 // 16-row tiles and the four W fragments of the K block.  A pairs are double-buffered, the W set of the other
 // K block is read under the current one, the staging traffic of the next steps rides in sub-blocks 0-5,
-// the barrier sits before the last sub-block, which reads the first fragments of the next step.
+// the barrier sits before the last two sub-blocks, which read the first fragments of the next step.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // a K step = 2 K blocks x 4 sub-blocks; sub-block sb uses the A fragments of row tiles 2s, 2s+1 (s = sb & 3) and the
     // four W fragments of its K block: 8 MFMAs.  A pairs are double-buffered, W sets alternate per K block.
-    u32x4 fa[2][2], fw[2][4];
+    u32x4 fa[3][2], fw[2][4];     // A pair of sub-block sb lives in set sb % 3 (three sets: the pairs of the last two
+                                  // sub-blocks are both read before the barrier)
     auto read_a = [&](int stage, int sb, int set, int h) {
         fa[set][h] = *(const u32x4*)(smem + stage * G256_STAGE_BYTES + a_off[sb >> 2] + (2 * (sb & 3) + h) * 16 * GEMM_ROW_BYTES);
     };
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto mfma_one = [&](int sb, int m) {                     // m = 0..7: A fragment m >> 2 of the pair, W fragment m & 3
         const int i = 2 * (sb & 3) + (m >> 2), j = m & 3;
-        acc[i][j] = mfma16_kb<T>(fa[sb & 1][m >> 2], fw[sb >> 2][j], acc[i][j]);
+        acc[i][j] = mfma16_kb<T>(fa[sb % 3][m >> 2], fw[sb >> 2][j], acc[i][j]);
     };
 
     const int nk = g.K / BK;
@@ -147,10 +148,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
         const int cur = kt & 1;
         // eight sub-blocks of 8 MFMAs, one MFMA per scheduling region.  Fillers: the A pair of the next sub-block
-        // (2 reads), one W fragment of the other K block, and the staging traffic of the next steps.
+        // (2 reads), one W fragment of the other K block, and the staging traffic of the next steps.  The barrier
+        // sits before sub-block 6: sub-blocks 6 and 7 (16 MFMAs) cover the first fragment reads of step kt+1.
 #pragma unroll
         for (int sb = 0; sb < 8; ++sb) {
-            if (sb == 7) {
+            if (sb == 6) {
                 // every read of stage cur and every write of stage cur^1 by this wave is complete
                 __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
                 __builtin_amdgcn_s_barrier();
@@ -159,9 +161,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 mfma_one(sb, m);
-                if (sb < 7) {
-                    if (m == 0) read_a(cur, sb + 1, (sb + 1) & 1, 0);
-                    if (m == 1) read_a(cur, sb + 1, (sb + 1) & 1, 1);
+                if (sb < 5) {
+                    if (m == 0) read_a(cur, sb + 1, (sb + 1) % 3, 0);
+                    if (m == 1) read_a(cur, sb + 1, (sb + 1) % 3, 1);
                     if (sb < 4 && m == 2) read_w(cur, 1, sb);                        // W fragments of K block 1
                     if (sb == 0 && (m == 4 || m == 6) && more) store_a(cur ^ 1, (m - 4) >> 1);
                     if (sb == 1 && (m == 4 || m == 6) && more) store_a(cur ^ 1, 2 + ((m - 4) >> 1));
@@ -170,11 +172,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (sb == 2 && (m == 4 || m == 6) && more) store_w(cur ^ 1, (m - 4) >> 1);
                     if (sb == 3 && (m == 4 || m == 6) && more) store_w(cur ^ 1, 2 + ((m - 4) >> 1));
                     if (sb == 4 && (m == 4 || m == 6) && more2) load_w(kt + 2, (m - 4) >> 1);
-                    if (sb == 5 && (m == 4 || m == 6) && more2) load_w(kt + 2, 2 + ((m - 4) >> 1));
-                } else if (more) {                              // first fragments of step kt+1
-                    if (m < 4) read_w(cur ^ 1, 0, m);
-                    if (m == 4) read_a(cur ^ 1, 0, 0, 0);
-                    if (m == 5) read_a(cur ^ 1, 0, 0, 1);
+                } else if (sb == 5) {                               // pairs of sub-blocks 6 and 7
+                    if (m == 0) read_a(cur, 6, 0, 0);
+                    if (m == 1) read_a(cur, 6, 0, 1);
+                    if (m == 2) read_a(cur, 7, 1, 0);
+                    if (m == 3) read_a(cur, 7, 1, 1);
+                    if ((m == 4 || m == 6) && more2) load_w(kt + 2, 2 + ((m - 4) >> 1));
+                } else if (more) {                                  // first fragments of step kt+1
+                    if (sb == 6 && m < 4) read_w(cur ^ 1, 0, m);
+                    if (sb == 7 && m == 0) read_a(cur ^ 1, 0, 0, 0);
+                    if (sb == 7 && m == 1) read_a(cur ^ 1, 0, 0, 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -437,7 +437,7 @@ struct Runner {
         if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift || e.residual)) variant = 2;
         // long K without a residual: the same kernel on 16x16x32 MFMAs (less accumulator traffic per FLOP
         // inside the power envelope: +3-6 %; identical bits)
-        if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= 2048 && !e.residual) variant = 6;
+        if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= 4096 && !e.residual) variant = 6;
         if ((variant == 4 || variant == 6) && is_f32) variant = 2;
         // the large tiles drain eight columns per lane with 16-byte accesses
         const bool wide_ok = N % 8 == 0 && (!e.out_lo || e.ld_lo % 8 == 0) && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0) &&
