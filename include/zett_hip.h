@@ -125,7 +125,7 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
 
 int zett_get_stats(const zett_hypernet* h, zett_stats* out);
 
-/* Options: "max_chunk_tokens" (default 65536), "time_gemm" (0/1: bracket every
+/* Options: "max_chunk_tokens" (default 131072), "time_gemm" (0/1: bracket every
  * GEMM launch with HIP events on the launch stream and report the sum in
  * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "gemm_variant"
  * (0 = choose per launch, 1 = 128x128, 2 = 256x256 register-staged eight-wave,

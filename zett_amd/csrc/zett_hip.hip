@@ -66,7 +66,7 @@ struct zett_hypernet {
     float* head_shift = nullptr;
     std::vector<void*> owned;         // everything to hipFree at destroy
     // options
-    int64_t max_chunk_tokens = 65536;
+    int64_t max_chunk_tokens = 131072;     // ~90 KB of workspace per packed position at H = 4096: 11.8 GB per chunk
     int time_gemm = 0;
     int cls_only_last = 1;
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
