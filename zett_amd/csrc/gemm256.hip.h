@@ -67,7 +67,8 @@ template <> __device__ __forceinline__ void store_out8<f16_t>(f16_t* dst, float4
 // every earlier store to be acknowledged — one full write latency per row group, which the
 // first version of this epilogue paid (11 us per tile).
 // SCALE = false: the caller guarantees epi.scale == nullptr (saves the 16 scale/shift registers).
-template <typename T, int ACT, bool RES, int ROWS, int COLS, bool SCALE = true>
+// NTF32 = false: never use the non-temporal store path (callers whose register budget is exhausted).
+template <typename T, int ACT, bool RES, int ROWS, int COLS, bool SCALE = true, bool NTF32 = true>
 struct EpiDrain {
     static constexpr int LPR = COLS / 8;       // lanes per row
     static constexpr int RPI = 64 / LPR;       // rows per wave instruction
@@ -91,6 +92,9 @@ struct EpiDrain {
         const int idx = lane % LPR;
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool has_scale = SCALE && e.scale != nullptr;
+        // non-temporal fp32 stores for the residual epilogue of long-K launches (+3..6 % there: tools/gemm_bench
+        // EPI=2; at K = 1024, where a CU is in an epilogue a third of the time, they cost 12 %)
+        const bool nt_f32 = NTF32 && RES && g.K >= 2048;
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
             const int lrow = t * RPI + lane / LPR;
@@ -106,7 +110,18 @@ struct EpiDrain {
             const int grow = row0 + t * RPI + lane / LPR;
             if (grow >= g.M || !col_ok) continue;
             if (gcol < e.split_col) {
-                if (e.out_f32) { float* d = e.out_f32 + (size_t)grow * e.ld_f32 + gcol; *(float4*)d = oa[t]; *(float4*)(d + 4) = ob[t]; }
+                if (e.out_f32) {
+                    float* d = e.out_f32 + (size_t)grow * e.ld_f32 + gcol;
+                    if (nt_f32) {      // streamed once to the LayerNorm kernel: keep it out of the L2 the operand panels live in
+                        // (inline asm: two IR stores that differ only in the nontemporal hint get merged into a plain one)
+                        const f32x4 va = {oa[t].x, oa[t].y, oa[t].z, oa[t].w}, vb = {ob[t].x, ob[t].y, ob[t].z, ob[t].w};
+                        asm volatile("global_store_dwordx4 %0, %1, off nt\n\tglobal_store_dwordx4 %0, %2, off offset:16 nt"
+                                     :: "v"(d), "v"(va), "v"(vb) : "memory");
+                    } else {
+                        *(float4*)d = oa[t];
+                        *(float4*)(d + 4) = ob[t];
+                    }
+                }
                 if (e.out_lo) store_out8<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, oa[t], ob[t]);
             } else if (e.out_f32_b) {
                 float* d = e.out_f32_b + (size_t)grow * e.ld_f32 + (gcol - e.split_col);

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (64 rows x 128 fp32), two passes, drained by EpiDrain (gemm256.hip.h).
     __syncthreads();
     float* region = (float*)(smem + wave * 32768);
-    typedef EpiDrain<T, ACT, RES, 64, 128> Drain;
+    typedef EpiDrain<T, ACT, RES, 64, 128, true, false> Drain;      // 256 + 256 registers are all in use: no second store path
     const int gcol = n0 + wn * 128 + (lane % Drain::LPR) * 8;
     const bool col_ok = gcol < g.N;
     float4 bias8[2], sc8[2], sh8[2];
