@@ -115,7 +115,9 @@ struct EpiDrain {
                     if (nt_f32) {      // streamed once to the LayerNorm kernel: keep it out of the L2 the operand panels live in
                         // (inline asm: two IR stores that differ only in the nontemporal hint get merged into a plain one)
                         const f32x4 va = {oa[t].x, oa[t].y, oa[t].z, oa[t].w}, vb = {ob[t].x, ob[t].y, ob[t].z, ob[t].w};
-                        asm volatile("global_store_dwordx4 %0, %1, off nt\n\tglobal_store_dwordx4 %0, %2, off offset:16 nt"
+                        // (s_nop 1: the two wait states hipcc itself leaves between a >8-byte store and a VALU write
+                        //  of its data registers; it does not know this block is a store)
+                        asm volatile("global_store_dwordx4 %0, %1, off nt\n\tglobal_store_dwordx4 %0, %2, off offset:16 nt\n\ts_nop 1"
                                      :: "v"(d), "v"(va), "v"(vb) : "memory");
                     } else {
                         *(float4*)d = oa[t];
