@@ -1,4 +1,6 @@
-// gemm256.hip.h — the large-tile MFMA GEMM for gfx950: 256x256 output tile, 8 waves,
+// gemm256.hip.h — the LDS-DMA 256x256 MFMA GEMM for gfx950 (tile variant 5: the round's first large-tile
+// kernel, since superseded as the default by the register-staged gemm8r.hip.h / gemm8x.hip.h, which are
+// 7-11 % faster) and the epilogue drain shared by every large tile (EpiDrain).  256x256 output tile, 8 waves,
 // K staged 128 bytes per row and step straight from HBM/L2 into LDS by the LDS-DMA path
 // (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass), two LDS stages of
 // 64 KiB so the DMA of K-step t+1 runs under the MFMAs of K-step t, one barrier per step.
@@ -144,7 +146,7 @@ struct EpiDrain {
 };
 
 // VAR (experiments, tools/gemm_bench): bit 0 = spread the DMA issue over the 4 K chunks of a step,
-// bit 1 = s_setprio(1) around the MFMA groups.  The product uses VAR = 0.
+// bit 1 = s_setprio(1) around the MFMA groups.  The library instantiates VAR = 1.
 template <typename T, int VAR = 0, int ACT = ACT_NONE, bool RES = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm256_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
