@@ -94,6 +94,66 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int32_t* __r
     if (t == 1023) out[n] = part[1023];
 }
 
+// Multi-block exclusive scan for the plan arrays (V can be 250 k source ids, N 262 k rows: the single
+// workgroup above takes 75-400 us on those).  Chunks of SCAN_CHUNK elements:
+//   (1) scan_chunk_sums_kernel: sums[c] = sum of chunk c;
+//   (2) exclusive_scan_kernel on sums (a few hundred entries) -> offs[c], offs[chunks] = total;
+//   (3) scan_apply_kernel: out[i] = offs[c] + exclusive scan inside the chunk; out[n] = total.
+constexpr int SCAN_CHUNK = 4096;          // 256 threads x 16 elements
+
+__device__ __forceinline__ int32_t block_exclusive_scan_256(int32_t v, int32_t* sh /* [256] */, int32_t* total) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int32_t add = (t >= off) ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    if (total) *total = sh[255];
+    return sh[t] - v;
+}
+
+__global__ __launch_bounds__(256) void scan_chunk_sums_kernel(const int32_t* __restrict__ in, int64_t n, int32_t* __restrict__ sums) {
+    __shared__ int32_t sh[256];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x * 16;
+    int32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int64_t i = base + k; if (i < n) s += in[i]; }
+    int32_t total;
+    block_exclusive_scan_256(s, sh, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ offs,
+                                                         int32_t* __restrict__ out) {
+    __shared__ int32_t sh[256];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x * 16;
+    int32_t v[16];
+    int32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int64_t i = base + k; v[k] = i < n ? in[i] : 0; s += v[k]; }
+    int32_t run = offs[blockIdx.x] + block_exclusive_scan_256(s, sh, nullptr);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int64_t i = base + k; if (i < n) out[i] = run; run += v[k]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = offs[gridDim.x];
+}
+
+// out[0..n] = exclusive scan of in[0..n) (out[n] = total); scratch: 2*chunks + 1 ints
+inline void launch_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* scratch, hipStream_t st) {
+    if (n <= SCAN_CHUNK * 4) {        // small: one workgroup does it in one launch
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, in, out, n);
+        return;
+    }
+    const int chunks = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    int32_t* sums = scratch;
+    int32_t* offs = scratch + chunks;
+    hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(chunks), dim3(256), 0, st, in, n, sums);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)sums, offs, (int64_t)chunks);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(chunks), dim3(256), 0, st, in, n, (const int32_t*)offs, out);
+}
+
 __global__ void plan_tokens_kernel(const int32_t* __restrict__ sfm, int64_t n_rows, int seq, int pad, int lam,
                                    PlanArrays p) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -514,8 +514,9 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     h->ev_shape.clear();
 
     // ---- plan ---------------------------------------------------------------------
-    // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] err[1]
-    const size_t n_i32 = (size_t)N + (N + 1) + V + (V + 1) + V + 2 * (size_t)max_tok + 1;
+    // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] err[1] scan scratch
+    const size_t scan_scratch = 2 * ((size_t)std::max<int64_t>(N, V) / SCAN_CHUNK + 2) + 1;
+    const size_t n_i32 = (size_t)N + (N + 1) + V + (V + 1) + V + 2 * (size_t)max_tok + 1 + scan_scratch;
     if (int rc = h->plan_i32.reserve(n_i32 * 4)) return rc;
     if (int rc = h->plan_u8.reserve((size_t)N + (size_t)max_tok)) return rc;
     PlanArrays p{};
@@ -527,15 +528,16 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     p.id_list = base; base += V;
     p.tok_slot = base; base += max_tok;
     p.tok_pos = base; base += max_tok;
-    p.err = base;
+    p.err = base; base += 1;
+    int32_t* scan_tmp = base;
     p.row_uniform = h->plan_u8.as<uint8_t>();
     p.tok_key = p.row_uniform + N;
     HIP_TRY(hipMemsetAsync(p.id_flag, 0, (size_t)V * 4, st));
     HIP_TRY(hipMemsetAsync(p.err, 0, 4, st));
     const int rb = (int)((N + 255) / 256);
     hipLaunchKernelGGL(plan_rows_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, p.row_count, p.row_offset, N);
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, p.id_flag, p.id_slot, (int64_t)V);
+    launch_exclusive_scan(p.row_count, p.row_offset, N, scan_tmp, st);
+    launch_exclusive_scan(p.id_flag, p.id_slot, (int64_t)V, scan_tmp, st);
     hipLaunchKernelGGL(plan_tokens_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, p);
     hipLaunchKernelGGL(plan_idlist_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, p);
     HIP_TRY(hipGetLastError());
