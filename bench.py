@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--max-chunk-tokens", type=int, default=0, help="A/B only: zett_set_option max_chunk_tokens (0 = library default)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force one GEMM tile variant (zett_set_option gemm_variant); 0 = per-launch choice")
+    ap.add_argument("--no-retokenize", action="store_true", help="A/B only: start every step from the id matrix instead of the surface forms")
     ap.add_argument("--serial-allgather", action="store_true",
                     help="N > 1: wait for the all-gather of a step before the next forward starts (default: the RCCL "
                          "all-gather of step i runs on its own stream under the forward of step i+1, outputs double-buffered)")
@@ -182,6 +183,20 @@ def main():
     ids_all = synth.make_surface_forms(cfg, rows, seed=0, hist=hist)
     lo, hi = shard_bounds(rows, world, rank)
     ids = torch.from_numpy(ids_all[lo:hi]).to(device)
+    # The step starts from SURFACE FORMS: the byte-level strings of this rank's target tokens and the tables of a
+    # synthetic hn tokenizer (Unigram, one 3-byte piece per source id) are resident on the device; every step
+    # retokenizes them on the GPU (zett_retokenize: byte table, Viterbi) into the [rows, L] id matrix the forward
+    # consumes.  The strings are built so that this matrix is exactly `ids` (checked below, untimed).
+    retok = None
+    if not args.no_retokenize:
+        from zett_amd.surface_forms import DeviceRetokenizer, HnTokenizerSpec
+        spec = HnTokenizerSpec.from_model_json(synth.make_hn_unigram_model(cfg), ["<unk>", "<s>", "</s>"], [0, 1, 2], dims.pad_token_id)
+        retok = DeviceRetokenizer(spec, device)
+        d_text, d_off, n_tok = retok.encode(synth.tokens_for_surface_forms(cfg, ids_all[lo:hi]))
+        seq_len = int(ids_all.shape[1])
+        sfm0, n_trunc0 = retok.run(d_text, d_off, n_tok, seq_len)
+        if n_trunc0 != 0 or not torch.equal(sfm0, ids):
+            raise SystemExit("the retokenized surface forms differ from the workload's id matrix")
     src = torch.from_numpy(synth.make_source_embeddings(cfg, seed=0, dtype=src_dtype)).to(device)
     per = shard_bounds(rows, world, 0)[1]      # rows of the largest shard (all-gather pads to it)
 
@@ -202,7 +217,8 @@ def main():
         return tuple(None if f is None else f[:rows] for f in entry[0])
 
     def step():
-        o_in, o_out, o_bias = engine.forward(ids, src, -1 if lang is None else lang)
+        sfm = ids if retok is None else retok.run(d_text, d_off, n_tok, seq_len)[0]
+        o_in, o_out, o_bias = engine.forward(sfm, src, -1 if lang is None else lang)
         if world == 1:
             return o_in, o_out, o_bias
         fulls, works, keep = [], [], []
@@ -251,7 +267,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # untimed: the gathered matrix must hold this rank's rows bit for bit (rows are shard-independent)
-        chk = engine.forward(ids, src, -1 if lang is None else lang)
+        chk = engine.forward(ids, src, -1 if lang is None else lang)          # `ids` == the retokenized matrix (checked above)
         for full, loc in zip(out, chk):
             if full is not None and not torch.equal(full[lo:hi], loc):
                 raise SystemExit(f"rank {rank}: all-gathered rows [{lo}, {hi}) differ from the local forward")
@@ -286,7 +302,9 @@ def main():
                                f"L={ids_all.shape[1]}, source_embeddings {src_dtype}",
                    "rows": rows, "rows_per_gpu": hi - lo, "parallelism": f"vocab-row shards x{world} + RCCL all-gather" + ("" if world == 1 else (" (after each forward)" if args.serial_allgather else " (step i's gather on the RCCL stream under the forward of step i+1; last one inside the timed region)")),
                    "precision": f"{args.precision} MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision != "f32" else "fp32 MFMA",
-                   "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"]},
+                   "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"],
+                   "step": ("surface forms (byte strings resident on the device) -> GPU retokenization -> hypernet forward" if retok is not None
+                            else "id matrix -> hypernet forward [A/B: --no-retokenize]") + ("" if world == 1 else " -> all-gather")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak if peak else None, "traffic": traffic,
                      "kernel": "zett::gemm8r_tn_kernel (256x256 register-staged MFMA GEMM) with the 384x256 and 128x128 tile variants where wave quantisation / small shapes call for them: all GEMM launches, FLOP-weighted", "launches_per_step": launches / max(args.steps, 1),

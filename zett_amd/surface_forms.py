@@ -182,16 +182,18 @@ class DeviceRetokenizer:
         _lib.check(self.lib.zett_retok_create(C.byref(m), index, C.byref(handle)), "zett_retok_create")
         self.handle = handle
 
-    def __call__(self, tokens: Sequence[str], maxlen: int) -> Tuple[torch.Tensor, int]:
-        """int32 [len(tokens), maxlen] on the device + number of truncated tokens."""
+    def encode(self, tokens: Sequence[str]) -> Tuple[torch.Tensor, torch.Tensor, int]:
+        """Host side of a call: UTF-8 text of the byte-level token strings + int32 offsets, copied to the device."""
         encoded = [t.encode("utf-8") for t in tokens]
         n = len(encoded)
         offsets = np.zeros(n + 1, dtype=np.int32)
         if n:
             np.cumsum(np.fromiter(map(len, encoded), dtype=np.int64, count=n), out=offsets[1:])
         text = np.frombuffer(b"".join(encoded) or b"\0", dtype=np.uint8)
-        d_text = torch.from_numpy(text.copy()).to(self.device)
-        d_off = torch.from_numpy(offsets).to(self.device)
+        return torch.from_numpy(text.copy()).to(self.device), torch.from_numpy(offsets).to(self.device), n
+
+    def run(self, d_text: torch.Tensor, d_off: torch.Tensor, n: int, maxlen: int, tokens: Optional[Sequence[str]] = None) -> Tuple[torch.Tensor, int]:
+        """Device side: zett_retokenize on resident text/offsets -> int32 [n, maxlen] on the device + n_truncated."""
         out = torch.empty((n, maxlen), dtype=torch.int32, device=self.device)
         n_trunc = C.c_int64(0)
         bad = C.c_int64(-1)
@@ -200,7 +202,7 @@ class DeviceRetokenizer:
             rc = self.lib.zett_retokenize(self.handle, C.c_void_p(d_text.data_ptr()), C.c_void_p(d_off.data_ptr()), n,
                                           int(maxlen), self.spec.pad_token_id, C.c_void_p(out.data_ptr()),
                                           C.byref(n_trunc), C.byref(bad), C.c_void_p(stream))
-        if rc == _lib.E_KEY and bad.value >= 0:
+        if rc == _lib.E_KEY and bad.value >= 0 and tokens is not None:
             for ch in tokens[bad.value]:                 # the reference raises KeyError(<character>)
                 if ch not in CHARS_TO_BYTES:
                     raise KeyError(ch)
@@ -208,6 +210,11 @@ class DeviceRetokenizer:
             raise Exception(self.lib.zett_last_error().decode())      # tokenizers raises a bare Exception here
         _lib.check(rc, "zett_retokenize")
         return out, int(n_trunc.value)
+
+    def __call__(self, tokens: Sequence[str], maxlen: int) -> Tuple[torch.Tensor, int]:
+        """int32 [len(tokens), maxlen] on the device + number of truncated tokens."""
+        d_text, d_off, n = self.encode(tokens)
+        return self.run(d_text, d_off, n, maxlen, tokens)
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -143,3 +143,49 @@ def make_surface_forms(cfg, n_rows: int, seed: int = 0, hist=LEN_HIST_MISTRAL,
     if n_special:
         out[:n_special] = d.pad_token_id
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic hn tokenizer + target-token strings whose retokenization IS a given surface-form matrix,
+# so that a benchmark can start from surface forms (bytes) and still run the exact id workload above.
+# ---------------------------------------------------------------------------------------------
+_PIECE_ALPHABET = "".join(chr(c) for c in range(33, 127) if chr(c) not in "<>/[]|_#'\"\\`{}")   # 80 byte-chars that are plain ASCII
+
+
+def _piece(i: int) -> str:
+    a = _PIECE_ALPHABET
+    n = len(a)
+    return a[i % n] + a[(i // n) % n] + a[(i // (n * n)) % n]
+
+
+def make_hn_unigram_model(cfg) -> dict:
+    """A tokenizers-format Unigram model JSON with one 3-byte piece per id in [0, V0 + X): every piece has the
+    same score and no shorter piece exists, so the Viterbi segmentation of a concatenation of pieces is that
+    concatenation.  Ids 0..2 are special-token strings (never produced by make_surface_forms)."""
+    d = HypernetDims.from_config(cfg)
+    n = d.original_vocab_size + d.n_extra
+    assert n <= len(_PIECE_ALPHABET) ** 3
+    vocab = [["<unk>", 0.0], ["<s>", 0.0], ["</s>", 0.0]] + [[_piece(i), -10.0] for i in range(3, n)]
+    return {"type": "Unigram", "unk_id": 0, "vocab": vocab, "byte_fallback": False}
+
+
+def tokens_for_surface_forms(cfg, ids: np.ndarray):
+    """Target-token strings (byte-level alphabet) that retokenize to the rows of `ids` under make_hn_unigram_model:
+    the pieces of the non-pad ids of the row, concatenated.  Rows must be pad-free up to their length (what
+    make_surface_forms produces with n_special = 0)."""
+    d = HypernetDims.from_config(cfg)
+    ids = np.asarray(ids)
+    lengths = (ids != d.pad_token_id).sum(axis=1)
+    assert ((np.arange(ids.shape[1])[None, :] < lengths[:, None]) == (ids != d.pad_token_id)).all(), "pads must be trailing"
+    assert (lengths > 0).all(), "all-pad rows stand for special tokens: not representable as a byte string"
+    cache: Dict[int, str] = {}
+    out = []
+    for row, ln in zip(ids.tolist(), lengths.tolist()):
+        parts = []
+        for i in row[:ln]:
+            p = cache.get(i)
+            if p is None:
+                p = cache[i] = _piece(i)
+            parts.append(p)
+        out.append("".join(parts))
+    return out
