@@ -43,3 +43,18 @@ def test_known_answers():
     assert retok_ref.tokenize(ign, b"abc") == [3]
     noign = retok_ref.model_from_tokenizer_json({"type": "BPE", "vocab": v, "merges": [["a", "b"]]})
     assert retok_ref.tokenize(noign, b"abc") == [4, 2]
+
+
+@pytest.mark.parametrize("name", ["tiny", "mistral_gpt2_32k", "xlmr_gpt2"])
+def test_bench_surface_forms_retokenize_to_the_workload_ids(name):
+    """bench.py starts every step from byte strings: the synthetic hn tokenizer and the target-token strings of
+    zett_amd.synth must retokenize (oracle: the tokenizers-library algorithm) to exactly the id matrix the
+    forward is benchmarked on, with nothing truncated."""
+    from zett_amd import synth
+    cfg, _, _, hist = synth.workload(name)
+    ids = synth.make_surface_forms(cfg, 3000, seed=0, hist=hist)
+    model = synth.make_hn_unigram_model(cfg)
+    tokens = synth.tokens_for_surface_forms(cfg, ids)
+    om = retok_ref.model_from_tokenizer_json({"model": model}, ["<unk>", "<s>", "</s>"], [0, 1, 2])
+    got, n_trunc = retok_ref.surface_form_matrix_c(om, tokens, ids.shape[1], cfg["pad_token_id"])
+    assert n_trunc == 0 and (got == ids).all()
