@@ -15,7 +15,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libzett_hip.so")
 SOURCES = ("zett_hip.hip",)
-HEADERS = ("common.hip.h", "gemm.hip.h", "gemm256.hip.h", "gemm384.hip.h", "rowops.hip.h", "retok.hip.h", "../../include/zett_hip.h")
+HEADERS = tuple(sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))) + ("../../include/zett_hip.h",)      # every header of csrc/
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC")
 
 
