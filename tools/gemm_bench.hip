@@ -26,6 +26,7 @@
 #include "gemm4r.hip.h"
 #include "gemm8r.hip.h"
 #include "gemm8x.hip.h"
+#include "gemm8p.hip.h"
 #include "gemm384.hip.h"
 
 using namespace zett;
@@ -91,6 +92,7 @@ int main(int argc, char** argv) {
     variants.push_back({"g256l", launch_gemm256l<bf16_t>});
     variants.push_back({"g4r", launch_gemm4r<bf16_t>});
     variants.push_back({"g8r", launch_gemm8r<bf16_t>});
+    variants.push_back({"g8p", launch_gemm8p<bf16_t>});
     variants.push_back({"g8x", launch_gemm8x<bf16_t>});
     if (getenv("RING")) { variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>}); variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>}); }
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
