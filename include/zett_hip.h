@@ -125,6 +125,13 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
 
 int zett_get_stats(const zett_hypernet* h, zett_stats* out);
 
+/* Upper bound of the device bytes zett_forward reserves (and keeps until zett_destroy)
+ * for a [n_rows, seq] batch at the current options: the plan's worst case, no pad
+ * position and every position a different source id.  The reference has no counterpart
+ * (torch's caching allocator owns its activations); callers use it to size --batch_size
+ * against free HBM before the first forward. */
+int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, int64_t* out_bytes);
+
 /* Options: "max_chunk_tokens" (default 131072), "time_gemm" (0/1: bracket every
  * GEMM launch with HIP events on the launch stream and report the sum in
  * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "gemm_variant"

@@ -178,3 +178,28 @@ def test_full_size_shards_equal_whole(name, rows):
         got = [None if t is None else t[torch.from_numpy(sample).cuda()].cpu().numpy() for t in full]
         util.assert_bf16_close(got[0], want[0], "xlmr full-size sample pred_in")
         util.assert_bf16_close(got[2], want[2], "xlmr full-size sample bias")
+
+
+def test_workspace_bytes_bounds_what_a_forward_reserves():
+    """zett_workspace_bytes is an upper bound of the device memory a forward takes from HIP
+    (measured as the drop of free HBM, minus the torch-owned outputs), grows with the batch
+    and shrinks with max_chunk_tokens."""
+    cfg, *_ = synth.workload("tiny")
+    eng = _engine(cfg, 3, "bf16")
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 3)).cuda()
+    ids = synth.make_surface_forms(cfg, 20000, seed=3)
+    bound = eng.workspace_bytes(*ids.shape)
+    assert bound > 0 and eng.workspace_bytes(2 * ids.shape[0], ids.shape[1]) > bound
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    reserved0 = torch.cuda.memory_reserved()
+    out = _run(eng, ids, src, 2)
+    free1, _ = torch.cuda.mem_get_info()
+    torch_grew = torch.cuda.memory_reserved() - reserved0
+    taken = (free0 - free1) - torch_grew
+    assert taken <= bound + (8 << 20), (taken, bound)          # 8 MiB: allocator granularity of ~12 buffers
+    eng.set_option("max_chunk_tokens", 4096)
+    assert eng.workspace_bytes(*ids.shape) < bound
+    with pytest.raises(Exception):
+        eng.workspace_bytes(-1, 7)
+    del out

@@ -1,10 +1,13 @@
 """Yardstick only (not on the product path): hipBLASLt bf16 TN GEMM rate via torch.matmul on the
 shapes the benchmark workload launches, to compare with the in-tree kernel's per-launch log."""
-import torch, time
+import os, torch, time
+ZERO = bool(os.environ.get("ZERO"))
 shapes = [(65536, 3072, 1024), (65536, 1024, 1024), (65536, 4096, 1024), (65536, 1024, 4096), (32768, 8192, 1024), (65536, 1024, 1536), (8192, 8192, 8192)]
 for M, N, K in shapes:
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
+    if ZERO:
+        a.zero_(); w.zero_()
     for _ in range(3): torch.matmul(a, w.t())
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -26,6 +26,7 @@
 #include "gemm4r.hip.h"
 #include "gemm8r.hip.h"
 #include "gemm8x.hip.h"
+#include "gemm4d.hip.h"
 #include "gemm8p.hip.h"
 #include "gemm384.hip.h"
 
@@ -41,6 +42,19 @@ __global__ void fill_bf16(bf16_t* p, size_t n, uint32_t seed, float scale) {
         x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
         const float f = ((float)(x & 0xffffff) / 8388608.0f - 1.0f) * scale;
         p[i] = f32_to_bf16(f);
+    }
+}
+// standard normal (Box-Muller) times scale: what torch.randn gives the hipBLASLt yardstick
+__global__ void fill_bf16_normal(bf16_t* p, size_t n, uint32_t seed, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        uint32_t y = x * 0x9e3779b9u + 0x7f4a7c15u;
+        y ^= y >> 16; y *= 0x7feb352du; y ^= y >> 15; y *= 0x846ca68bu; y ^= y >> 16;
+        const float u1 = ((float)(x >> 8) + 1.0f) / 16777217.0f, u2 = (float)(y >> 8) / 16777216.0f;
+        p[i] = f32_to_bf16(sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2) * scale);
     }
 }
 __global__ void fill_f32(float* p, size_t n, uint32_t seed, float scale) {
@@ -94,6 +108,10 @@ int main(int argc, char** argv) {
     variants.push_back({"g8r", launch_gemm8r<bf16_t>});
     variants.push_back({"g8p", launch_gemm8p<bf16_t>});
     variants.push_back({"g8x", launch_gemm8x<bf16_t>});
+    variants.push_back({"g4d", launch_gemm4d<bf16_t>});
+    variants.push_back({"g4dt4", launch_gemm4d<bf16_t, 4>});
+    variants.push_back({"g4ds1", launch_gemm4d<bf16_t, 101>});
+    variants.push_back({"g4ds2", launch_gemm4d<bf16_t, 102>});
     if (getenv("RING")) { variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>}); variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>}); }
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
@@ -126,21 +144,31 @@ int main(int argc, char** argv) {
     const char* epi_env = getenv("EPI");     // 0 = bf16 out only, 1 = bias+gelu_erf bf16 out, 2 = bias+residual f32 out, 3 = bias+gelu_tanh, 4 = bias+scale/shift f32+bf16 out
     const int epi_mode = epi_env ? atoi(epi_env) : 0;
     const int rounds = getenv("ROUNDS") ? atoi(getenv("ROUNDS")) : 5;
+    const int burst = getenv("BURST") ? atoi(getenv("BURST")) : 3;      // back-to-back launches per timing
     for (auto& s : shapes) {
         const int M = s[0], N = s[1], K = s[2];
         bf16_t *A, *W, *C0, *C1;
         float *bias, *res, *cf;
-        CK(hipMalloc(&A, ((size_t)M + 512) * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2));
+        const int ldpad = getenv("LDPAD") ? atoi(getenv("LDPAD")) : 0;      // extra elements per operand row (channel spread)
+        const int ldk = K + ldpad;
+        CK(hipMalloc(&A, ((size_t)M + 512) * ldk * 2)); CK(hipMalloc(&W, (size_t)N * ldk * 2));
         CK(hipMalloc(&C0, (size_t)M * N * 2)); CK(hipMalloc(&C1, (size_t)M * N * 2));
         CK(hipMalloc(&bias, (size_t)N * 4)); CK(hipMalloc(&res, (size_t)M * N * 4)); CK(hipMalloc(&cf, (size_t)M * N * 4));
-        fill_bf16<<<2048, 256>>>(A, (size_t)M * K, 1, 1.0f);
-        fill_bf16<<<2048, 256>>>(W, (size_t)N * K, 2, 0.05f);
+        if (getenv("ZERO")) {               // all-zero operands: the rate of the schedule without the power limit
+            CK(hipMemset(A, 0, (size_t)M * ldk * 2)); CK(hipMemset(W, 0, (size_t)N * ldk * 2));
+        } else if (getenv("NORMAL")) {
+            fill_bf16_normal<<<2048, 256>>>(A, (size_t)M * ldk, 1, 1.0f);
+            fill_bf16_normal<<<2048, 256>>>(W, (size_t)N * ldk, 2, 1.0f);
+        } else {
+            fill_bf16<<<2048, 256>>>(A, (size_t)M * ldk, 1, 1.0f);
+            fill_bf16<<<2048, 256>>>(W, (size_t)N * ldk, 2, 0.05f);
+        }
         fill_f32<<<64, 256>>>(bias, N, 3, 0.1f);
         fill_f32<<<2048, 256>>>(res, (size_t)M * N, 4, 1.0f);
         CK(hipDeviceSynchronize());
         auto make = [&](bf16_t* out) {
             GemmArgs<bf16_t> g{};
-            g.A = A; g.lda = getenv("LDA0") ? 0 : K; g.W = W; g.ldw = getenv("LDA0") ? 0 : K; g.M = M; g.N = N; g.K = K;
+            g.A = A; g.lda = getenv("LDA0") ? 0 : ldk; g.W = W; g.ldw = getenv("LDA0") ? 0 : ldk; g.M = M; g.N = N; g.K = K;
             g.epi.split_col = 0x7fffffff;
             if (epi_mode == 0) { g.epi.out_lo = out; g.epi.ld_lo = N; }
             else if (epi_mode == 1) { g.epi.bias = bias; g.epi.act = ACT_GELU_ERF; g.epi.out_lo = out; g.epi.ld_lo = N; }
@@ -172,11 +200,11 @@ int main(int argc, char** argv) {
             for (size_t v = 0; v < variants.size(); ++v) {
                 GemmArgs<bf16_t> g = make(C1);
                 CK(hipEventRecord(e0, 0));
-                for (int it = 0; it < 3; ++it) CK(variants[v].launch(g, 0));
+                for (int it = 0; it < burst; ++it) CK(variants[v].launch(g, 0));
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-                times[v].push_back(ms / 3);
+                times[v].push_back(ms / burst);
             }
         }
         printf("M=%d N=%d K=%d epi=%d :", M, N, K, epi_mode);

@@ -19,7 +19,7 @@ RETOK_BPE, RETOK_UNIGRAM = 0, 1
 
 ABI_SYMBOLS = (
     "zett_last_error", "zett_abi_version", "zett_create", "zett_destroy", "zett_load_weight",
-    "zett_finalize", "zett_forward", "zett_get_stats", "zett_set_option",
+    "zett_finalize", "zett_forward", "zett_get_stats", "zett_workspace_bytes", "zett_set_option",
     "zett_retok_create", "zett_retok_destroy", "zett_retokenize",
 )
 
@@ -82,6 +82,7 @@ def load():
         lib.zett_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_int64,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.zett_get_stats.argtypes = [C.c_void_p, C.POINTER(ZettStats)]
+        lib.zett_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         lib.zett_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.zett_retok_create.argtypes = [C.POINTER(ZettRetokModel), C.c_int, C.POINTER(C.c_void_p)]
         lib.zett_retok_destroy.argtypes = [C.c_void_p]

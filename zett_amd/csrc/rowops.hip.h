@@ -392,10 +392,13 @@ template <typename T> __device__ __forceinline__ void store8_16bit(T* p, const f
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&o)[8]) { store8_16bit<bf16_t>(p, o); }
 template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&o)[8]) { store8_16bit<f16_t>(p, o); }
 
-// qkv: [T, 3H] (q | k | v), ctx: [T or rows, H].  cls_only: compute query 0 only and
+// q: [T, ldq] per packed position, or (cls_only) [rows, ldq] holding the query of position 0
+// of each row; k, v: [T, ldkv]; ctx: [T or rows, H].  cls_only: compute query 0 only and
 // write it at ctx[row_local] (compact [rows, H] output for the last layer).
 template <typename T>
-__global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict__ qkv, int H, int head_dim,
+__global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict__ qbase, size_t ldq,
+                                                             const T* __restrict__ kbase, const T* __restrict__ vbase,
+                                                             size_t ldkv, int H, int head_dim,
                                                              const int32_t* __restrict__ row_offset,
                                                              const uint8_t* __restrict__ row_uniform,
                                                              const uint8_t* __restrict__ tok_key, int64_t row0,
@@ -412,12 +415,11 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
     const int64_t n = row0 + rl;
     const int t0 = row_offset[n] - tok0, t1 = row_offset[n + 1] - tok0;
     const bool uniform = row_uniform[n];
-    const size_t ld = (size_t)3 * H;
     const int nq = cls_only ? 1 : (t1 - t0);
     const int ccol = active ? col : 0;
     for (int qi = 0; qi < nq; ++qi) {
         float q[8];
-        load8<T>(qkv + (size_t)(t0 + qi) * ld + ccol, q);
+        load8<T>(qbase + (cls_only ? (size_t)rl : (size_t)(t0 + qi)) * ldq + ccol, q);
         // one pass over the keys with a running maximum (online softmax): K and V are read once
         float mx = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
@@ -425,8 +427,8 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
         for (int kj = t0; kj < t1; ++kj) {
             if (!uniform && !tok_key[tok0 + kj]) continue;
             float k[8], v[8];
-            load8<T>(qkv + (size_t)kj * ld + H + ccol, k);
-            load8<T>(qkv + (size_t)kj * ld + 2 * H + ccol, v);
+            load8<T>(kbase + (size_t)kj * ldkv + ccol, k);
+            load8<T>(vbase + (size_t)kj * ldkv + ccol, v);
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) s = fmaf(q[c], k[c], s);

@@ -158,6 +158,36 @@ int validate_config(const zett_config& c, int precision) {
     return 0;
 }
 
+// Device bytes zett_forward reserves, as a function of what the plan found (packed positions
+// Ttot, distinct ids D).  One definition shared by do_forward and zett_workspace_bytes.
+struct WorkspaceSizes {
+    int64_t chunk_tokens;
+    size_t table, x0, f32_rows, lo_rows, big;
+    size_t total() const { return table + x0 + 3 * f32_rows + 3 * lo_rows + big; }
+};
+
+static size_t plan_i32_bytes(const zett_config& c, int64_t N, int seq) {
+    const int64_t V = (int64_t)c.original_vocab_size + c.n_extra;
+    const int64_t max_tok = N * (int64_t)(seq + (c.embed_lang ? 1 : 0));
+    // row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] err[1] scan scratch
+    const size_t scan_scratch = 2 * ((size_t)std::max<int64_t>(N, V) / SCAN_CHUNK + 2) + 1;
+    return ((size_t)N + (N + 1) + V + (V + 1) + V + 2 * (size_t)max_tok + 1 + scan_scratch) * 4;
+}
+
+static WorkspaceSizes workspace_sizes(const zett_config& c, size_t es, int seq, int64_t Ttot, int64_t D, int64_t cap) {
+    const int lam = c.embed_lang ? 1 : 0;
+    WorkspaceSizes w{};
+    w.chunk_tokens = std::max<int64_t>(std::min<int64_t>(cap, std::max<int64_t>(Ttot, D)), seq + lam);
+    const size_t MC = (size_t)w.chunk_tokens, MCS = MC + 384;
+    const size_t wide = (size_t)std::max(c.intermediate, 3 * c.hidden);
+    w.table = (size_t)D * c.hidden * 4;
+    w.x0 = MCS * c.n_in_embd * es;
+    w.f32_rows = MC * c.hidden * 4;
+    w.lo_rows = MCS * c.hidden * es;
+    w.big = MCS * wide * es;
+    return w;
+}
+
 template <typename T>
 int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const void* src, int src_dtype,
                int64_t v_src, int lang_index, float* out_in, float* out_out, float* out_bias, hipStream_t st);
@@ -330,6 +360,18 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else {
         return fail(ZETT_E_INVALID, "unknown option %s", key);
     }
+    return 0;
+}
+
+int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, int64_t* out_bytes) {
+    if (!h || !out_bytes) return fail(ZETT_E_INVALID, "null argument");
+    if (n_rows < 0 || seq < 1) return fail(ZETT_E_INVALID, "bad surface-form shape [%lld, %d]", (long long)n_rows, seq);
+    const zett_config& c = h->cfg;
+    const int64_t V = (int64_t)c.original_vocab_size + c.n_extra;
+    const int64_t max_tok = n_rows * (int64_t)(seq + (c.embed_lang ? 1 : 0));
+    // worst case of the plan: no pad position, every position a different source id
+    const WorkspaceSizes w = workspace_sizes(c, elt_size(h->precision), seq, max_tok, std::min<int64_t>(V, max_tok), h->max_chunk_tokens);
+    *out_bytes = (int64_t)(w.total() + plan_i32_bytes(c, n_rows, seq) + (size_t)n_rows + (size_t)max_tok);
     return 0;
 }
 
@@ -515,9 +557,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
 
     // ---- plan ---------------------------------------------------------------------
     // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] err[1] scan scratch
-    const size_t scan_scratch = 2 * ((size_t)std::max<int64_t>(N, V) / SCAN_CHUNK + 2) + 1;
-    const size_t n_i32 = (size_t)N + (N + 1) + V + (V + 1) + V + 2 * (size_t)max_tok + 1 + scan_scratch;
-    if (int rc = h->plan_i32.reserve(n_i32 * 4)) return rc;
+    if (int rc = h->plan_i32.reserve(plan_i32_bytes(c, N, seq))) return rc;
     if (int rc = h->plan_u8.reserve((size_t)N + (size_t)max_tok)) return rc;
     PlanArrays p{};
     int32_t* base = h->plan_i32.as<int32_t>();
@@ -563,20 +603,18 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     h->stats.distinct_ids = D;
 
     // ---- workspace ------------------------------------------------------------------
-    const int64_t cap = h->max_chunk_tokens;
-    const int64_t MC = std::max<int64_t>(std::min<int64_t>(cap, std::max<int64_t>(Ttot, D)), seq + lam);
-    const size_t es = sizeof(T);
-    const size_t wide = (size_t)std::max(I, 3 * H);
+    const WorkspaceSizes ws = workspace_sizes(c, sizeof(T), seq, Ttot, D, h->max_chunk_tokens);
+    const int64_t MC = ws.chunk_tokens;
     const size_t MCS = (size_t)MC + 384;      // slack rows: the 384-row GEMM tile reads whole tiles of A
-    if (int rc = h->table.reserve((size_t)D * H * 4)) return rc;
-    if (int rc = h->x0.reserve(MCS * EIN * es)) return rc;
-    if (int rc = h->yf.reserve((size_t)MC * H * 4)) return rc;
-    if (int rc = h->yt.reserve(MCS * H * es)) return rc;
-    if (int rc = h->big.reserve(MCS * wide * es)) return rc;
-    if (int rc = h->pre.reserve((size_t)MC * H * 4)) return rc;
-    if (int rc = h->ctx.reserve(MCS * H * es)) return rc;
-    if (int rc = h->cf.reserve((size_t)MC * H * 4)) return rc;
-    if (int rc = h->ct.reserve(MCS * H * es)) return rc;
+    if (int rc = h->table.reserve(ws.table)) return rc;
+    if (int rc = h->x0.reserve(ws.x0)) return rc;
+    if (int rc = h->yf.reserve(ws.f32_rows)) return rc;
+    if (int rc = h->yt.reserve(ws.lo_rows)) return rc;
+    if (int rc = h->big.reserve(ws.big)) return rc;
+    if (int rc = h->pre.reserve(ws.f32_rows)) return rc;
+    if (int rc = h->ctx.reserve(ws.lo_rows)) return rc;
+    if (int rc = h->cf.reserve(ws.f32_rows)) return rc;
+    if (int rc = h->ct.reserve(ws.lo_rows)) return rc;
     float* TBL = h->table.as<float>();
     T* X0 = h->x0.as<T>();
     float* Zf = h->yf.as<float>();
@@ -637,22 +675,36 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         for (int l = 0; l < c.layers && !R.rc; ++l) {
             const std::string lp = "model.encoder.layer." + std::to_string(l) + ".";
             const bool cls_only = h->cls_only_last && l == c.layers - 1;
-            GemmEpilogue<T> eq = R.epi();
-            eq.bias = h->qkv_b[l]; eq.out_lo = BIG; eq.ld_lo = 3 * H;
-            R.gemm(Zt, H, (const T*)h->qkv_w[l], H, m, 3 * H, H, eq);
-            {
-                const int64_t waves = (int64_t)rows * groups;
-                hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
-                                   (const T*)BIG, H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0,
-                                   scaling, cls_only ? 1 : 0, CTX);
-                R.check("attention");
-            }
             const float* resid = Zf;
-            if (cls_only) {   // only hidden[:,0] is consumed after this layer (modeling_hypernet.py:234)
-                hipLaunchKernelGGL((cls_gather_kernel<T>), dim3(rows), dim3(256), 0, st, (const float*)Zf, (const T*)nullptr, H,
-                                   p.row_offset, r0, rows, tok0, 0, Cf, (T*)nullptr, (const float*)nullptr,
+            const T* wqkv = (const T*)h->qkv_w[l];
+            const int64_t waves = (int64_t)rows * groups;
+            if (!cls_only) {
+                GemmEpilogue<T> eq = R.epi();
+                eq.bias = h->qkv_b[l]; eq.out_lo = BIG; eq.ld_lo = 3 * H;
+                R.gemm(Zt, H, wqkv, H, m, 3 * H, H, eq);
+                hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
+                                   (const T*)BIG, (size_t)3 * H, (const T*)BIG + H, (const T*)BIG + 2 * H, (size_t)3 * H,
+                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 0, CTX);
+                R.check("attention");
+            } else {
+                // Only hidden[:,0] is consumed after this layer (modeling_hypernet.py:234): keys and
+                // values for every position, the query (and everything downstream) for position 0.
+                hipLaunchKernelGGL((cls_gather_kernel<T>), dim3(rows), dim3(256), 0, st, (const float*)Zf, (const T*)Zt, H,
+                                   p.row_offset, r0, rows, tok0, 0, Cf, Ct, (const float*)nullptr,
                                    (const float*)nullptr, (float*)nullptr);
-                R.check("cls_gather(residual)");
+                R.check("cls_gather(layer input)");
+                T* KV = BIG;                              // [m, 2H]
+                T* Q = BIG + (size_t)m * 2 * H;           // [rows, H]  (rows <= m, BIG holds >= m x 3H)
+                GemmEpilogue<T> ekv = R.epi();
+                ekv.bias = h->qkv_b[l] + H; ekv.out_lo = KV; ekv.ld_lo = 2 * H;
+                R.gemm(Zt, H, wqkv + (size_t)H * H, H, m, 2 * H, H, ekv);
+                GemmEpilogue<T> eq = R.epi();
+                eq.bias = h->qkv_b[l]; eq.out_lo = Q; eq.ld_lo = H;
+                R.gemm(Ct, H, wqkv, H, rows, H, H, eq);
+                hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
+                                   (const T*)Q, (size_t)H, (const T*)KV, (const T*)KV + H, (size_t)2 * H,
+                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 1, CTX);
+                R.check("attention(position 0)");
                 resid = Cf;
                 zrows = rows;
                 compact = true;

@@ -103,6 +103,12 @@ class HipEngine:
     def set_option(self, key: str, value: int) -> None:
         _lib.check(self.lib.zett_set_option(self.handle, key.encode(), int(value)), f"zett_set_option({key})")
 
+    def workspace_bytes(self, n_rows: int, seq: int) -> int:
+        """Upper bound of the device bytes a [n_rows, seq] forward reserves (zett_workspace_bytes)."""
+        out = C.c_int64(0)
+        _lib.check(self.lib.zett_workspace_bytes(self.handle, int(n_rows), int(seq), C.byref(out)), "zett_workspace_bytes")
+        return out.value
+
     def stats(self) -> dict:
         s = _lib.ZettStats()
         _lib.check(self.lib.zett_get_stats(self.handle, C.byref(s)))
