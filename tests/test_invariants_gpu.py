@@ -74,12 +74,12 @@ def test_gemm_tile_variants_bit_identical(precision, name, rows):
     lang = 1 if cfg.get("hn_embed_lang_id") else -1
     auto = _run(eng, ids, src, lang)
     assert all(t is None or bool(torch.isfinite(t).all()) for t in auto)
-    for variant in (1, 2, 3, 4, 5, 6):
+    for variant in (1, 2, 3, 4, 5, 6, 7):
         eng.set_option("gemm_variant", variant)
         assert _eq(_run(eng, ids, src, lang), auto), f"gemm_variant {variant}"
     eng.set_option("gemm_variant", 0)
     with pytest.raises(ValueError):
-        eng.set_option("gemm_variant", 7)
+        eng.set_option("gemm_variant", 8)
 
 
 def test_repeated_launches_identical_bits_small_grids():
@@ -92,7 +92,7 @@ def test_repeated_launches_identical_bits_small_grids():
     src = torch.from_numpy(synth.make_source_embeddings(cfg, 3, dtype=src_dtype)).cuda()
     ids = synth.make_surface_forms(cfg, 32, seed=3, hist=hist, n_special=1)
     auto = _run(eng, ids, src, -1)
-    for variant in (0, 2, 3, 4, 5, 6):
+    for variant in (0, 2, 3, 4, 5, 6, 7):
         eng.set_option("gemm_variant", variant)
         for it in range(12):
             assert _eq(_run(eng, ids, src, -1), auto), f"gemm_variant {variant}, launch {it}"

@@ -1,4 +1,4 @@
-// gemm4d.hip.h — EXPERIMENT (tools/gemm_bench only, not in the library): 256x256 tile, FOUR waves (one per
+// gemm4dx.hip.h — EXPERIMENT (tools/gemm_bench only, not in the library): 256x256 tile, FOUR waves (one per
 // SIMD, 128x128 of the tile each), both operands streamed HBM/L2 -> LDS by buffer_load_dwordx4 ... lds
 // (no VGPR round trip, no ds_write pass), on v_mfma_f32_16x16x32_{bf16,f16}, accumulators pinned to AGPRs.
 // This is the geometry of the hipBLASLt kernel the yardstick runs (MT256x256x64, MI16x16, 256 threads,
@@ -47,36 +47,20 @@
 
 #include <type_traits>
 
-#include "gemm8x.hip.h"
+#include "gemm4d.hip.h"
 
 #ifndef G4D_ABL
 #define G4D_ABL 0      // ablation bits for tools/gemm_bench (results are garbage when set): 1 no DMA in the loop,
-#endif                 // 2 no B1/B2, 4 no B3/B4 + vmcnt waits, 8 no fragment reads in the loop
+#endif                 // 2 no B1/B2, 4 no B3/B4 + vmcnt waits, 8 no fragment reads in the loop, 16 no s_barrier (waits kept), 32 no vmcnt waits (barriers kept)
 
 namespace zett {
-
-// s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt = simm16[15:14]:[3:0], expcnt [6:4], lgkmcnt [11:8])
-constexpr int g4d_wait_vm(int n) { return ((n >> 4) << 14) | 0x0F70 | (n & 15); }
-
-// The accumulators are pinned to the AGPR half of the register file ("+a") and the fragments to the VGPR
-// half: with 256 + 128 live registers the allocator otherwise spreads the accumulators over both halves and
-// shuttles them through v_accvgpr_read/write around every MFMA.  Nothing reads an accumulator between the
-// MFMAs of the K loop (64 MFMAs lie between two uses of the same one); the caller covers the MFMA -> VALU
-// read latency after the loop, which the hazard recogniser cannot see through inline assembly.
-template <typename T> __device__ __forceinline__ void mfma16_agpr(f32x4& c, const u32x4& a, const u32x4& b);
-template <> __device__ __forceinline__ void mfma16_agpr<bf16_t>(f32x4& c, const u32x4& a, const u32x4& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-template <> __device__ __forceinline__ void mfma16_agpr<f16_t>(f32x4& c, const u32x4& a, const u32x4& b) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
 
 // PF > 0: every K step also touches one dword of each 128-byte operand line of step t+PF (one load per wave
 // and operand into a junk register that is never read): the lines are in L2 when their LDS-DMA request is
 // issued PF-2 steps later.  LDS holds two steps, so a request has one step to land - less than a miss to
 // HBM/MALL takes under load (all-hit addressing runs 30 % faster without this).
 template <typename T, int ACT = ACT_NONE, bool RES = false, int PF = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4d_tn_kernel(GemmArgs<T> g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4dx_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
 
@@ -122,7 +106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // PF = 101 / 102: the K loop of a tile starts at step ((tm + tn) / tn only) % 32 * 2 and wraps (what Tensile calls
     // StaggerU): tiles running at the same time then read different 256-byte columns, i.e. different memory channels.
     // 101 makes the summation order depend on the row tile and is for measurement only.
-    const int stag = PF == 101 ? (((tm + tn) & 31) * 2) % nk : PF == 102 ? ((tn & 31) * 2) % nk : 0;
+    const int stag = (PF == 101 || PF == 201 || PF == 211) ? (((tm + tn) & 31) * 2) % nk : PF == 102 ? ((tn & 31) * 2) % nk : 0;
     uint32_t a_touch, w_touch, junk = 0;
     {
         const int row = wave * 64 + lane;
@@ -195,8 +179,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 8; ++i) read_a(0, 0, i);
 
     // more: step kt+1 exists (its block-0 fragments are read here); more2: step kt+2 exists (requested here)
-    auto step = [&](int kt, auto more_c, auto more2_c) {
+    auto step = [&](int kt, auto more_c, auto more2_c, auto wave_c) {
         constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
+        constexpr int WV = decltype(wave_c)::value;     // schedule 2: this copy of the loop belongs to wave WV
         const int cur = kt & 1;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -205,22 +190,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int p = kb * 64 + i * 8 + j;
-            if (p == 18 || p == 40) {
-                // this wave's reads of the W (p = 18) / A (p = 40) image of stage cur are complete
-                if (more2 && !(G4D_ABL & 2)) {
+            if constexpr (PF >= 210) {
+                // schedule 3: two barriers per step.  All block-1 fragments are read under MFMAs 0..30, one barrier
+                // releases both images of stage cur (p = 36), the 16 requests of step kt+2 are paced over p = 38..101,
+                // one wait + barrier (p = 102) admits the block-0 reads of step kt+1.
+                if (p == 36 && more2) {
                     __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (p == 102 && more) {
+                    __builtin_amdgcn_s_waitcnt(g4d_wait_vm(more2 ? 16 : 0));
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma16_agpr<T>(acc[i][j], fa[kb][i], fw[kb][j]);
+                if (p < 16 && (p & 1) == 0) read_w(cur, 1, p >> 1);
+                if (p >= 16 && p <= 30 && (p & 1) == 0) read_a(cur, 1, (p - 16) >> 1);
+                if (more2 && p >= 38 && p < 70 && WV == ((p - 38) & 3)) dma_w(kt + 2, (p - 38) >> 2);
+                if (more2 && p >= 70 && p < 102 && WV == ((p - 70) & 3)) dma_a(kt + 2, (p - 70) >> 2);
+                if (more && p >= 103 && p <= 110) read_w(cur ^ 1, 0, p - 103);
+                if (more && p >= 111 && p <= 125 && (p & 1) == 1) read_a(cur ^ 1, 0, (p - 111) >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
+            if constexpr (PF >= 200) {
+                // schedule 2: three barriers per step, and the four waves take turns at the texture path - wave w
+                // issues its request r of an operand under MFMA base + 4r + w, so that the CU sees one request
+                // per MFMA instead of four at once every fourth
+                if ((p == 18 || p == 40) && more2) {
+                    __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (p == 84 && more) {              // everything requested during the previous step has landed
+                    __builtin_amdgcn_s_waitcnt(g4d_wait_vm(more2 ? 16 : 0));
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma16_agpr<T>(acc[i][j], fa[kb][i], fw[kb][j]);
+                if (p < 16 && (p & 1) == 0) read_w(cur, 1, p >> 1);
+                if (p >= 21 && p <= 35 && (p & 1) == 1) read_a(cur, 1, (p - 21) >> 1);
+                if (more2 && p >= 20 && p < 52 && WV == ((p - 20) & 3)) dma_w(kt + 2, (p - 20) >> 2);
+                if (more2 && p >= 52 && p < 84 && WV == ((p - 52) & 3)) dma_a(kt + 2, (p - 52) >> 2);
+                if (more && p >= 85 && p <= 99 && (p & 1) == 1) read_w(cur ^ 1, 0, (p - 85) >> 1);
+                if (more && p >= 100 && p <= 121 && (p - 100) % 3 == 0) read_a(cur ^ 1, 0, (p - 100) / 3);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
+            if (p == 18 || p == 40) {
+                // this wave's reads of the W (p = 18) / A (p = 40) image of stage cur are complete
+                if (more2 && !(G4D_ABL & 2)) {
+                    __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
+                    if (!(G4D_ABL & 16)) __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (p == 72 && more && !(G4D_ABL & 4)) {          // W of step kt+1: everything requested after it may still be in flight
-                __builtin_amdgcn_s_waitcnt(g4d_wait_vm(more2 ? (PF && PF < 100 ? 26 : 24) : 8));
-                __builtin_amdgcn_s_barrier();
+                if (!(G4D_ABL & 32)) __builtin_amdgcn_s_waitcnt(g4d_wait_vm(more2 ? (PF && PF < 100 ? 26 : 24) : 8));
+                if (!(G4D_ABL & 16)) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (p == 96 && more && !(G4D_ABL & 4)) {          // A of step kt+1
-                __builtin_amdgcn_s_waitcnt(g4d_wait_vm(more2 ? (PF && PF < 100 ? 18 : 16) : 0));
-                __builtin_amdgcn_s_barrier();
+                if (!(G4D_ABL & 32)) __builtin_amdgcn_s_waitcnt(g4d_wait_vm(more2 ? (PF && PF < 100 ? 18 : 16) : 0));
+                if (!(G4D_ABL & 16)) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
             mfma16_agpr<T>(acc[i][j], fa[kb][i], fw[kb][j]);
@@ -240,10 +273,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     typedef std::integral_constant<bool, true> yes_t;
     typedef std::integral_constant<bool, false> no_t;
-    int kt = 0;
-    for (; kt + 2 < nk; ++kt) step(kt, yes_t{}, yes_t{});
-    if (kt + 1 < nk) { step(kt, yes_t{}, no_t{}); ++kt; }
-    step(kt, no_t{}, no_t{});
+    auto k_loop = [&](auto wave_c) {
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) step(kt, yes_t{}, yes_t{}, wave_c);
+        if (kt + 1 < nk) { step(kt, yes_t{}, no_t{}, wave_c); ++kt; }
+        step(kt, no_t{}, no_t{}, wave_c);
+    };
+    if constexpr (PF >= 200) {          // one copy of the loop per wave: the request slots differ
+        if (wave == 0) k_loop(std::integral_constant<int, 0>{});
+        else if (wave == 1) k_loop(std::integral_constant<int, 1>{});
+        else if (wave == 2) k_loop(std::integral_constant<int, 2>{});
+        else k_loop(std::integral_constant<int, 3>{});
+    } else {
+        k_loop(std::integral_constant<int, 0>{});
+    }
 
     // ---- epilogue: each wave stages its 128x128 quadrant through a private 32 KiB LDS region
     // (64 rows x 128 fp32), two passes, drained by EpiDrain (gemm256.hip.h).
@@ -274,31 +317,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 template <typename T, int ACT, bool RES, int PF>
-inline hipError_t launch_gemm4d_inst(const GemmArgs<T>& g, hipStream_t stream) {
+inline hipError_t launch_gemm4dx_inst(const GemmArgs<T>& g, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm4d_tn_kernel<T, ACT, RES, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm4dx_tn_kernel<T, ACT, RES, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
-    hipLaunchKernelGGL((gemm4d_tn_kernel<T, ACT, RES, PF>), dim3(tiles_m * tiles_n), dim3(256), G256_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm4dx_tn_kernel<T, ACT, RES, PF>), dim3(tiles_m * tiles_n), dim3(256), G256_LDS_BYTES, stream, g);
     return hipGetLastError();
 }
 
 template <typename T, int ACT, int PF>
-inline hipError_t launch_gemm4d_act(const GemmArgs<T>& g, hipStream_t stream) {
-    return g.epi.residual ? launch_gemm4d_inst<T, ACT, true, PF>(g, stream) : launch_gemm4d_inst<T, ACT, false, PF>(g, stream);
+inline hipError_t launch_gemm4dx_act(const GemmArgs<T>& g, hipStream_t stream) {
+    return g.epi.residual ? launch_gemm4dx_inst<T, ACT, true, PF>(g, stream) : launch_gemm4dx_inst<T, ACT, false, PF>(g, stream);
 }
 
 template <typename T, int PF = 0>
-inline hipError_t launch_gemm4d(const GemmArgs<T>& g, hipStream_t stream) {
+inline hipError_t launch_gemm4dx(const GemmArgs<T>& g, hipStream_t stream) {
     switch (g.epi.act) {
-        case ACT_GELU_TANH: return launch_gemm4d_act<T, ACT_GELU_TANH, PF>(g, stream);
-        case ACT_GELU_ERF: return launch_gemm4d_act<T, ACT_GELU_ERF, PF>(g, stream);
-        default: return launch_gemm4d_act<T, ACT_NONE, PF>(g, stream);
+        case ACT_GELU_TANH: return launch_gemm4dx_act<T, ACT_GELU_TANH, PF>(g, stream);
+        case ACT_GELU_ERF: return launch_gemm4dx_act<T, ACT_GELU_ERF, PF>(g, stream);
+        default: return launch_gemm4dx_act<T, ACT_NONE, PF>(g, stream);
     }
 }
 

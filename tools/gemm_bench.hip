@@ -26,7 +26,7 @@
 #include "gemm4r.hip.h"
 #include "gemm8r.hip.h"
 #include "gemm8x.hip.h"
-#include "gemm4d.hip.h"
+#include "gemm4dx.hip.h"
 #include "gemm8p.hip.h"
 #include "gemm384.hip.h"
 
@@ -108,10 +108,14 @@ int main(int argc, char** argv) {
     variants.push_back({"g8r", launch_gemm8r<bf16_t>});
     variants.push_back({"g8p", launch_gemm8p<bf16_t>});
     variants.push_back({"g8x", launch_gemm8x<bf16_t>});
-    variants.push_back({"g4d", launch_gemm4d<bf16_t>});
-    variants.push_back({"g4dt4", launch_gemm4d<bf16_t, 4>});
-    variants.push_back({"g4ds1", launch_gemm4d<bf16_t, 101>});
-    variants.push_back({"g4ds2", launch_gemm4d<bf16_t, 102>});
+    variants.push_back({"g4d", launch_gemm4dx<bf16_t>});
+    variants.push_back({"g4dt4", launch_gemm4dx<bf16_t, 4>});
+    variants.push_back({"g4ds1", launch_gemm4dx<bf16_t, 101>});
+    variants.push_back({"g4ds2", launch_gemm4dx<bf16_t, 102>});
+    variants.push_back({"g4dp", launch_gemm4dx<bf16_t, 200>});
+    variants.push_back({"g4dps", launch_gemm4dx<bf16_t, 201>});
+    variants.push_back({"g4dq", launch_gemm4dx<bf16_t, 210>});
+    variants.push_back({"g4dqs", launch_gemm4dx<bf16_t, 211>});
     if (getenv("RING")) { variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>}); variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>}); }
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
@@ -141,7 +145,7 @@ int main(int argc, char** argv) {
             if (o.find(std::string(",") + variants[v].name + ",") != std::string::npos) kept.push_back(variants[v]);
         variants = kept;
     }
-    const char* epi_env = getenv("EPI");     // 0 = bf16 out only, 1 = bias+gelu_erf bf16 out, 2 = bias+residual f32 out, 3 = bias+gelu_tanh, 4 = bias+scale/shift f32+bf16 out
+    const char* epi_env = getenv("EPI");     // 0 = bf16 out only, 1 = bias+gelu_erf bf16 out, 2 = bias+residual f32 out, 3 = bias+gelu_tanh, 4 = bias+scale/shift f32+bf16 out, 5 = bias+residual f32 out only
     const int epi_mode = epi_env ? atoi(epi_env) : 0;
     const int rounds = getenv("ROUNDS") ? atoi(getenv("ROUNDS")) : 5;
     const int burst = getenv("BURST") ? atoi(getenv("BURST")) : 3;      // back-to-back launches per timing
@@ -173,6 +177,7 @@ int main(int argc, char** argv) {
             if (epi_mode == 0) { g.epi.out_lo = out; g.epi.ld_lo = N; }
             else if (epi_mode == 1) { g.epi.bias = bias; g.epi.act = ACT_GELU_ERF; g.epi.out_lo = out; g.epi.ld_lo = N; }
             else if (epi_mode == 3) { g.epi.bias = bias; g.epi.act = ACT_GELU_TANH; g.epi.out_lo = out; g.epi.ld_lo = N; }
+            else if (epi_mode == 5) { g.epi.bias = bias; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N; }   // the library's residual launches: fp32 out only
             else if (epi_mode == 4) { g.epi.bias = bias; g.epi.scale = res; g.epi.shift = bias; g.epi.out_f32 = cf; g.epi.ld_f32 = N; g.epi.out_lo = out; g.epi.ld_lo = N; }
             else { g.epi.bias = bias; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N; g.epi.out_lo = out; g.epi.ld_lo = N; }
             return g;

@@ -35,6 +35,7 @@
 #include "gemm4r.hip.h"
 #include "gemm8r.hip.h"
 #include "gemm8x.hip.h"
+#include "gemm4d.hip.h"
 #include "rowops.hip.h"
 #include "retok.hip.h"
 
@@ -355,7 +356,7 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "cls_only_last_layer") {
         h->cls_only_last = value != 0;
     } else if (k == "gemm_variant") {
-        if (value < 0 || value > 6) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto) or 1..6 (128x128, 256x256 register-staged, 384x256, 256x256 four-wave, 256x256 LDS-DMA, 256x256 register-staged on 16x16x32 MFMAs)");
+        if (value < 0 || value > 7) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto) or 1..7 (128x128, 256x256 register-staged, 384x256, 256x256 four-wave, 256x256 LDS-DMA, 256x256 register-staged on 16x16x32 MFMAs, 256x256 four-wave direct-to-LDS for residual launches)");
         h->gemm_variant = (int)value;
     } else {
         return fail(ZETT_E_INVALID, "unknown option %s", key);
@@ -434,6 +435,11 @@ struct Runner {
         else return launch_gemm8x<T>(g, s);
     }
 
+    static hipError_t launch_4d(const GemmArgs<T>& g, hipStream_t s) {
+        if constexpr (std::is_same<T, float>::value) return hipErrorInvalidValue;
+        else return launch_gemm4d<T>(g, s);
+    }
+
     static hipError_t launch_4r(const GemmArgs<T>& g, hipStream_t s) {
         if constexpr (std::is_same<T, float>::value) return hipErrorInvalidValue;
         else return launch_gemm4r<T>(g, s);
@@ -477,9 +483,13 @@ struct Runner {
             }
         }
         if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift || e.residual)) variant = 2;
-        // long K without a residual: the same kernel on 16x16x32 MFMAs (less accumulator traffic per FLOP
-        // inside the power envelope: +3-6 %; identical bits)
-        if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= 4096 && !e.residual) variant = 6;
+        // long K: the same kernel on 16x16x32 MFMAs (less accumulator traffic per FLOP inside the power
+        // envelope: +2-6 % on every K >= 4096 launch of the benchmark step, residual epilogues included; identical bits)
+        if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= 4096) variant = 6;
+        // residual launches with long K (fp32 output): the four-wave direct-to-LDS tile, 5-9 % ahead there
+        const bool ok_4d = !is_f32 && e.residual && e.act == ACT_NONE && K >= 128;
+        if (h->gemm_variant == 0 && variant == 6 && ok_4d) variant = 7;
+        if (variant == 7 && !ok_4d) variant = is_f32 ? 2 : 6;
         if ((variant == 4 || variant == 6) && is_f32) variant = 2;
         // the large tiles drain eight columns per lane with 16-byte accesses
         const bool wide_ok = N % 8 == 0 && (!e.out_lo || e.ld_lo % 8 == 0) && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0) &&
@@ -488,6 +498,7 @@ struct Runner {
         if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
         hipError_t err;
         switch (variant) {
+            case 7: err = launch_4d(g, st); break;
             case 6: err = launch_16(g, st); break;
             case 5: err = launch_gemm256<T, 1>(g, st); break;
             case 4: err = launch_4r(g, st); break;
@@ -772,7 +783,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 (void)hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]);
                 const auto& sh = h->ev_shape[i / 2];
                 fprintf(stderr, "[zett gemm] M=%6d N=%6d K=%5d tile=%s %8.3f ms %7.1f TF\n", sh[0], sh[1], sh[2],
-                        sh[3] == 6 ? "8x " : sh[3] == 5 ? "dma" : sh[3] == 4 ? "4r " : sh[3] == 3 ? "384" : sh[3] == 2 ? "8r " : "128", t, h->ev_flops[i / 2] / (t * 1e9));
+                        sh[3] == 7 ? "4d " : sh[3] == 6 ? "8x " : sh[3] == 5 ? "dma" : sh[3] == 4 ? "4r " : sh[3] == 3 ? "384" : sh[3] == 2 ? "8r " : "128", t, h->ev_flops[i / 2] / (t * 1e9));
             }
         }
     }
