@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
     }
-    constexpr int GROUP_M = 8;
+    constexpr int GROUP_M = (PF == 212 || PF == 213) ? 4 : PF == 214 ? 2 : PF == 215 ? 1 : PF == 216 ? 6 : 8;     // 212: 4 (M) x 8 (N) tiles per XCD + K start staggered by tn; 213: the mapping alone
     const int group_size = GROUP_M * tiles_n;
     const int first_m = (wg / group_size) * GROUP_M;
     const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // PF = 101 / 102: the K loop of a tile starts at step ((tm + tn) / tn only) % 32 * 2 and wraps (what Tensile calls
     // StaggerU): tiles running at the same time then read different 256-byte columns, i.e. different memory channels.
     // 101 makes the summation order depend on the row tile and is for measurement only.
-    const int stag = (PF == 101 || PF == 201 || PF == 211) ? (((tm + tn) & 31) * 2) % nk : PF == 102 ? ((tn & 31) * 2) % nk : 0;
+    const int stag = (PF == 101 || PF == 201 || PF == 211) ? (((tm + tn) & 31) * 2) % nk : (PF == 102 || PF == 212) ? ((tn & 31) * 2) % nk : 0;
     uint32_t a_touch, w_touch, junk = 0;
     {
         const int row = wave * 64 + lane;
@@ -119,13 +119,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned char* src = base + (size_t)kt * GEMM_ROW_BYTES;
         asm volatile("global_load_dword %0, %1, %2" : "+v"(junk) : "v"(voff), "s"(src));
     };
+    u32x4 junk4 = {0, 0, 0, 0};       // G4D_ABL & 64: the requests fetch into this register instead of LDS
     auto dma_a = [&](int kt, int r) {
         int ks = kt + stag; if (ks >= nk) ks -= nk;
+        if (G4D_ABL & 64) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(junk4) : "v"(a_voff[r]), "s"(a_rsrc), "s"(ks * GEMM_ROW_BYTES)); return; }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(my_rows + (kt & 1) * G256_STAGE_BYTES + r * 8 * GEMM_ROW_BYTES), 16,
                                                  a_voff[r], ks * GEMM_ROW_BYTES, 0, 0);
     };
     auto dma_w = [&](int kt, int r) {
         int ks = kt + stag; if (ks >= nk) ks -= nk;
+        if (G4D_ABL & 64) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(junk4) : "v"(w_voff[r]), "s"(w_rsrc), "s"(ks * GEMM_ROW_BYTES)); return; }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(my_rows + (kt & 1) * G256_STAGE_BYTES + G256_OPERAND_BYTES + r * 8 * GEMM_ROW_BYTES), 16,
                                                  w_voff[r], ks * GEMM_ROW_BYTES, 0, 0);
     };
@@ -190,6 +193,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int p = kb * 64 + i * 8 + j;
+            if constexpr (PF >= 220) {
+                // schedule 4: as 3 with the block-1 reads one per MFMA (p = 0..15), 12 MFMAs of slack before the release
+                // barrier (p = 28), requests over p = 30..93, landed barrier at p = 96, 31 slots for the 16 block-0 reads
+                if (p == 28 && more2) {
+                    __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (p == 96 && more) {
+                    __builtin_amdgcn_s_waitcnt(g4d_wait_vm(more2 ? 16 : 0));
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma16_agpr<T>(acc[i][j], fa[kb][i], fw[kb][j]);
+                if (p < 8) read_w(cur, 1, p);
+                if (p >= 8 && p < 16) read_a(cur, 1, p - 8);
+                if (more2 && p >= 30 && p < 62 && WV == ((p - 30) & 3)) dma_w(kt + 2, (p - 30) >> 2);
+                if (more2 && p >= 62 && p < 94 && WV == ((p - 62) & 3)) dma_a(kt + 2, (p - 62) >> 2);
+                if (more && p >= 97 && p <= 111 && (p & 1) == 1) read_w(cur ^ 1, 0, (p - 97) >> 1);
+                if (more && p >= 112 && p <= 126 && (p & 1) == 0) read_a(cur ^ 1, 0, (p - 112) >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             if constexpr (PF >= 210) {
                 // schedule 3: two barriers per step.  All block-1 fragments are read under MFMAs 0..30, one barrier
                 // releases both images of stage cur (p = 36), the 16 requests of step kt+2 are paced over p = 38..101,
@@ -292,6 +318,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (64 rows x 128 fp32), two passes, drained by EpiDrain (gemm256.hip.h).
     asm volatile("s_nop 15\n\ts_nop 15");     // last MFMA (8 passes) -> first accumulator read
     if (PF) { __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0); asm volatile("" :: "v"(junk)); }
+    if (G4D_ABL & 64) { __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0); asm volatile("" :: "v"(junk4)); }
     __syncthreads();
     float* region = (float*)(smem + wave * 32768);
     typedef EpiDrain<T, ACT, RES, 64, 128, true, false> Drain;

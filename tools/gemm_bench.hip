@@ -116,6 +116,12 @@ int main(int argc, char** argv) {
     variants.push_back({"g4dps", launch_gemm4dx<bf16_t, 201>});
     variants.push_back({"g4dq", launch_gemm4dx<bf16_t, 210>});
     variants.push_back({"g4dqs", launch_gemm4dx<bf16_t, 211>});
+    variants.push_back({"g4dr", launch_gemm4dx<bf16_t, 220>});
+    variants.push_back({"g4dqn", launch_gemm4dx<bf16_t, 212>});
+    variants.push_back({"g4dqm", launch_gemm4dx<bf16_t, 213>});
+    variants.push_back({"g4dqm2", launch_gemm4dx<bf16_t, 214>});
+    variants.push_back({"g4dqm1", launch_gemm4dx<bf16_t, 215>});
+    variants.push_back({"g4dqm6", launch_gemm4dx<bf16_t, 216>});
     if (getenv("RING")) { variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>}); variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>}); }
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));

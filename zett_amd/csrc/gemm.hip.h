@@ -20,6 +20,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// M tiles per group of the tile order of the large-tile kernels (gemm8r / gemm8x / gemm4d): consecutive workgroups of
+// an XCD walk GROUP_M row tiles down before moving one column tile right, so the 32 tiles an XCD runs at a time form
+// a GROUP_M x (32 / GROUP_M) block and share GROUP_M + 32 / GROUP_M operand panels in its L2.  4 x 8 and 8 x 4 are the
+// same traffic, but the tall-skinny launches of this path (M = 30-80 k rows, N = 4-12 k) run 3-8 % faster on 4 x 8
+// (tools/gemm_bench -DZETT_GROUP_M=2/4/8/16: 16 loses 6-9 %, 2 is within 2 % of 4 either way).
+#ifndef ZETT_GROUP_M
+#define ZETT_GROUP_M 4
+#endif
+
 namespace zett {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;

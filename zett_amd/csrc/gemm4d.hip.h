@@ -1,8 +1,8 @@
 // gemm4d.hip.h — tile variant 7: 256x256 tile, FOUR waves (one per SIMD, 128x128 of the tile each), both operands
 // streamed HBM/L2 -> LDS by buffer_load_dwordx4 ... lds (no VGPR round trip, no ds_write pass), on
-// v_mfma_f32_16x16x32_{bf16,f16} with the 256 accumulator registers pinned to AGPRs.  Chosen for the residual
-// launches with K >= 4096 (fp32 output): 5-9 % faster there than gemm8x (tools/gemm_bench EPI=5), equal elsewhere,
-// slower below K ~ 2048.  Same geometry as the hipBLASLt kernel the yardstick runs; the experiments that led
+// v_mfma_f32_16x16x32_{bf16,f16} with the 256 accumulator registers pinned to AGPRs.  The tile of every 16-bit
+// launch with K >= 2048: with the 4 x 8 tile order (ZETT_GROUP_M = 4) 4-8 % faster than gemm8x on the shapes of
+// the benchmark step, residual or not (tools/gemm_bench), 5 % slower at K = 1024.  Same geometry as the hipBLASLt kernel the yardstick runs; the experiments that led
 // here (ablations, K-start staggering, schedules with 3-4 barriers) are in tools/experiments/gemm4dx.hip.h.
 //
 //   C[M,N] = epilogue( A[M,K] · W[N,K]ᵀ )      (contract and epilogue of gemm.hip.h; bit-identical results)
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
     }
-    constexpr int GROUP_M = 8;
+    constexpr int GROUP_M = ZETT_GROUP_M;
     const int group_size = GROUP_M * tiles_n;
     const int first_m = (wg / group_size) * GROUP_M;
     const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
@@ -231,21 +231,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-// Only the residual epilogue without activation is instantiated: that is where the caller uses this tile.
-template <typename T>
-inline hipError_t launch_gemm4d(const GemmArgs<T>& g, hipStream_t stream) {
-    if (!g.epi.residual || g.epi.act != ACT_NONE) return hipErrorInvalidValue;
+template <typename T, int ACT, bool RES>
+inline hipError_t launch_gemm4d_inst(const GemmArgs<T>& g, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm4d_tn_kernel<T, ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm4d_tn_kernel<T, ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
-    hipLaunchKernelGGL((gemm4d_tn_kernel<T, ACT_NONE, true>), dim3(tiles_m * tiles_n), dim3(256), G256_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm4d_tn_kernel<T, ACT, RES>), dim3(tiles_m * tiles_n), dim3(256), G256_LDS_BYTES, stream, g);
     return hipGetLastError();
+}
+
+template <typename T, int ACT>
+inline hipError_t launch_gemm4d_act(const GemmArgs<T>& g, hipStream_t stream) {
+    return g.epi.residual ? launch_gemm4d_inst<T, ACT, true>(g, stream) : launch_gemm4d_inst<T, ACT, false>(g, stream);
+}
+
+template <typename T>
+inline hipError_t launch_gemm4d(const GemmArgs<T>& g, hipStream_t stream) {
+    switch (g.epi.act) {
+        case ACT_GELU_TANH: return launch_gemm4d_act<T, ACT_GELU_TANH>(g, stream);
+        case ACT_GELU_ERF: return launch_gemm4d_act<T, ACT_GELU_ERF>(g, stream);
+        default: return launch_gemm4d_act<T, ACT_NONE>(g, stream);
+    }
 }
 
 }  // namespace zett

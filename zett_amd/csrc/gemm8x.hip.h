@@ -46,7 +46,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
     }
-    constexpr int GROUP_M = 8;
+    constexpr int GROUP_M = ZETT_GROUP_M;
     const int group_size = GROUP_M * tiles_n;
     const int first_m = (wg / group_size) * GROUP_M;
     const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;

@@ -356,7 +356,7 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "cls_only_last_layer") {
         h->cls_only_last = value != 0;
     } else if (k == "gemm_variant") {
-        if (value < 0 || value > 7) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto) or 1..7 (128x128, 256x256 register-staged, 384x256, 256x256 four-wave, 256x256 LDS-DMA, 256x256 register-staged on 16x16x32 MFMAs, 256x256 four-wave direct-to-LDS for residual launches)");
+        if (value < 0 || value > 7) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto) or 1..7 (128x128, 256x256 register-staged, 384x256, 256x256 four-wave, 256x256 LDS-DMA, 256x256 register-staged on 16x16x32 MFMAs, 256x256 four-wave direct-to-LDS)");
         h->gemm_variant = (int)value;
     } else {
         return fail(ZETT_E_INVALID, "unknown option %s", key);
@@ -483,13 +483,10 @@ struct Runner {
             }
         }
         if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift || e.residual)) variant = 2;
-        // long K: the same kernel on 16x16x32 MFMAs (less accumulator traffic per FLOP inside the power
-        // envelope: +2-6 % on every K >= 4096 launch of the benchmark step, residual epilogues included; identical bits)
-        if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= 4096) variant = 6;
-        // residual launches with long K (fp32 output): the four-wave direct-to-LDS tile, 5-9 % ahead there
-        const bool ok_4d = !is_f32 && e.residual && e.act == ACT_NONE && K >= 128;
-        if (h->gemm_variant == 0 && variant == 6 && ok_4d) variant = 7;
-        if (variant == 7 && !ok_4d) variant = is_f32 ? 2 : 6;
+        // 16-bit operands, K >= 2048: the four-wave direct-to-LDS tile on 16x16x32 MFMAs (4-8 % ahead of gemm8x on the
+        // launches of the benchmark step; identical bits).  gemm8x (variant 6) stays selectable.
+        if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= 2048) variant = 7;
+        if (variant == 7 && is_f32) variant = 2;
         if ((variant == 4 || variant == 6) && is_f32) variant = 2;
         // the large tiles drain eight columns per lane with 16-byte accesses
         const bool wide_ok = N % 8 == 0 && (!e.out_lo || e.ld_lo % 8 == 0) && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0) &&
