@@ -281,7 +281,7 @@ def main():
     peak = PEAK_TFLOPS[args.precision]
 
     # HBM traffic of the dominant kernel comes from PMC counters, which cannot be read from inside this
-    # process: the figure is the one measured by the committed rocprofv3 passes (profiles/r1j_pmc.md,
+    # process: the figure is the one measured by the committed rocprofv3 passes (profiles/r1k_pmc.md,
     # tools/pmc_summary.py --json) for this same command, and only quoted for the workload it was taken on.
     traffic = None
     try:
@@ -309,7 +309,7 @@ def main():
                             else "id matrix -> hypernet forward [A/B: --no-retokenize]") + ("" if world == 1 else " -> all-gather")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak if peak else None, "traffic": traffic,
-                     "kernel": "zett::gemm8x_tn_kernel / gemm8r_tn_kernel (256x256 register-staged MFMA GEMM on 16x16x32 / 32x32x16 MFMAs) and zett::gemm4d_tn_kernel (256x256 four-wave direct-to-LDS, residual launches), with the 384x256 and 128x128 tiles where wave quantisation / small shapes call for them: all GEMM launches, FLOP-weighted", "launches_per_step": launches / max(args.steps, 1),
+                     "kernel": "zett::gemm4d_tn_kernel (256x256 four-wave direct-to-LDS MFMA GEMM on 16x16x32 MFMAs: every 16-bit launch with K >= 2048), zett::gemm8r_tn_kernel (256x256 register-staged: shorter K and fp32 mode), 384x256 / 128x128 tiles where wave quantisation / small shapes call for them: all GEMM launches, FLOP-weighted", "launches_per_step": launches / max(args.steps, 1),
                      "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
                      "executed_tflop_per_step": gemm_fl / max(args.steps, 1) / 1e12},
         "as_written_tflops": rows * f_ref * args.steps / dt / 1e12,
