@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--max-chunk-tokens", type=int, default=0, help="A/B only: zett_set_option max_chunk_tokens (0 = library default)")
+    ap.add_argument("--gemm-tile-order", type=int, default=0, help="A/B only: zett_set_option gemm_tile_order (0 = default)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force one GEMM tile variant (zett_set_option gemm_variant); 0 = per-launch choice")
     ap.add_argument("--no-retokenize", action="store_true", help="A/B only: start every step from the id matrix instead of the surface forms")
     ap.add_argument("--serial-allgather", action="store_true",
@@ -172,6 +173,8 @@ def main():
     engine.set_option("time_gemm", 1)
     if args.gemm_variant:
         engine.set_option("gemm_variant", args.gemm_variant)
+    if args.gemm_tile_order:
+        engine.set_option("gemm_tile_order", args.gemm_tile_order)
     if args.max_chunk_tokens:
         engine.set_option("max_chunk_tokens", args.max_chunk_tokens)
     if rank != 0 or args.no_cpu_baseline or world > 1:

@@ -139,7 +139,8 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
  * 3 = 384x256 LDS-DMA, 4 = 256x256 register-staged four-wave, 5 = 256x256 LDS-DMA,
  * 6 = as 2 on 16x16x32 MFMAs, 7 = 256x256 four-wave direct-to-LDS (the choice for
  * 16-bit operands and K >= 2048); all produce identical bits; a forced variant falls back to
- * 2 where its preconditions do not hold). */
+ * 2 where its preconditions do not hold), "gemm_tile_order" (A/B only: 0 = the order
+ * in which gemm4d walks column tiles first, default; 1 = row tiles first; same bits). */
 int zett_set_option(zett_hypernet* h, const char* key, int64_t value);
 
 /* ---- retokenizer ------------------------------------------------------------

@@ -55,6 +55,8 @@
 
 namespace zett {
 
+__device__ int g4dx_cfg[2] = {4, 0};     // GROUP_M, map mode of the PF = 230 variant
+
 // PF > 0: every K step also touches one dword of each 128-byte operand line of step t+PF (one load per wave
 // and operand into a junk register that is never read): the lines are in L2 when their LDS-DMA request is
 // issued PF-2 steps later.  LDS holds two steps, so a request has one step to land - less than a miss to
@@ -68,16 +70,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     const int nwg = tiles_m * tiles_n;
     int wg = blockIdx.x;
-    {
+    // PF = 230: tile order read at run time from g4dx_cfg (tools/gemm_bench G4DX_GROUP_M / G4DX_MAP): the sweep behind
+    // the library's ZETT_GROUP_M.  map 0 = XCD chunks (each XCD a contiguous range of the order), 1 = no remap (the
+    // hardware's round-robin: neighbouring tiles of the order on different XCDs), 2 = XCD chunks, N-major groups.
+    const int map_mode = PF == 230 ? g4dx_cfg[1] : 0;
+    if (map_mode != 1) {
         const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
     }
-    constexpr int GROUP_M = (PF == 212 || PF == 213) ? 4 : PF == 214 ? 2 : PF == 215 ? 1 : PF == 216 ? 6 : 8;     // 212: 4 (M) x 8 (N) tiles per XCD + K start staggered by tn; 213: the mapping alone
-    const int group_size = GROUP_M * tiles_n;
-    const int first_m = (wg / group_size) * GROUP_M;
-    const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
-    const int tm = first_m + (wg % group_size) % gm;
-    const int tn = (wg % group_size) / gm;
+    const int GROUP_M = PF == 230 ? g4dx_cfg[0] : (PF == 212 || PF == 213) ? 4 : PF == 214 ? 2 : PF == 215 ? 1 : PF == 216 ? 6 : 8;
+    int tm, tn;
+    if (map_mode == 2) {          // groups of GROUP_M column tiles, row tiles outermost inside a group
+        const int group_size = GROUP_M * tiles_m;
+        const int first_n = (wg / group_size) * GROUP_M;
+        const int gn = (tiles_n - first_n) < GROUP_M ? (tiles_n - first_n) : GROUP_M;
+        tn = first_n + (wg % group_size) % gn;
+        tm = (wg % group_size) / gn;
+    } else {
+        const int group_size = GROUP_M * tiles_n;
+        const int first_m = (wg / group_size) * GROUP_M;
+        const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+        tm = first_m + (wg % group_size) % gm;
+        tn = (wg % group_size) / gm;
+    }
     const int m0 = tm * G256_BM, n0 = tn * G256_BN;
 
     const int tid = threadIdx.x;

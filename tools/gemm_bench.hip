@@ -122,6 +122,11 @@ int main(int argc, char** argv) {
     variants.push_back({"g4dqm2", launch_gemm4dx<bf16_t, 214>});
     variants.push_back({"g4dqm1", launch_gemm4dx<bf16_t, 215>});
     variants.push_back({"g4dqm6", launch_gemm4dx<bf16_t, 216>});
+    variants.push_back({"g4dv", launch_gemm4dx<bf16_t, 230>});
+    {
+        int cfg[2] = {getenv("G4DX_GROUP_M") ? atoi(getenv("G4DX_GROUP_M")) : 4, getenv("G4DX_MAP") ? atoi(getenv("G4DX_MAP")) : 0};
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(zett::g4dx_cfg), cfg, sizeof(cfg)));
+    }
     if (getenv("RING")) { variants.push_back({"g256r4", launch_gemm256r<bf16_t, 4>}); variants.push_back({"g256r5", launch_gemm256r<bf16_t, 5>}); }
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));
     CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES + 2048));

@@ -154,6 +154,7 @@ struct GemmArgs {
     int ldw;     // elements
     int M, N, K;
     GemmEpilogue<T> epi;
+    int tile_order = 0;     // gemm4d only: 0 = column-tile-major groups (default), 1 = row-tile-major groups (A/B option)
 };
 
 constexpr int GEMM_BM = 128;

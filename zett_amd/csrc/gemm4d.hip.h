@@ -62,12 +62,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
     }
-    constexpr int GROUP_M = ZETT_GROUP_M;
-    const int group_size = GROUP_M * tiles_n;
-    const int first_m = (wg / group_size) * GROUP_M;
-    const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
-    const int tm = first_m + (wg % group_size) % gm;
-    const int tn = (wg % group_size) / gm;
+    // Tile order: each XCD owns a contiguous range of the order (remap above); the order walks the GROUP_N column tiles
+    // of a group first, then steps one row tile down, so the 32 tiles an XCD runs at a time are 8 row tiles x 4 column
+    // tiles and its next 32 are the next 8 row tiles of the SAME 4 column tiles: the W panels (the small operand, MALL-
+    // resident) stay, the A panels stream.  Against row-major groups of 4 (what gemm8r/gemm8x use): +5 % on the
+    // K = 8192 launches, equal on the others (tools/gemm_bench g4dv, G4DX_MAP / G4DX_GROUP_M sweep).
+    constexpr int GROUP_N = 4;
+    int tm, tn;
+    if (g.tile_order == 0) {
+        const int group_size = GROUP_N * tiles_m;
+        const int first_n = (wg / group_size) * GROUP_N;
+        const int gn = (tiles_n - first_n) < GROUP_N ? (tiles_n - first_n) : GROUP_N;
+        tn = first_n + (wg % group_size) % gn;
+        tm = (wg % group_size) / gn;
+    } else {                      // zett_set_option("gemm_tile_order", 1): ZETT_GROUP_M row tiles first, as gemm8r / gemm8x
+        constexpr int GROUP_M = ZETT_GROUP_M;
+        const int group_size = GROUP_M * tiles_n;
+        const int first_m = (wg / group_size) * GROUP_M;
+        const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+        tm = first_m + (wg % group_size) % gm;
+        tn = (wg % group_size) / gm;
+    }
     const int m0 = tm * G256_BM, n0 = tn * G256_BN;
 
     const int tid = threadIdx.x;

@@ -70,6 +70,7 @@ struct zett_hypernet {
     int64_t max_chunk_tokens = 131072;     // ~90 KB of workspace per packed position at H = 4096: 11.8 GB per chunk
     int time_gemm = 0;
     int cls_only_last = 1;
+    int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
                                       // 4 = 256x256 register-staged (4 waves), 5 = 256x256 LDS-DMA, 6 = as 2 on 16x16x32 MFMAs
     // workspace
@@ -355,6 +356,9 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
         h->time_gemm = value != 0;
     } else if (k == "cls_only_last_layer") {
         h->cls_only_last = value != 0;
+    } else if (k == "gemm_tile_order") {
+        if (value < 0 || value > 1) return fail(ZETT_E_INVALID, "gemm_tile_order must be 0 or 1");
+        h->gemm_tile_order = (int)value;
     } else if (k == "gemm_variant") {
         if (value < 0 || value > 7) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto) or 1..7 (128x128, 256x256 register-staged, 384x256, 256x256 four-wave, 256x256 LDS-DMA, 256x256 register-staged on 16x16x32 MFMAs, 256x256 four-wave direct-to-LDS)");
         h->gemm_variant = (int)value;
@@ -448,6 +452,7 @@ struct Runner {
     void gemm(const T* A, int lda, const T* Wp, int ldw, int M, int N, int K, const GemmEpilogue<T>& e) {
         if (rc || M <= 0) return;
         GemmArgs<T> g{A, lda, Wp, ldw, M, N, K, e};
+        g.tile_order = h->gemm_tile_order;
         const double fl = 2.0 * (double)M * (double)N * (double)K;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->time_gemm) {
