@@ -284,7 +284,7 @@ def main():
     peak = PEAK_TFLOPS[args.precision]
 
     # HBM traffic of the dominant kernel comes from PMC counters, which cannot be read from inside this
-    # process: the figure is the one measured by the committed rocprofv3 passes (profiles/r1k_pmc.md,
+    # process: the figure is the one measured by the committed rocprofv3 passes (profiles/r1l_pmc.md,
     # tools/pmc_summary.py --json) for this same command, and only quoted for the workload it was taken on.
     traffic = None
     try:
