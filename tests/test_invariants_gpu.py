@@ -97,6 +97,14 @@ def test_repeated_launches_identical_bits_small_grids():
         for it in range(12):
             assert _eq(_run(eng, ids, src, -1), auto), f"gemm_variant {variant}, launch {it}"
     eng.set_option("gemm_variant", 0)
+    # the order in which workgroups take tiles is not allowed to matter either
+    eng.set_option("gemm_tile_order", 1)
+    big = synth.make_surface_forms(cfg, 3000, seed=4, hist=hist, n_special=1)
+    alt = _run(eng, big, src, -1)
+    eng.set_option("gemm_tile_order", 0)
+    assert _eq(_run(eng, big, src, -1), alt)
+    with pytest.raises(ValueError):
+        eng.set_option("gemm_tile_order", 2)
 
 
 def test_pad_content_independence():
