@@ -74,13 +74,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the library's ZETT_GROUP_M.  map 0 = XCD chunks (each XCD a contiguous range of the order), 1 = no remap (the
     // hardware's round-robin: neighbouring tiles of the order on different XCDs), 2 = XCD chunks, N-major groups.
     const int map_mode = PF == 230 ? g4dx_cfg[1] : 0;
-    if (map_mode != 1) {
+    if (map_mode != 1 && map_mode != 3) {
         const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
     }
     const int GROUP_M = PF == 230 ? g4dx_cfg[0] : (PF == 212 || PF == 213) ? 4 : PF == 214 ? 2 : PF == 215 ? 1 : PF == 216 ? 6 : 8;
     int tm, tn;
-    if (map_mode == 2) {          // groups of GROUP_M column tiles, row tiles outermost inside a group
+    if (map_mode >= 2) {          // (3 = as 2 without the XCD remap) groups of GROUP_M column tiles, row tiles outermost inside a group
         const int group_size = GROUP_M * tiles_m;
         const int first_n = (wg / group_size) * GROUP_M;
         const int gn = (tiles_n - first_n) < GROUP_M ? (tiles_n - first_n) : GROUP_M;
