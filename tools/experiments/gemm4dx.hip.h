@@ -49,6 +49,9 @@
 
 #include "gemm4d.hip.h"
 
+#ifndef G4DX_AUX
+#define G4DX_AUX 0      // cache-policy bits of the LDS-DMA requests (gfx940: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 #ifndef G4D_ABL
 #define G4D_ABL 0      // ablation bits for tools/gemm_bench (results are garbage when set): 1 no DMA in the loop,
 #endif                 // 2 no B1/B2, 4 no B3/B4 + vmcnt waits, 8 no fragment reads in the loop, 16 no s_barrier (waits kept), 32 no vmcnt waits (barriers kept)
@@ -139,13 +142,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         int ks = kt + stag; if (ks >= nk) ks -= nk;
         if (G4D_ABL & 64) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(junk4) : "v"(a_voff[r]), "s"(a_rsrc), "s"(ks * GEMM_ROW_BYTES)); return; }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(my_rows + (kt & 1) * G256_STAGE_BYTES + r * 8 * GEMM_ROW_BYTES), 16,
-                                                 a_voff[r], ks * GEMM_ROW_BYTES, 0, 0);
+                                                 a_voff[r], ks * GEMM_ROW_BYTES, 0, G4DX_AUX);
     };
     auto dma_w = [&](int kt, int r) {
         int ks = kt + stag; if (ks >= nk) ks -= nk;
         if (G4D_ABL & 64) { asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(junk4) : "v"(w_voff[r]), "s"(w_rsrc), "s"(ks * GEMM_ROW_BYTES)); return; }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(my_rows + (kt & 1) * G256_STAGE_BYTES + G256_OPERAND_BYTES + r * 8 * GEMM_ROW_BYTES), 16,
-                                                 w_voff[r], ks * GEMM_ROW_BYTES, 0, 0);
+                                                 w_voff[r], ks * GEMM_ROW_BYTES, 0, G4DX_AUX);
     };
 
     f32x4 acc[8][8];                 // 128x128 per wave as 8x8 tiles of 16x16
