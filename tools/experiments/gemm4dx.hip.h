@@ -211,6 +211,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int p = kb * 64 + i * 8 + j;
+            if constexpr (PF == 240) {
+                // schedule 5: ONE barrier per step (p = 102): it both admits the block-0 reads of step kt+1 (vmcnt) and
+                // releases stage cur (every wave read its last fragment of it before p = 31).  The 16 requests of step
+                // kt+2 follow at p = 103..126 (12 slots x 2 waves) and, in the next step, p = 0..39: half a step to land.
+                // Measured: correct, and 7-13 % SLOWER than schedule 3 on real operands (1 607 vs 1 984 TFLOP/s on zeros):
+                // with half a step of lookahead the vmcnt wait does stall.  A request needs about one K step to land;
+                // the number of barriers (1, 2, 3 or 4 per step) is not what separates these schedules.
+                if (p == 102 && more) {
+                    __builtin_amdgcn_s_waitcnt(g4d_wait_vm(0));
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma16_agpr<T>(acc[i][j], fa[kb][i], fw[kb][j]);
+                if (p < 16 && (p & 1) == 0) read_w(cur, 1, p >> 1);
+                if (p >= 16 && p <= 30 && (p & 1) == 0) read_a(cur, 1, (p - 16) >> 1);
+                // requests of step kt+2 (issued in step kt after the barrier) and of step kt+1 (the rest, issued here)
+                if (more2 && p >= 103 && p < 127 && WV == ((p - 103) & 3)) dma_w(kt + 2, (p - 103) >> 2);          // W 0..5
+                if (more && p < 40 && WV == (p & 3)) {
+                    const int r = p >> 2;                                                                   // 0..9
+                    if (r < 2) dma_w(kt + 1, 6 + r); else dma_a(kt + 1, r - 2);
+                }
+                if (more && p >= 103 && p <= 110) read_w(cur ^ 1, 0, p - 103);
+                if (more && p >= 111 && p <= 125 && (p & 1) == 1) read_a(cur ^ 1, 0, (p - 111) >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             if constexpr (PF >= 220) {
                 // schedule 4: as 3 with the block-1 reads one per MFMA (p = 0..15), 12 MFMAs of slack before the release
                 // barrier (p = 28), requests over p = 30..93, landed barrier at p = 96, 31 slots for the 16 block-0 reads

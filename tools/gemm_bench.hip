@@ -123,6 +123,7 @@ int main(int argc, char** argv) {
     variants.push_back({"g4dqm1", launch_gemm4dx<bf16_t, 215>});
     variants.push_back({"g4dqm6", launch_gemm4dx<bf16_t, 216>});
     variants.push_back({"g4dv", launch_gemm4dx<bf16_t, 230>});
+    variants.push_back({"g4d1b", launch_gemm4dx<bf16_t, 240>});
     {
         int cfg[2] = {getenv("G4DX_GROUP_M") ? atoi(getenv("G4DX_GROUP_M")) : 4, getenv("G4DX_MAP") ? atoi(getenv("G4DX_MAP")) : 0};
         CK(hipMemcpyToSymbol(HIP_SYMBOL(zett::g4dx_cfg), cfg, sizeof(cfg)));
