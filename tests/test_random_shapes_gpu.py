@@ -24,7 +24,7 @@ def _cases():
                    hn_num_attention_heads=heads, separate_out_embeddings=bool(rng.integers(2)), hn_embed_lang_id=bool(rng.integers(2)),
                    hn_rescale_embeddings=bool(rng.integers(2)), hn_predict_bias=bool(rng.integers(2)), hn_single_head=bool(rng.integers(2)),
                    hn_surface_maxlen=int(rng.choice([1, 3, 7, 8])))
-        out.append((k, cfg, int(rng.integers(1, 700)), int(rng.choice([0, 2, 6])) if k % 3 else 7))
+        out.append((k, cfg, int(rng.integers(1, 700)), int(rng.choice([0, 2, 8])) if k % 3 else 7))
     return out
 
 

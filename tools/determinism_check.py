@@ -10,7 +10,7 @@ for fixture, precision in [("fwd_real_xlmr_gpt2", "f16"), ("fwd_real_xlmr_gpt2",
     w = synth.make_weights(case["cfg"], case["seed"])
     src = synth.make_source_embeddings(case["cfg"], case["seed"], dtype=case["src_dtype"])
     model = util.hip_model(case["cfg"], w, precision)
-    for variant in (0, 1, 2, 3, 4, 5, 6):
+    for variant in (0, 1, 2, 3, 7, 8):
         import torch
         model.engine(torch.device("cuda:0")).set_option("gemm_variant", variant)
         ref = util.hip_forward(model, case["ids"], src, case["lang"])

@@ -1,6 +1,6 @@
 // gemm256.hip.h — the LDS-DMA 256x256 MFMA GEMM for gfx950 (tile variant 5: the round's first large-tile
 // kernel, since superseded as the default by the register-staged gemm8r.hip.h / gemm8x.hip.h, which are
-// 7-11 % faster) and the epilogue drain shared by every large tile (EpiDrain).  256x256 output tile, 8 waves,
+// 7-11 % faster) (the epilogue drain shared by every large tile, EpiDrain, lives in zett_amd/csrc/gemm_tile.hip.h).  256x256 output tile, 8 waves,
 // K staged 128 bytes per row and step straight from HBM/L2 into LDS by the LDS-DMA path
 // (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass), two LDS stages of
 // 64 KiB so the DMA of K-step t+1 runs under the MFMAs of K-step t, one barrier per step.
@@ -23,127 +23,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "gemm.hip.h"
+#include "gemm_tile.hip.h"
 
 namespace zett {
-
-constexpr int G256_BM = 256;
-constexpr int G256_BN = 256;
-constexpr int G256_OPERAND_BYTES = G256_BM * GEMM_ROW_BYTES;      // 32 KiB
-constexpr int G256_STAGE_BYTES = 2 * G256_OPERAND_BYTES;          // A + W = 64 KiB
-constexpr int G256_LDS_BYTES = 2 * G256_STAGE_BYTES;              // 128 KiB
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-template <typename T> __device__ __forceinline__ void store_out4(T* dst, float4 v);
-template <> __device__ __forceinline__ void store_out4<float>(float* dst, float4 v) { *(float4*)dst = v; }
-template <> __device__ __forceinline__ void store_out4<bf16_t>(bf16_t* dst, float4 v) {
-    *(uint2*)dst = make_uint2(pack2_lo<bf16_t>(v.x, v.y), pack2_lo<bf16_t>(v.z, v.w));
-}
-template <> __device__ __forceinline__ void store_out4<f16_t>(f16_t* dst, float4 v) {
-    *(uint2*)dst = make_uint2(pack2_lo<f16_t>(v.x, v.y), pack2_lo<f16_t>(v.z, v.w));
-}
-
-template <typename T> __device__ __forceinline__ void store_out8(T* dst, float4 a, float4 b);
-template <> __device__ __forceinline__ void store_out8<float>(float* dst, float4 a, float4 b) { *(float4*)dst = a; *(float4*)(dst + 4) = b; }
-template <> __device__ __forceinline__ void store_out8<bf16_t>(bf16_t* dst, float4 a, float4 b) {
-    *(uint4*)dst = make_uint4(pack2_lo<bf16_t>(a.x, a.y), pack2_lo<bf16_t>(a.z, a.w), pack2_lo<bf16_t>(b.x, b.y), pack2_lo<bf16_t>(b.z, b.w));
-}
-template <> __device__ __forceinline__ void store_out8<f16_t>(f16_t* dst, float4 a, float4 b) {
-    *(uint4*)dst = make_uint4(pack2_lo<f16_t>(a.x, a.y), pack2_lo<f16_t>(a.z, a.w), pack2_lo<f16_t>(b.x, b.y), pack2_lo<f16_t>(b.z, b.w));
-}
-
-// Epilogue drain shared by the large-tile kernels.  One wave has staged ROWS x COLS fp32
-// accumulators (row stride COLS floats) in its private LDS region; every lane takes EIGHT
-// consecutive columns of a row, so the 16-bit output is one global_store_dwordx4 per lane and
-// instruction: stores are issue-bound (a wave instruction costs about the same whatever its
-// width; MI355X_MICROARCH.md "store tail"), and with four columns per lane the bf16 output of a
-// 256x256 tile took 10 us.  The two 16-byte LDS reads of a lane are ordered so that the lane
-// groups of ds_read_b128 hit 16 distinct bank quads (rows are a multiple of 256 bytes apart):
-// the second half first for odd rows (COLS = 64) / for the upper half of the row (COLS = 128).
-//
-// Order of a pass: residual rows requested first, all at once (load_res), the caller stages the
-// accumulators, one explicit vmcnt(0), then a drain without any load in it.  Loads and stores
-// share the vmcnt counter: a wait for a residual value placed between stores also waits for
-// every earlier store to be acknowledged — one full write latency per row group, which the
-// first version of this epilogue paid (11 us per tile).
-// SCALE = false: the caller guarantees epi.scale == nullptr (saves the 16 scale/shift registers).
-// NTF32 = false: never use the non-temporal store path (callers whose register budget is exhausted).
-template <typename T, int ACT, bool RES, int ROWS, int COLS, bool SCALE = true, bool NTF32 = true>
-struct EpiDrain {
-    static constexpr int LPR = COLS / 8;       // lanes per row
-    static constexpr int RPI = 64 / LPR;       // rows per wave instruction
-    static constexpr int NIT = ROWS / RPI;     // instructions per pass
-
-    static __device__ __forceinline__ void load_res(const GemmArgs<T>& g, int row0, int gcol, bool col_ok, int lane, float4 (&oa)[NIT], float4 (&ob)[NIT]) {
-        if (!RES) return;
-#pragma unroll
-        for (int t = 0; t < NIT; ++t) {
-            const int grow = row0 + t * RPI + lane / LPR;
-            const bool ok = grow < g.M && col_ok;
-            const float* src = g.epi.residual + (size_t)grow * g.epi.ld_res + gcol;
-            oa[t] = ok ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
-            ob[t] = ok ? *(const float4*)(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-
-    static __device__ __forceinline__ void drain(const GemmArgs<T>& g, const float* region, int row0, int gcol, bool col_ok, int lane,
-                                                 const float4 (&bias8)[2], const float4 (&sc8)[2], const float4 (&sh8)[2], float4 (&oa)[NIT], float4 (&ob)[NIT]) {
-        const GemmEpilogue<T>& e = g.epi;
-        const int idx = lane % LPR;
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool has_scale = SCALE && e.scale != nullptr;
-        // non-temporal fp32 stores for the residual epilogue of long-K launches (+3..6 % there: tools/gemm_bench
-        // EPI=2; at K = 1024, where a CU is in an epilogue a third of the time, they cost 12 %)
-        const bool nt_f32 = NTF32 && RES && g.K >= 2048;
-#pragma unroll
-        for (int t = 0; t < NIT; ++t) {
-            const int lrow = t * RPI + lane / LPR;
-            const int sw = COLS == 128 ? (idx >> 3) : (lrow & 1);
-            const float* src = region + lrow * COLS + idx * 8;
-            const float4 first = *(const float4*)(src + 4 * sw), second = *(const float4*)(src + 4 * (sw ^ 1));
-            const float4 lo = sw ? second : first, hi = sw ? first : second;
-            oa[t] = epi_value4<ACT>(lo, bias8[0], RES, RES ? oa[t] : zero, has_scale, sc8[0], sh8[0]);
-            ob[t] = epi_value4<ACT>(hi, bias8[1], RES, RES ? ob[t] : zero, has_scale, sc8[1], sh8[1]);
-        }
-#pragma unroll
-        for (int t = 0; t < NIT; ++t) {
-            const int grow = row0 + t * RPI + lane / LPR;
-            if (grow >= g.M || !col_ok) continue;
-            if (gcol < e.split_col) {
-                if (e.out_f32) {
-                    float* d = e.out_f32 + (size_t)grow * e.ld_f32 + gcol;
-                    if (nt_f32) {      // streamed once to the LayerNorm kernel: keep it out of the L2 the operand panels live in
-                        // (inline asm: two IR stores that differ only in the nontemporal hint get merged into a plain one)
-                        const f32x4 va = {oa[t].x, oa[t].y, oa[t].z, oa[t].w}, vb = {ob[t].x, ob[t].y, ob[t].z, ob[t].w};
-                        // (s_nop 1: the two wait states hipcc itself leaves between a >8-byte store and a VALU write
-                        //  of its data registers; it does not know this block is a store)
-                        asm volatile("global_store_dwordx4 %0, %1, off nt\n\tglobal_store_dwordx4 %0, %2, off offset:16 nt\n\ts_nop 1"
-                                     :: "v"(d), "v"(va), "v"(vb) : "memory");
-                    } else {
-                        *(float4*)d = oa[t];
-                        *(float4*)(d + 4) = ob[t];
-                    }
-                }
-                if (e.out_lo) store_out8<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, oa[t], ob[t]);
-            } else if (e.out_f32_b) {
-                float* d = e.out_f32_b + (size_t)grow * e.ld_f32 + (gcol - e.split_col);
-                *(float4*)d = oa[t]; *(float4*)(d + 4) = ob[t];
-            }
-        }
-    }
-
-    // bias / scale / shift of the lane's eight columns
-    static __device__ __forceinline__ void load_cols(const GemmEpilogue<T>& e, int gcol, bool col_ok, float4 (&bias8)[2], float4 (&sc8)[2], float4 (&sh8)[2]) {
-        bias8[0] = bias8[1] = sh8[0] = sh8[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        sc8[0] = sc8[1] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (!col_ok) return;
-        if (e.bias) { bias8[0] = *(const float4*)(e.bias + gcol); bias8[1] = *(const float4*)(e.bias + gcol + 4); }
-        if (SCALE && e.scale) { sc8[0] = *(const float4*)(e.scale + gcol); sc8[1] = *(const float4*)(e.scale + gcol + 4); }
-        if (SCALE && e.shift) { sh8[0] = *(const float4*)(e.shift + gcol); sh8[1] = *(const float4*)(e.shift + gcol + 4); }
-    }
-};
 
 // VAR (experiments, tools/gemm_bench): bit 0 = spread the DMA issue over the 4 K chunks of a step,
 // bit 1 = s_setprio(1) around the MFMA groups.  The library instantiates VAR = 1.

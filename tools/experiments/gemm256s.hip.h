@@ -11,7 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../zett_amd/csrc/gemm256.hip.h"
+#include "gemm256.hip.h"
 
 namespace zett {
 

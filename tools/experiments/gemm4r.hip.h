@@ -33,13 +33,10 @@
 
 #include <type_traits>
 
-#include "gemm256.hip.h"
+#include "gemm_tile.hip.h"
 
 namespace zett {
 
-constexpr int G4R_RSRC_WORD3 = 0x00020000;   // raw buffer, DATA_FORMAT_32 (gfx9 resource word 3)
-
-constexpr int G4R_WAIT_LGKM0 = 0xC07F;     // s_waitcnt lgkmcnt(0), vmcnt/expcnt untouched
 
 template <typename T, int ACT = ACT_NONE, bool RES = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4r_tn_kernel(GemmArgs<T> g) {

@@ -15,7 +15,7 @@
 
 #include <type_traits>
 
-#include "../../zett_amd/csrc/gemm256.hip.h"
+#include "gemm256.hip.h"
 
 namespace zett {
 

@@ -7,7 +7,7 @@
 
 #include <type_traits>
 
-#include "../../zett_amd/csrc/gemm8x.hip.h"
+#include "gemm8x.hip.h"
 
 namespace zett {
 

@@ -108,6 +108,8 @@ int main(int argc, char** argv) {
     variants.push_back({"g8r", launch_gemm8r<bf16_t>});
     variants.push_back({"g8p", launch_gemm8p<bf16_t>});
     variants.push_back({"g8x", launch_gemm8x<bf16_t>});
+    variants.push_back({"p4d", [](const GemmArgs<bf16_t>& g, hipStream_t st) { return launch_gemm4d<bf16_t>(g, st, false); }});      // the product kernel, streamlined epilogues
+    variants.push_back({"p4dg", [](const GemmArgs<bf16_t>& g, hipStream_t st) { return launch_gemm4d<bf16_t>(g, st, true); }});      // the product kernel, generic drain
     variants.push_back({"g4d", launch_gemm4dx<bf16_t>});
     variants.push_back({"g4dt4", launch_gemm4dx<bf16_t, 4>});
     variants.push_back({"g4ds1", launch_gemm4dx<bf16_t, 101>});
@@ -157,7 +159,7 @@ int main(int argc, char** argv) {
             if (o.find(std::string(",") + variants[v].name + ",") != std::string::npos) kept.push_back(variants[v]);
         variants = kept;
     }
-    const char* epi_env = getenv("EPI");     // 0 = bf16 out only, 1 = bias+gelu_erf bf16 out, 2 = bias+residual f32 out, 3 = bias+gelu_tanh, 4 = bias+scale/shift f32+bf16 out, 5 = bias+residual f32 out only
+    const char* epi_env = getenv("EPI");     // 0 = bf16 out only, 1 = bias+gelu_erf bf16 out, 2 = bias+residual f32+bf16 out, 3 = bias+gelu_tanh, 4 = bias+scale/shift f32+bf16 out, 5 = bias+residual f32 out only, 6 = bias+gelu_tanh+residual f32 out, 7 = bias+scale/shift f32 out
     const int epi_mode = epi_env ? atoi(epi_env) : 0;
     const int rounds = getenv("ROUNDS") ? atoi(getenv("ROUNDS")) : 5;
     const int burst = getenv("BURST") ? atoi(getenv("BURST")) : 3;      // back-to-back launches per timing
@@ -190,6 +192,8 @@ int main(int argc, char** argv) {
             else if (epi_mode == 1) { g.epi.bias = bias; g.epi.act = ACT_GELU_ERF; g.epi.out_lo = out; g.epi.ld_lo = N; }
             else if (epi_mode == 3) { g.epi.bias = bias; g.epi.act = ACT_GELU_TANH; g.epi.out_lo = out; g.epi.ld_lo = N; }
             else if (epi_mode == 5) { g.epi.bias = bias; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N; }   // the library's residual launches: fp32 out only
+            else if (epi_mode == 6) { g.epi.bias = bias; g.epi.act = ACT_GELU_TANH; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N; }   // ProjectorBlock dense2
+            else if (epi_mode == 7) { g.epi.bias = bias; g.epi.scale = res; g.epi.shift = bias; g.epi.out_f32 = cf; g.epi.ld_f32 = N; }   // output head with Rescaler
             else if (epi_mode == 4) { g.epi.bias = bias; g.epi.scale = res; g.epi.shift = bias; g.epi.out_f32 = cf; g.epi.ld_f32 = N; g.epi.out_lo = out; g.epi.ld_lo = N; }
             else { g.epi.bias = bias; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N; g.epi.out_lo = out; g.epi.ld_lo = N; }
             return g;

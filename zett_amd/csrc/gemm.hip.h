@@ -126,6 +126,109 @@ __device__ __forceinline__ float4 epi_value4(float4 a, float4 bias, bool has_res
                        epi_value<ACT>(a.z, bias.z, has_res, res.z, has_scale, sc.z, sh.z), epi_value<ACT>(a.w, bias.w, has_res, res.w, has_scale, sc.w, sh.w));
 }
 
+// The same epilogue over NV values of one lane, written stage by stage on pairs of values (the packed fp32
+// operations of the vector ALU): every statement below is one operation of epi_value applied to all NV values
+// before the next operation starts, so the NV/2 dependency chains interleave.  The element-at-a-time form above
+// compiles to one dependent chain of packed operations per pair of values, ~100 cycles per value with one wave per
+// SIMD, and the machine scheduler rebuilds that order from any source order (it minimises live ranges; a
+// sched_barrier does not hold pure arithmetic in place): the empty volatile asm statements between the stages do,
+// because they keep their own order — a pair can run at most one stage ahead of the others.
+// Operation for operation the arithmetic of epi_value: identical bits.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+#define ZETT_PIN_STAGE(arr, n) do { _Pragma("unroll") for (int e_ = 0; e_ < (n); ++e_) asm volatile("" : "+v"((arr)[e_])); } while (0)
+
+template <int ACT, bool HAS_RES, bool HAS_SCALE, int NV>
+__device__ __forceinline__ void epi_values(float (&vs)[NV], const float (&bias)[NV], const float (&res)[NV], const float (&sc)[NV], const float (&sh)[NV]) {
+#pragma clang fp contract(off)
+    static_assert(NV % 2 == 0, "pairs");
+    constexpr int NP = NV / 2;
+    f32x2 v[NP];
+#pragma unroll
+    for (int e = 0; e < NP; ++e) v[e] = f32x2{vs[2 * e], vs[2 * e + 1]} + f32x2{bias[2 * e], bias[2 * e + 1]};
+    if (ACT == ACT_GELU_TANH) {
+        f32x2 u2[NP], t[NP];
+        ZETT_PIN_STAGE(v, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) u2[e] = (v[e] * v[e]) * v[e];
+        ZETT_PIN_STAGE(u2, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) u2[e] = 1.5957691216057308f * __builtin_elementwise_fma(f32x2{0.044715f, 0.044715f}, u2[e], v[e]);
+        ZETT_PIN_STAGE(u2, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) u2[e] = u2[e] * 1.4426950408889634f;
+        ZETT_PIN_STAGE(u2, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) t[e] = f32x2{__builtin_amdgcn_exp2f(u2[e].x), __builtin_amdgcn_exp2f(u2[e].y)};
+        ZETT_PIN_STAGE(t, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) t[e] = 1.0f + t[e];
+        ZETT_PIN_STAGE(t, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) t[e] = f32x2{__builtin_amdgcn_rcpf(t[e].x), __builtin_amdgcn_rcpf(t[e].y)};
+        ZETT_PIN_STAGE(t, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) t[e] = 1.0f - 2.0f * t[e];
+        ZETT_PIN_STAGE(t, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) v[e] = (0.5f * v[e]) * (1.0f + t[e]);
+        ZETT_PIN_STAGE(v, NP);
+    } else if (ACT == ACT_GELU_ERF) {
+        f32x2 z[NP], ax[NP], t[NP], p[NP], ex[NP];
+        ZETT_PIN_STAGE(v, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) z[e] = v[e] * 0.70710678118654752440f;
+        ZETT_PIN_STAGE(z, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) ax[e] = __builtin_elementwise_abs(z[e]);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) t[e] = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, ax[e], f32x2{1.0f, 1.0f});
+        ZETT_PIN_STAGE(t, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) t[e] = f32x2{__builtin_amdgcn_rcpf(t[e].x), __builtin_amdgcn_rcpf(t[e].y)};
+        ZETT_PIN_STAGE(t, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) ex[e] = (ax[e] * ax[e]) * -1.4426950408889634f;
+        ZETT_PIN_STAGE(ex, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) ex[e] = f32x2{__builtin_amdgcn_exp2f(ex[e].x), __builtin_amdgcn_exp2f(ex[e].y)};
+        ZETT_PIN_STAGE(ex, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) p[e] = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t[e], f32x2{-1.453152027f, -1.453152027f});
+        ZETT_PIN_STAGE(p, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) p[e] = __builtin_elementwise_fma(p[e], t[e], f32x2{1.421413741f, 1.421413741f});
+        ZETT_PIN_STAGE(p, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) p[e] = __builtin_elementwise_fma(p[e], t[e], f32x2{-0.284496736f, -0.284496736f});
+        ZETT_PIN_STAGE(p, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) p[e] = __builtin_elementwise_fma(p[e], t[e], f32x2{0.254829592f, 0.254829592f});
+        ZETT_PIN_STAGE(p, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) p[e] = -(p[e] * t[e]);
+        ZETT_PIN_STAGE(p, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) p[e] = __builtin_elementwise_fma(p[e], ex[e], f32x2{1.0f, 1.0f});
+        ZETT_PIN_STAGE(p, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) p[e] = 1.0f + __builtin_elementwise_copysign(p[e], z[e]);
+        ZETT_PIN_STAGE(p, NP);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) v[e] = (v[e] * 0.5f) * p[e];
+        ZETT_PIN_STAGE(v, NP);
+    }
+    if (HAS_RES) {
+#pragma unroll
+        for (int e = 0; e < NP; ++e) v[e] = v[e] + f32x2{res[2 * e], res[2 * e + 1]};
+    }
+    if (HAS_SCALE) {
+#pragma unroll
+        for (int e = 0; e < NP; ++e) v[e] = __builtin_elementwise_fma(f32x2{sc[2 * e], sc[2 * e + 1]}, v[e], f32x2{sh[2 * e], sh[2 * e + 1]});
+    }
+#pragma unroll
+    for (int e = 0; e < NP; ++e) { vs[2 * e] = v[e].x; vs[2 * e + 1] = v[e].y; }
+}
+
 // Row-wise epilogue description (all pointers device, nullable unless noted).
 //   v = acc + bias[col]; v = act(v); v += residual[row, col]; v = scale[col]*v + shift[col]
 //   col <  split_col -> out_f32[row*ld_f32 + col], out_lo[row*ld_lo + col]

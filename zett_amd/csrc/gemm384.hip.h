@@ -18,7 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "gemm256.hip.h"
+#include "gemm_tile.hip.h"
 
 namespace zett {
 
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 
     // ---- epilogue: accumulators through a private 8 KiB LDS region per wave (32 rows x 64 fp32),
-    // four passes (one per 32-row MFMA tile row), drained by EpiDrain (gemm256.hip.h).
+    // four passes (one per 32-row MFMA tile row), drained by EpiDrain (gemm_tile.hip.h).
     __syncthreads();
     float* region = (float*)(smem + wave * 8192);
     typedef EpiDrain<T, ACT, RES, 32, 64, false> Drain;      // no scale/shift: launch_gemm384 refuses such epilogues

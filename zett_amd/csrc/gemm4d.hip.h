@@ -1,9 +1,10 @@
 // gemm4d.hip.h — tile variant 7: 256x256 tile, FOUR waves (one per SIMD, 128x128 of the tile each), both operands
 // streamed HBM/L2 -> LDS by buffer_load_dwordx4 ... lds (no VGPR round trip, no ds_write pass), on
 // v_mfma_f32_16x16x32_{bf16,f16} with the 256 accumulator registers pinned to AGPRs.  The tile of every 16-bit
-// launch with K >= 2048: with the 4 x 8 tile order (ZETT_GROUP_M = 4) 4-8 % faster than gemm8x on the shapes of
-// the benchmark step, residual or not (tools/gemm_bench), 5 % slower at K = 1024.  Same geometry as the hipBLASLt kernel the yardstick runs; the experiments that led
-// here (ablations, K-start staggering, schedules with 3-4 barriers) are in tools/experiments/gemm4dx.hip.h.
+// launch with K >= 2048: 4-8 % faster than the register-staged eight-wave kernels on the shapes of the benchmark step,
+// residual or not (tools/gemm_bench), 5 % slower at K = 1024.  Same geometry as the hipBLASLt kernel the yardstick
+// runs; the experiments that led here (ablations, K-start staggering, schedules with 3-4 barriers) are in
+// tools/experiments/gemm4dx.hip.h.
 //
 //   C[M,N] = epilogue( A[M,K] · W[N,K]ᵀ )      (contract and epilogue of gemm.hip.h; bit-identical results)
 //
@@ -19,9 +20,24 @@
 // Fragments are double-buffered in 128 VGPRs.  A wave reads 32 KiB of fragments per step for 128 MFMAs: a third
 // less LDS traffic per FLOP than the eight-wave kernels, and no LDS write traffic from the waves.
 //
-// LDS image and swizzle as in gemm256.hip.h: per stage and operand 256 rows x 128 B, 16-byte chunks
+// LDS image and swizzle of gemm_tile.hip.h: per stage and operand 256 rows x 128 B, 16-byte chunks
 // XOR-swizzled by (row>>1)&7, applied to each lane's SOURCE address and undone on the ds_read_b128 side.
 // The K reduction order per accumulator is that of every other tile variant.
+//
+// Epilogue (r2).  A per-tile timeline (tools/experiments/trace4d.hip) showed 8 / 17 / 19 us of epilogue (plain bf16
+// / erf-GELU / fp32 residual) behind an 80-88 us K loop at K = 4096, none of it memory latency: the generic drain of
+// gemm_tile.hip.h spends its time on run-time epilogue flags (select chains, exec-mask branches), on a dependent
+// packed-FMA chain per pair of GELU values, and on 16-byte accesses with 16-byte holes for fp32 rows (half the
+// per-CU rate alone, a tenth under load: tools/experiments/store_bench.hip).  The three epilogues that carry the
+// benchmark step are therefore compiled as their own instantiations (EPI below): everything about the output is a
+// template parameter, fp32 rows and residual rows are read and written as whole 512-byte row segments (four
+// columns per lane), the 16-bit output as 256-byte segments (eight columns per lane), the staged rows are padded
+// by four floats so both read patterns are conflict-free without per-lane reordering, the residual rows of BOTH
+// passes are requested before the first store leaves (loads and stores share one in-order counter: a load issued
+// behind a store cannot be waited for without waiting for the store), the GELUs are evaluated stage by stage over
+// all values of a lane so that the chains interleave, and the last barrier moves into the last K step so that a
+// wave starts staging as soon as its own MFMAs are done.  Same arithmetic per element (epi_value's operations in
+// epi_value's order): identical bits, checked against the generic drain (gemm_variant 8) by the tile-variant test.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -29,7 +45,7 @@
 
 #include <type_traits>
 
-#include "gemm8x.hip.h"
+#include "gemm_tile.hip.h"
 
 namespace zett {
 
@@ -49,10 +65,37 @@ template <> __device__ __forceinline__ void mfma16_agpr<f16_t>(f32x4& c, const u
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
-template <typename T, int ACT = ACT_NONE, bool RES = false>
+#ifdef G4D_TRACE
+// per-tile timeline (tools/experiments/trace4d.hip): [block]{start, K loop begins, K loop ends, end, hw id} in 10 ns ticks
+__device__ unsigned long long g4d_trace[32768 * 8];
+// wave 0's epilogue: {barrier+cols, then per pass: residual loads issued, staged in LDS, vmcnt(0), drain issued; all stores acknowledged}
+__device__ unsigned long long g4d_trace_epi[32768 * 16];
+__device__ int g4d_stagger_ticks, g4d_stagger_mode;
+#endif
+
+// EPI: which epilogue the instantiation carries.
+//   GENERIC    EpiDrain of gemm_tile.hip.h: every combination of outputs, decided at run time
+//   LO         only the 16-bit output (out_lo), bias + ACT            (QKV, FFN up, ProjectorBlock dense1)
+//   F32        only the fp32 output (out_f32), bias + ACT + residual  (attention output, FFN down, dense2, heads)
+//   F32_SCALE  as F32 with the Rescaler (scale, shift)                (output heads)
+enum { G4D_EPI_GENERIC = 0, G4D_EPI_LO = 1, G4D_EPI_F32 = 2, G4D_EPI_F32_SCALE = 3 };
+constexpr int G4D_EPI_STRIDE = 132;                                   // floats per staged row: 128 columns + 4 of padding
+constexpr int G4D_EPI_REGION = 64 * G4D_EPI_STRIDE * 4;               // bytes per wave
+constexpr int G4D_LDS_BYTES = 4 * G4D_EPI_REGION;                     // 132 KiB (the K loop uses the first 128)
+static_assert(G4D_LDS_BYTES >= G256_LDS_BYTES && G4D_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+template <typename T, int ACT = ACT_NONE, bool RES = false, int EPI = G4D_EPI_GENERIC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4d_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
+#ifdef G4D_TRACE
+    if (g4d_stagger_ticks > 0 && blockIdx.x < 256) {      // experiment: XCD x of the first round starts x/8 of the spread late
+        const unsigned long long t_in = wall_clock64();
+        const unsigned long long d = (unsigned long long)g4d_stagger_ticks * (g4d_stagger_mode == 0 ? (blockIdx.x & 7) : (blockIdx.x >> 3) & 7) / 8;
+        while (wall_clock64() - t_in < d) __builtin_amdgcn_s_sleep(8);
+    }
+    const unsigned long long tr0 = wall_clock64();
+#endif
 
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
@@ -180,7 +223,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int p = kb * 64 + i * 8 + j;
-            if (p == 36 && more2) {         // this wave has every fragment of stage cur in registers
+            // (last step, streamlined epilogues: the barrier every wave passes after its last fragment read, so that
+            //  staging the accumulators over the operand images needs no barrier behind the loop)
+            if (p == 36 && (more2 || (!more && EPI != G4D_EPI_GENERIC))) {         // this wave has every fragment of stage cur in registers
                 __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -200,6 +245,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+#ifdef G4D_TRACE
+    const unsigned long long tr1 = wall_clock64();
+#endif
     typedef std::integral_constant<bool, true> yes_t;
     typedef std::integral_constant<bool, false> no_t;
     auto k_loop = [&](auto wave_c) {
@@ -213,65 +261,247 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else if (wave == 2) k_loop(std::integral_constant<int, 2>{});
     else k_loop(std::integral_constant<int, 3>{});
 
-    // ---- epilogue: each wave stages its 128x128 quadrant through a private 32 KiB LDS region
-    // (64 rows x 128 fp32), two passes, drained by EpiDrain (gemm256.hip.h).
     asm volatile("s_nop 15\n\ts_nop 15");     // last MFMA (8 passes) -> first accumulator read
-    __syncthreads();
-    float* region = (float*)(smem + wave * 32768);
-    typedef EpiDrain<T, ACT, RES, 64, 128, true, false> Drain;
+#ifdef G4D_TRACE
+    const unsigned long long tr2 = wall_clock64();
+    unsigned long long trp[2][4] = {};
+    unsigned long long tr2b = tr2;
+#endif
     // the lane-derived indices of the epilogue are recomputed from an opaque copy of the thread id: kept alive
     // across the K loop (the compiler shares them with the prologue's) they are what no longer fits in 256 VGPRs
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63;
     const int l15 = lane_e & 15, kq = lane_e >> 4;
-    const int gcol = n0 + wn * 128 + (lane_e % Drain::LPR) * 8;
-    const bool col_ok = gcol < g.N;
-    float4 bias8[2], sc8[2], sh8[2];
-    Drain::load_cols(g.epi, gcol, col_ok, bias8, sc8, sh8);
+    if constexpr (EPI == G4D_EPI_GENERIC) {
+        // ---- generic epilogue: each wave stages its 128x128 quadrant through a private 32 KiB LDS region
+        // (64 rows x 128 fp32), two passes, drained by EpiDrain (gemm_tile.hip.h).
+        __syncthreads();
+        float* region = (float*)(smem + wave * 32768);
+        typedef EpiDrain<T, ACT, RES, 64, 128, true, false> Drain;
+        const int gcol = n0 + wn * 128 + (lane_e % Drain::LPR) * 8;
+        const bool col_ok = gcol < g.N;
+        float4 bias8[2], sc8[2], sh8[2];
+        Drain::load_cols(g.epi, gcol, col_ok, bias8, sc8, sh8);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        float4 oa[Drain::NIT], ob[Drain::NIT];
-        const int row0 = m0 + wm * 128 + p * 64;
-        Drain::load_res(g, row0, gcol, col_ok, lane_e, oa, ob);
+        for (int p = 0; p < 2; ++p) {
+            float4 oa[Drain::NIT], ob[Drain::NIT];
+            const int row0 = m0 + wm * 128 + p * 64;
+            Drain::load_res(g, row0, gcol, col_ok, lane_e, oa, ob);
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4)
+            for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    region[(i4 * 16 + kq * 4 + r) * 128 + j * 16 + l15] = acc[4 * p + i4][j][r];
-        if (RES || p == 0) __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
-        Drain::drain(g, region, row0, gcol, col_ok, lane_e, bias8, sc8, sh8, oa, ob);
+                    for (int r = 0; r < 4; ++r)
+                        region[(i4 * 16 + kq * 4 + r) * 128 + j * 16 + l15] = acc[4 * p + i4][j][r];
+            if (RES || p == 0) __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
+            Drain::drain(g, region, row0, gcol, col_ok, lane_e, bias8, sc8, sh8, oa, ob);
+        }
+    } else {
+        // ---- streamlined epilogues (see the header).  No barrier here: the last K step carries it.
+        constexpr bool LO = EPI == G4D_EPI_LO, SCALE = EPI == G4D_EPI_F32_SCALE;
+        constexpr int CPL = LO ? 8 : 4;            // columns per lane
+        constexpr int LPR = 128 / CPL;             // lanes per row
+        constexpr int RPI = 64 / LPR;              // rows per wave instruction
+        constexpr int NIT = 64 / RPI;              // instructions per pass
+        static_assert(!(LO && RES), "the 16-bit-only epilogue has no residual");
+        float* region = (float*)(smem + wave * G4D_EPI_REGION);
+        const GemmEpilogue<T>& e = g.epi;
+        const int idx = lane_e % LPR, rsub = lane_e / LPR;
+        const int gcol = n0 + wn * 128 + idx * CPL;
+        const bool col_ok = gcol < g.N;
+        const int grow0 = m0 + wm * 128 + rsub;    // the lane's row in instruction t of pass p: grow0 + p*64 + t*RPI
+        float bias[CPL], sc[CPL], sh[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { bias[c] = 0.f; sc[c] = 1.f; sh[c] = 0.f; }
+        if (col_ok) {
+#pragma unroll
+            for (int c4 = 0; c4 < CPL; c4 += 4) {
+                if (e.bias) { const float4 b = *(const float4*)(e.bias + gcol + c4); bias[c4] = b.x; bias[c4 + 1] = b.y; bias[c4 + 2] = b.z; bias[c4 + 3] = b.w; }
+                if (SCALE) {
+                    const float4 a = *(const float4*)(e.scale + gcol + c4), b = *(const float4*)(e.shift + gcol + c4);
+                    sc[c4] = a.x; sc[c4 + 1] = a.y; sc[c4 + 2] = a.z; sc[c4 + 3] = a.w;
+                    sh[c4] = b.x; sh[c4 + 1] = b.y; sh[c4 + 2] = b.z; sh[c4 + 3] = b.w;
+                }
+            }
+        }
+        // residual rows of both passes: requested before any store leaves (pass 1's right after pass 0 is staged, by
+        // which time the accumulators of pass 0 have left their registers)
+        float4 res[2][RES ? NIT : 1];
+        auto load_res = [&](int p) {
+            if constexpr (RES) {
+#pragma unroll
+                for (int t = 0; t < NIT; ++t) {
+                    const int grow = grow0 + p * 64 + t * RPI;
+                    res[p][t] = (grow < g.M && col_ok) ? *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        auto stage = [&](int p) {
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        region[(i4 * 16 + kq * 4 + r) * G4D_EPI_STRIDE + j * 16 + l15] = acc[4 * p + i4][j][r];
+        };
+        // FULL: all 64 rows and all 128 columns of the pass lie inside the matrix (wave-uniform): no predicate anywhere.
+        // fp32 rows behind a residual go out non-temporal: they are streamed once to the LayerNorm kernel and stay out
+        // of the L2 the operand panels live in (+3..6 % on those launches, tools/gemm_bench EPI=2).
+        auto drain = [&](int p, auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+            // GROUP instructions at a time: their LDS reads, then their arithmetic stage by stage, then their stores
+            constexpr int GROUP = (LO || RES) ? 4 : 8;      // 32 values per lane and group (16 beside the 256 residual registers)
+            constexpr int NV = GROUP * CPL;
+#pragma unroll
+            for (int t0 = 0; t0 < NIT; t0 += GROUP) {
+                float v[NV], bb[NV], rr[NV], ss[NV], hh[NV];
+#pragma unroll
+                for (int u = 0; u < GROUP; ++u) {
+                    const float* src = region + ((t0 + u) * RPI + rsub) * G4D_EPI_STRIDE + idx * CPL;
+#pragma unroll
+                    for (int c4 = 0; c4 < CPL; c4 += 4) {
+                        const float4 x = *(const float4*)(src + c4);
+                        v[u * CPL + c4] = x.x; v[u * CPL + c4 + 1] = x.y; v[u * CPL + c4 + 2] = x.z; v[u * CPL + c4 + 3] = x.w;
+                    }
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) { bb[u * CPL + c] = bias[c]; ss[u * CPL + c] = sc[c]; hh[u * CPL + c] = sh[c]; rr[u * CPL + c] = 0.f; }
+                    if constexpr (RES) {
+                        const float4 x = res[p][t0 + u];
+                        rr[u * CPL] = x.x; rr[u * CPL + 1] = x.y; rr[u * CPL + 2] = x.z; rr[u * CPL + 3] = x.w;
+                    }
+                }
+                epi_values<ACT, RES, SCALE, NV>(v, bb, rr, ss, hh);
+#pragma unroll
+                for (int u = 0; u < GROUP; ++u) {
+                    const int grow = grow0 + p * 64 + (t0 + u) * RPI;
+                    if (!FULL && (grow >= g.M || !col_ok)) continue;
+                    if constexpr (LO) {
+                        const float4 a = make_float4(v[u * 8], v[u * 8 + 1], v[u * 8 + 2], v[u * 8 + 3]);
+                        const float4 b = make_float4(v[u * 8 + 4], v[u * 8 + 5], v[u * 8 + 6], v[u * 8 + 7]);
+                        store_out8<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, a, b);
+                    } else {
+                        float* d = e.out_f32 + (size_t)grow * e.ld_f32 + gcol;
+                        const f32x4 x = {v[u * 4], v[u * 4 + 1], v[u * 4 + 2], v[u * 4 + 3]};
+                        if (RES) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(d), "v"(x) : "memory");
+                        else *(f32x4*)d = x;
+                    }
+                }
+            }
+        };
+        auto drain_pass = [&](int p) {
+            const bool full = m0 + wm * 128 + p * 64 + 64 <= g.M && n0 + wn * 128 + 128 <= g.N;
+            if (full) drain(p, std::integral_constant<bool, true>{});
+            else drain(p, std::integral_constant<bool, false>{});
+        };
+#ifdef G4D_TRACE
+        tr2b = wall_clock64();
+#endif
+        load_res(0);
+#ifdef G4D_TRACE
+        trp[0][0] = wall_clock64();
+#endif
+        stage(0);
+        __builtin_amdgcn_sched_barrier(0);         // (pass 1's residual registers only exist once pass 0's accumulators are staged)
+        load_res(1);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef G4D_TRACE
+        __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
+        trp[0][1] = trp[0][2] = wall_clock64();
+#endif
+        drain_pass(0);
+#ifdef G4D_TRACE
+        trp[0][3] = trp[1][0] = wall_clock64();
+#endif
+        stage(1);
+#ifdef G4D_TRACE
+        __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
+        trp[1][1] = trp[1][2] = wall_clock64();
+#endif
+        drain_pass(1);
+#ifdef G4D_TRACE
+        trp[1][3] = wall_clock64();
+#endif
     }
+#ifdef G4D_TRACE
+    __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
+    if (tid_e == 0 && blockIdx.x < 32768) {
+        unsigned long long* o = g4d_trace + (size_t)blockIdx.x * 8;
+        o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = wall_clock64(); o[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        o[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+        unsigned long long* q = g4d_trace_epi + (size_t)blockIdx.x * 16;
+        q[0] = tr2b - tr2;
+        for (int p = 0; p < 2; ++p) { q[1 + 4 * p] = trp[p][0] - tr2; q[2 + 4 * p] = trp[p][1] - tr2; q[3 + 4 * p] = trp[p][2] - tr2; q[4 + 4 * p] = trp[p][3] - tr2; }
+        q[9] = o[3] - tr2;
+    }
+#endif
 }
 
-template <typename T, int ACT, bool RES>
+// Which epilogue a launch gets.  force_generic: zett_set_option("gemm_variant", 8) (A/B and the bit-identity test).
+template <typename T>
+inline int gemm4d_epi_mode(const GemmArgs<T>& g) {
+    const GemmEpilogue<T>& e = g.epi;
+    if (e.out_f32_b || e.split_col < g.N) return G4D_EPI_GENERIC;
+    if (e.out_lo && !e.out_f32 && !e.residual && !e.scale && !e.shift && g.N % 8 == 0 && e.ld_lo % 8 == 0) return G4D_EPI_LO;
+    if (e.out_f32 && !e.out_lo && g.N % 4 == 0 && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0)) {
+        if (e.scale && e.shift && !e.residual && e.act == ACT_NONE) return G4D_EPI_F32_SCALE;
+        // (instantiated: no activation with or without the residual, tanh-GELU with it; anything else is generic)
+        if (!e.scale && !e.shift && (e.act == ACT_NONE || (e.act == ACT_GELU_TANH && e.residual))) return G4D_EPI_F32;
+    }
+    return G4D_EPI_GENERIC;
+}
+
+// Per-device opt-in to > 64 KiB of dynamic LDS: the attribute belongs to the function ON A DEVICE, and one process may
+// drive several (one handle per device).
+struct DeviceFlags {
+    bool set[64] = {};
+    bool* current() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+        return &set[d];
+    }
+};
+
+template <typename T, int ACT, bool RES, int EPI>
 inline hipError_t launch_gemm4d_inst(const GemmArgs<T>& g, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm4d_tn_kernel<T, ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
+    constexpr int lds = EPI == G4D_EPI_GENERIC ? G256_LDS_BYTES : G4D_LDS_BYTES;
+    static DeviceFlags attr;
+    bool* done = attr.current();
+    if (!done || !*done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm4d_tn_kernel<T, ACT, RES, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (done) *done = true;
     }
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
-    hipLaunchKernelGGL((gemm4d_tn_kernel<T, ACT, RES>), dim3(tiles_m * tiles_n), dim3(256), G256_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm4d_tn_kernel<T, ACT, RES, EPI>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, g);
     return hipGetLastError();
 }
 
 template <typename T, int ACT>
-inline hipError_t launch_gemm4d_act(const GemmArgs<T>& g, hipStream_t stream) {
-    return g.epi.residual ? launch_gemm4d_inst<T, ACT, true>(g, stream) : launch_gemm4d_inst<T, ACT, false>(g, stream);
+inline hipError_t launch_gemm4d_act(const GemmArgs<T>& g, hipStream_t stream, int mode) {
+    const bool res = g.epi.residual != nullptr;
+    switch (mode) {
+        case G4D_EPI_LO: return launch_gemm4d_inst<T, ACT, false, G4D_EPI_LO>(g, stream);
+        case G4D_EPI_F32:
+            if constexpr (ACT == ACT_NONE) return res ? launch_gemm4d_inst<T, ACT, true, G4D_EPI_F32>(g, stream) : launch_gemm4d_inst<T, ACT, false, G4D_EPI_F32>(g, stream);
+            else if constexpr (ACT == ACT_GELU_TANH) { if (res) return launch_gemm4d_inst<T, ACT, true, G4D_EPI_F32>(g, stream); }
+            [[fallthrough]];
+        default: return res ? launch_gemm4d_inst<T, ACT, true, G4D_EPI_GENERIC>(g, stream) : launch_gemm4d_inst<T, ACT, false, G4D_EPI_GENERIC>(g, stream);
+    }
 }
 
 template <typename T>
-inline hipError_t launch_gemm4d(const GemmArgs<T>& g, hipStream_t stream) {
+inline hipError_t launch_gemm4d(const GemmArgs<T>& g, hipStream_t stream, bool force_generic = false) {
+    const int mode = force_generic ? G4D_EPI_GENERIC : gemm4d_epi_mode(g);
+    if (mode == G4D_EPI_F32_SCALE) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE>(g, stream);
     switch (g.epi.act) {
-        case ACT_GELU_TANH: return launch_gemm4d_act<T, ACT_GELU_TANH>(g, stream);
-        case ACT_GELU_ERF: return launch_gemm4d_act<T, ACT_GELU_ERF>(g, stream);
-        default: return launch_gemm4d_act<T, ACT_NONE>(g, stream);
+        case ACT_GELU_TANH: return launch_gemm4d_act<T, ACT_GELU_TANH>(g, stream, mode);
+        case ACT_GELU_ERF: return launch_gemm4d_act<T, ACT_GELU_ERF>(g, stream, mode);
+        default: return launch_gemm4d_act<T, ACT_NONE>(g, stream, mode);
     }
 }
 

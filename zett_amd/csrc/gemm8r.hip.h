@@ -22,7 +22,7 @@
 
 #include <type_traits>
 
-#include "gemm4r.hip.h"
+#include "gemm_tile.hip.h"
 
 namespace zett {
 

@@ -30,11 +30,9 @@
 #include "../../include/zett_hip.h"
 #include "common.hip.h"
 #include "gemm.hip.h"
-#include "gemm256.hip.h"
+#include "gemm_tile.hip.h"
 #include "gemm384.hip.h"
-#include "gemm4r.hip.h"
 #include "gemm8r.hip.h"
-#include "gemm8x.hip.h"
 #include "gemm4d.hip.h"
 #include "rowops.hip.h"
 #include "retok.hip.h"
@@ -72,7 +70,7 @@ struct zett_hypernet {
     int cls_only_last = 1;
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
-                                      // 4 = 256x256 register-staged (4 waves), 5 = 256x256 LDS-DMA, 6 = as 2 on 16x16x32 MFMAs
+                                      // 7 = 256x256 four-wave direct-to-LDS, 8 = as 7 with the generic epilogue drain
     // workspace
     DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct;
     int32_t* host_pinned = nullptr;
@@ -360,7 +358,8 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
         if (value < 0 || value > 1) return fail(ZETT_E_INVALID, "gemm_tile_order must be 0 or 1");
         h->gemm_tile_order = (int)value;
     } else if (k == "gemm_variant") {
-        if (value < 0 || value > 7) return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto) or 1..7 (128x128, 256x256 register-staged, 384x256, 256x256 four-wave, 256x256 LDS-DMA, 256x256 register-staged on 16x16x32 MFMAs, 256x256 four-wave direct-to-LDS)");
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 7 && value != 8)
+            return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto), 1 (128x128), 2 (256x256 register-staged), 3 (384x256), 7 (256x256 four-wave direct-to-LDS) or 8 (7 with the generic epilogue drain)");
         h->gemm_variant = (int)value;
     } else {
         return fail(ZETT_E_INVALID, "unknown option %s", key);
@@ -434,19 +433,9 @@ struct Runner {
 
     long a_rows_readable = 0;   // rows every A operand buffer can be read for (workspace slack)
 
-    static hipError_t launch_16(const GemmArgs<T>& g, hipStream_t s) {
+    static hipError_t launch_4d(const GemmArgs<T>& g, hipStream_t s, bool generic_epilogue) {
         if constexpr (std::is_same<T, float>::value) return hipErrorInvalidValue;
-        else return launch_gemm8x<T>(g, s);
-    }
-
-    static hipError_t launch_4d(const GemmArgs<T>& g, hipStream_t s) {
-        if constexpr (std::is_same<T, float>::value) return hipErrorInvalidValue;
-        else return launch_gemm4d<T>(g, s);
-    }
-
-    static hipError_t launch_4r(const GemmArgs<T>& g, hipStream_t s) {
-        if constexpr (std::is_same<T, float>::value) return hipErrorInvalidValue;
-        else return launch_gemm4r<T>(g, s);
+        else return launch_gemm4d<T>(g, s, generic_epilogue);
     }
 
     void gemm(const T* A, int lda, const T* Wp, int ldw, int M, int N, int K, const GemmEpilogue<T>& e) {
@@ -474,9 +463,9 @@ struct Runner {
         // (168 per wave: it would spill to scratch, and no kernel with scratch is ever launched)
         // and does not clamp rows, so A must have
         // `a_rows_readable` >= tiles*384 rows (every A operand here is a workspace buffer with
-        // that slack) and N must be a multiple of 256.  The four-wave kernel (4, 16-bit types
-        // only) and the LDS-DMA kernel (5) stay selectable: the steps that led to gemm8r, within
-        // 2-12 % of it, bit-identical.
+        // that slack) and N must be a multiple of 256.  (The kernels that led to gemm8r and gemm4d
+        // -- four-wave register-staged, eight-wave LDS-DMA, gemm8r on 16x16x32 MFMAs -- live in
+        // tools/experiments/ with tools/gemm_bench.)
         constexpr bool is_f32 = std::is_same<T, float>::value;
         int variant = h->gemm_variant;
         if (variant == 0) {
@@ -488,11 +477,10 @@ struct Runner {
             }
         }
         if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift || e.residual)) variant = 2;
-        // 16-bit operands, K >= 2048: the four-wave direct-to-LDS tile on 16x16x32 MFMAs (4-8 % ahead of gemm8x on the
-        // launches of the benchmark step; identical bits).  gemm8x (variant 6) stays selectable.
+        // 16-bit operands, K >= 2048: the four-wave direct-to-LDS tile on 16x16x32 MFMAs (4-8 % ahead of the
+        // register-staged eight-wave kernels on the launches of the benchmark step; identical bits).
         if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= 2048) variant = 7;
-        if (variant == 7 && is_f32) variant = 2;
-        if ((variant == 4 || variant == 6) && is_f32) variant = 2;
+        if ((variant == 7 || variant == 8) && is_f32) variant = 2;
         // the large tiles drain eight columns per lane with 16-byte accesses
         const bool wide_ok = N % 8 == 0 && (!e.out_lo || e.ld_lo % 8 == 0) && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0) &&
                              (e.split_col >= N || e.split_col % 8 == 0);
@@ -500,10 +488,8 @@ struct Runner {
         if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
         hipError_t err;
         switch (variant) {
-            case 7: err = launch_4d(g, st); break;
-            case 6: err = launch_16(g, st); break;
-            case 5: err = launch_gemm256<T, 1>(g, st); break;
-            case 4: err = launch_4r(g, st); break;
+            case 8: err = launch_4d(g, st, true); break;
+            case 7: err = launch_4d(g, st, false); break;
             case 3: err = launch_gemm384<T>(g, st); break;
             case 2: err = launch_gemm8r<T>(g, st); break;
             default: err = launch_gemm<T>(g, st); break;
@@ -785,7 +771,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 (void)hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]);
                 const auto& sh = h->ev_shape[i / 2];
                 fprintf(stderr, "[zett gemm] M=%6d N=%6d K=%5d tile=%s %8.3f ms %7.1f TF\n", sh[0], sh[1], sh[2],
-                        sh[3] == 7 ? "4d " : sh[3] == 6 ? "8x " : sh[3] == 5 ? "dma" : sh[3] == 4 ? "4r " : sh[3] == 3 ? "384" : sh[3] == 2 ? "8r " : "128", t, h->ev_flops[i / 2] / (t * 1e9));
+                        sh[3] == 7 ? "4d " : sh[3] == 8 ? "4dg" : sh[3] == 3 ? "384" : sh[3] == 2 ? "8r " : "128", t, h->ev_flops[i / 2] / (t * 1e9));
             }
         }
     }
