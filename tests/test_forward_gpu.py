@@ -13,7 +13,7 @@ REAL = util.golden_cases("fwd_real_*.npz")
 
 
 def _check(case, out, precision):
-    close = {"f32": util.assert_f32_close, "bf16": util.assert_bf16_close, "f16": util.assert_f16_close}[precision]
+    close = util.CLOSE[precision]
     close(out[0], case["pred_in"], f"{case['name']}[{precision}] pred_in")
     if case["pred_out"] is None:
         assert out[1] is None
@@ -26,7 +26,7 @@ def _check(case, out, precision):
 
 
 @pytest.mark.parametrize("path", TINY, ids=lambda p: p.split("/")[-1][:-4])
-@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16", "f16a9"])
 def test_tiny_golden(path, precision):
     case = util.load_case(path)
     w = synth.make_weights(case["cfg"], case["seed"])
@@ -37,7 +37,7 @@ def test_tiny_golden(path, precision):
 
 
 @pytest.mark.parametrize("path", REAL, ids=lambda p: p.split("/")[-1][:-4])
-@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16", "f16a9"])
 def test_real_shape_golden(path, precision):
     case = util.load_case(path)
     w = synth.make_weights(case["cfg"], case["seed"])

@@ -1,0 +1,147 @@
+"""Parity at BASELINE.json's full sizes (SURVEY.md §8d T1, configs C2-C5 and the north-star headline).
+
+Every configuration runs its whole target vocabulary through the C ABI on the GPU, in f16a9 (the default),
+bf16 and f16 arithmetic, and is checked three ways:
+
+  * a fixed sample of rows against `oracle.hypernet_ref.forward` (the as-written reference math in
+    numpy fp32, itself pinned to the reference by tests/golden) — this is where the 256x256 GEMM tiles
+    that carry the benchmark (gemm4d at K >= 2048, gemm8r below) meet the oracle DIRECTLY: the launches
+    have M = 20 000 .. 600 000 rows here, whereas the golden fixtures' 16-64 rows run on the 128x128 tile;
+  * the 8-way row-sharded result reassembles to the single-GPU result bit for bit (what the all-gather
+    of `predict_sharded` relies on), with the small per-shard launches taking other tile kernels;
+  * the encoder chunking (`max_chunk_tokens`) changes no bit: the 262 144-row Llama-3 workload needs
+    five chunks at the default limit, the others are additionally run with a limit that forces chunks.
+
+Also here: the heavy-tailed checkpoint.  The synthetic weights are N(0, 0.02^2); real checkpoints have
+outlier channels.  With Student-t (3 degrees of freedom) Linear weights, outlier LayerNorm gains and a
+heavy-tailed source table, f16a9 arithmetic (the default) and f16 stay inside their tolerances with the same
+margin as on normal weights; bf16 arithmetic lands at rel-L2 1.04e-2 at the 4096-wide shape — on the wrong side of the 1e-2
+line it clears by 3 % on normal weights (the operand rounding error of a dot product is relative, so it barely
+moves with the tails: it was on the edge before).  That measurement is why bf16 is not the default; the test pins
+bf16 to <= 1.2e-2 there so that the number stays visible.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from zett_amd import synth
+from zett_amd.dims import HypernetDims
+
+pytestmark = pytest.mark.gpu
+
+SAMPLE_ROWS = 96
+
+
+def _engine(cfg, weights, precision):
+    from zett_amd.hypernet import HipEngine
+    dev = torch.device("cuda:0")
+    eng = HipEngine(HypernetDims.from_config(cfg), 1e-5, dev, precision)
+    eng.load_weights(weights)
+    return eng
+
+
+def _run(eng, ids, src, lang):
+    out = eng.forward(torch.as_tensor(ids).to(eng.device), src, lang)
+    torch.cuda.synchronize()
+    return out
+
+
+def _eq(a, b):
+    return all((x is None and y is None) or torch.equal(x, y) for x, y in zip(a, b))
+
+
+def _check_sample(full, want, sample, precision, what):
+    close = util.CLOSE[precision]
+    idx = torch.from_numpy(sample).cuda()
+    for got, ref, name in zip(full, want, ("pred_in", "pred_out", "bias")):
+        if ref is None:
+            assert got is None
+            continue
+        close(got[idx].cpu().numpy(), ref, f"{what} {precision} {name}")
+
+
+@pytest.mark.parametrize("name", ["xlmr_gpt2", "tinyllama_neox", "mistral_gpt2_32k", "mistral_neox", "llama3_256k"])
+def test_full_size_parity(name):
+    from bench import device_weights
+    from oracle import hypernet_ref
+    from zett_amd.sharding import shard_bounds
+
+    cfg, rows, src_dtype, hist = synth.workload(name)
+    dev = torch.device("cuda:0")
+    weights = device_weights(cfg, dev, seed=0)
+    src_np = synth.make_source_embeddings(cfg, 0, dtype=src_dtype)
+    src = torch.from_numpy(src_np).cuda()
+    ids = synth.make_surface_forms(cfg, rows, seed=0, hist=hist, n_special=2)
+    lang = 3 if cfg.get("hn_embed_lang_id") else -1
+    # oracle on a row sample that always holds the two all-pad rows' neighbours, the first and the last row
+    rng = np.random.default_rng(0)
+    sample = np.unique(np.concatenate([[2, 3, rows - 1], rng.choice(np.arange(2, rows), SAMPLE_ROWS - 3, replace=False)]))
+    hypernet_ref.set_matmul_backend("torch")
+    want = hypernet_ref.forward({k: v.float().cpu().numpy() for k, v in weights.items()}, cfg, ids[sample], src_np, None if lang < 0 else lang)
+    for precision in ("f16a9", "bf16", "f16"):
+        eng = _engine(cfg, weights, precision)
+        full = _run(eng, ids, src, lang)
+        assert all(t is None or bool(torch.isfinite(t).all()) for t in full)
+        st = eng.stats()
+        assert st["rows"] == rows and 0 < st["packed_tokens"] <= rows * 8 and 0 < st["distinct_ids"]
+        if name == "llama3_256k":
+            assert st["chunks"] >= 5, st["chunks"]          # 131 072 packed positions per chunk, ~620 k in the workload
+        _check_sample(full, want, sample, precision, name)
+        if precision == "f16a9":
+            parts = [_run(eng, ids[slice(*shard_bounds(rows, 8, r))], src, lang) for r in range(8)]
+            cat = [None if parts[0][k] is None else torch.cat([p[k] for p in parts]) for k in range(3)]
+            assert _eq(cat, full), f"{name}: 8 row shards differ from the whole vocabulary"
+            del parts, cat
+            if name != "llama3_256k":                        # force several encoder chunks
+                eng.set_option("max_chunk_tokens", 24576)
+                chunked = _run(eng, ids, src, lang)
+                assert eng.stats()["chunks"] >= 3
+                assert _eq(chunked, full), f"{name}: encoder chunking changed the result"
+                del chunked
+        eng.close()
+        del full
+
+
+def _student_t(gen, shape, device, std):
+    """Student-t with 3 degrees of freedom, scaled to the given standard deviation (variance of t3 is 3)."""
+    z = torch.randn(shape, device=device, generator=gen)
+    chi = torch.randn((3,) + tuple(shape), device=device, generator=gen).square_().sum(0).div_(3.0).sqrt_()
+    return z.div_(chi).mul_(std / 3.0 ** 0.5)
+
+
+@pytest.mark.parametrize("name,rows", [("tinyllama_neox", 4096), ("mistral_gpt2_32k", 2048)])
+def test_heavy_tailed_checkpoint_stays_inside_tolerance(name, rows):
+    from bench import device_weights
+    from oracle import hypernet_ref
+
+    cfg, _, src_dtype, hist = synth.workload(name)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    weights = device_weights(cfg, dev, seed=7)
+    for k in list(weights):
+        w = weights[k]
+        if w.dim() == 2 and w.shape[0] > 1 and w.shape[1] > 1 and not k.endswith("embeddings.weight"):
+            weights[k] = _student_t(gen, w.shape, dev, 0.02)                   # every Linear weight
+        elif k.endswith("LayerNorm.weight") or k.endswith("ln.weight"):
+            out = torch.rand(w.shape, device=dev, generator=gen) < 0.01        # 1 % outlier gains of 4..8
+            weights[k] = torch.where(out, 4.0 + 4.0 * torch.rand(w.shape, device=dev, generator=gen), w)
+    d = HypernetDims.from_config(cfg)
+    src = _student_t(gen, (d.original_vocab_size, d.n_in_embd), dev, 0.02)
+    ids = synth.make_surface_forms(cfg, rows, seed=7, hist=hist, n_special=1)
+    sample = np.arange(1, 129)
+    hypernet_ref.set_matmul_backend("torch")
+    want = hypernet_ref.forward({k: v.float().cpu().numpy() for k, v in weights.items()}, cfg, ids[sample], src.cpu().numpy(), None)
+    kurt = float(((src - src.mean()) ** 4).mean() / src.var() ** 2)
+    assert kurt > 6.0, kurt                                  # the table really is heavy-tailed (normal: 3)
+    for precision in ("f16a9", "f16", "bf16"):
+        eng = _engine(cfg, weights, precision)
+        full = _run(eng, ids, src, -1)
+        if precision != "bf16":
+            _check_sample(full, want, sample, precision, f"{name} heavy-tailed")
+        else:
+            idx = torch.from_numpy(sample).cuda()
+            for got, ref, what in zip(full, want, ("pred_in", "pred_out", "bias")):
+                util.assert_bf16_close(got[idx].cpu().numpy(), ref, f"{name} heavy-tailed bf16 {what}", rel_max=1.2e-2 if ref.ndim > 1 else 1.8e-2)
+        eng.close()

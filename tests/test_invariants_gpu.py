@@ -32,7 +32,7 @@ def _eq(a, b):
     return all((x is None and y is None) or torch.equal(x, y) for x, y in zip(a, b))
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("precision", ["f16a9", "bf16", "f16", "f32"])
 def test_row_order_shard_and_chunk_independence_tiny(precision):
     cfg, *_ = synth.workload("tiny")
     eng = _engine(cfg, 1, precision)
@@ -61,8 +61,8 @@ def test_row_order_shard_and_chunk_independence_tiny(precision):
             torch.testing.assert_close(a, b, rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("precision,name,rows", [("bf16", "tiny", 3000), ("f16", "tiny", 3000), ("f32", "tiny", 1500),
-                                                  ("bf16", "tinyllama_neox", 6000)])
+@pytest.mark.parametrize("precision,name,rows", [("bf16", "tiny", 3000), ("f16", "tiny", 3000), ("f16a9", "tiny", 3000), ("f32", "tiny", 1500),
+                                                  ("bf16", "tinyllama_neox", 6000), ("f16a9", "tinyllama_neox", 6000)])
 def test_gemm_tile_variants_bit_identical(precision, name, rows):
     """The GEMM kernels (128x128, 256x256 register-staged eight-wave, 384x256 LDS-DMA, 256x256 four-wave
     direct-to-LDS with its streamlined epilogues (7) and with the generic epilogue drain (8)) share one K
@@ -162,32 +162,7 @@ def test_empty_and_single_row():
     assert _eq([None if t is None else t[4:5] for t in nine], one)
 
 
-@pytest.mark.parametrize("name,rows", [("xlmr_gpt2", 50350), ("mistral_gpt2_32k", 32768)])
-def test_full_size_shards_equal_whole(name, rows):
-    """BASELINE.json sizes: the 8-way row-sharded result is bit-identical to the 1-GPU result,
-    outputs are finite, and a sample of rows matches the oracle."""
-    from oracle import hypernet_ref
-    from zett_amd.sharding import shard_bounds
-    cfg, _, src_dtype, hist = synth.workload(name)
-    eng = _engine(cfg, 0, "bf16")
-    src = torch.from_numpy(synth.make_source_embeddings(cfg, 0, dtype=src_dtype)).cuda()
-    ids = synth.make_surface_forms(cfg, rows, seed=0, hist=hist, n_special=2)
-    lang = 3 if cfg.get("hn_embed_lang_id") else -1
-    full = _run(eng, ids, src, lang)
-    assert all(t is None or bool(torch.isfinite(t).all()) for t in full)
-    st = eng.stats()
-    assert st["rows"] == rows and 0 < st["packed_tokens"] <= rows * 8 and 0 < st["distinct_ids"]
-    parts = [_run(eng, ids[slice(*shard_bounds(rows, 8, r))], src, lang) for r in range(8)]
-    cat = [None if parts[0][k] is None else torch.cat([p[k] for p in parts]) for k in range(3)]
-    assert _eq(cat, full)
-    if name == "xlmr_gpt2":     # oracle on a row sample (the big shapes are covered by the golden fixtures)
-        from bench import device_weights
-        w = {k: v.cpu().numpy() for k, v in device_weights(cfg, torch.device("cuda:0"), seed=0).items()}
-        sample = np.random.default_rng(0).choice(rows, 96, replace=False)
-        want = hypernet_ref.forward(w, cfg, ids[sample], src.cpu().numpy(), lang)
-        got = [None if t is None else t[torch.from_numpy(sample).cuda()].cpu().numpy() for t in full]
-        util.assert_bf16_close(got[0], want[0], "xlmr full-size sample pred_in")
-        util.assert_bf16_close(got[2], want[2], "xlmr full-size sample bias")
+# (full-size shard / chunk / oracle-sample checks: tests/test_full_size_gpu.py)
 
 
 def test_workspace_bytes_bounds_what_a_forward_reserves():

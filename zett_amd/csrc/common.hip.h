@@ -30,6 +30,23 @@ inline int fail(int code, const char* fmt, ...) {
             return ::zett::fail(ZETT_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+// Every ABI entry point works on its handle's device and leaves the calling thread's current device as it found it
+// (the caller may be a torch process holding several GPUs; zett_destroy can run from a garbage collector).
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device); else prev = -1;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define ZETT_ON_DEVICE(dev)                                                                          \
+    ::zett::DeviceScope _scope(dev);                                                                 \
+    if (_scope.err != hipSuccess) return ::zett::fail(ZETT_E_HIP, "hipSetDevice(%d) failed: %s", (int)(dev), hipGetErrorString(_scope.err))
+
 struct DevBuf {   // grow-only device allocation
     void* p = nullptr;
     size_t bytes = 0;

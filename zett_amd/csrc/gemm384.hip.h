@@ -149,11 +149,12 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 template <typename T, int ACT, bool RES>
 inline hipError_t launch_gemm384_inst(const GemmArgs<T>& g, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceFlags attr;      // per device: one process may hold a handle per GPU
+    bool* done = attr.current();
+    if (!done || !*done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm384_tn_kernel<T, ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G384_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (done) *done = true;
     }
     if (g.epi.scale || g.epi.shift) return hipErrorInvalidValue;      // register budget: EpiDrain<..., SCALE = false>
     const int tiles_m = (g.M + G384_BM - 1) / G384_BM;

@@ -84,6 +84,8 @@ constexpr int G4D_EPI_REGION = 64 * G4D_EPI_STRIDE * 4;               // bytes p
 constexpr int G4D_LDS_BYTES = 4 * G4D_EPI_REGION;                     // 132 KiB (the K loop uses the first 128)
 static_assert(G4D_LDS_BYTES >= G256_LDS_BYTES && G4D_LDS_BYTES <= 160 * 1024, "LDS budget");
 
+template <> __device__ __forceinline__ void mfma16_agpr<f16a_t>(f32x4& c, const u32x4& a, const u32x4& b) { mfma16_agpr<f16_t>(c, a, b); }
+
 template <typename T, int ACT = ACT_NONE, bool RES = false, int EPI = G4D_EPI_GENERIC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4d_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -452,17 +454,6 @@ inline int gemm4d_epi_mode(const GemmArgs<T>& g) {
     }
     return G4D_EPI_GENERIC;
 }
-
-// Per-device opt-in to > 64 KiB of dynamic LDS: the attribute belongs to the function ON A DEVICE, and one process may
-// drive several (one handle per device).
-struct DeviceFlags {
-    bool set[64] = {};
-    bool* current() {
-        int d = 0;
-        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
-        return &set[d];
-    }
-};
 
 template <typename T, int ACT, bool RES, int EPI>
 inline hipError_t launch_gemm4d_inst(const GemmArgs<T>& g, hipStream_t stream) {

@@ -201,11 +201,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <typename T, int ACT, bool RES>
 inline hipError_t launch_gemm8r_inst(const GemmArgs<T>& g, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceFlags attr;      // per device: one process may hold a handle per GPU
+    bool* done = attr.current();
+    if (!done || !*done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm8r_tn_kernel<T, ACT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (done) *done = true;
     }
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;

@@ -14,6 +14,17 @@
 
 namespace zett {
 
+// Per-device opt-in to > 64 KiB of dynamic LDS: the attribute belongs to the function ON A DEVICE, and one process may
+// drive several (one handle per device).
+struct DeviceFlags {
+    bool set[64] = {};
+    bool* current() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+        return &set[d];
+    }
+};
+
 constexpr int G4R_RSRC_WORD3 = 0x00020000;   // raw buffer, DATA_FORMAT_32 (gfx9 resource word 3)
 constexpr int G4R_WAIT_LGKM0 = 0xC07F;       // s_waitcnt lgkmcnt(0), vmcnt/expcnt untouched
 
@@ -35,6 +46,9 @@ template <> __device__ __forceinline__ void store_out4<f16_t>(f16_t* dst, float4
     *(uint2*)dst = make_uint2(pack2_lo<f16_t>(v.x, v.y), pack2_lo<f16_t>(v.z, v.w));
 }
 
+template <> __device__ __forceinline__ void store_out4<f16a_t>(f16a_t* dst, float4 v) {
+    *(uint2*)dst = make_uint2(pack2_lo<f16a_t>(v.x, v.y), pack2_lo<f16a_t>(v.z, v.w));
+}
 template <typename T> __device__ __forceinline__ void store_out8(T* dst, float4 a, float4 b);
 template <> __device__ __forceinline__ void store_out8<float>(float* dst, float4 a, float4 b) { *(float4*)dst = a; *(float4*)(dst + 4) = b; }
 template <> __device__ __forceinline__ void store_out8<bf16_t>(bf16_t* dst, float4 a, float4 b) {
@@ -42,6 +56,10 @@ template <> __device__ __forceinline__ void store_out8<bf16_t>(bf16_t* dst, floa
 }
 template <> __device__ __forceinline__ void store_out8<f16_t>(f16_t* dst, float4 a, float4 b) {
     *(uint4*)dst = make_uint4(pack2_lo<f16_t>(a.x, a.y), pack2_lo<f16_t>(a.z, a.w), pack2_lo<f16_t>(b.x, b.y), pack2_lo<f16_t>(b.z, b.w));
+}
+
+template <> __device__ __forceinline__ void store_out8<f16a_t>(f16a_t* dst, float4 a, float4 b) {
+    *(uint4*)dst = make_uint4(pack2_lo<f16a_t>(a.x, a.y), pack2_lo<f16a_t>(a.z, a.w), pack2_lo<f16a_t>(b.x, b.y), pack2_lo<f16a_t>(b.z, b.w));
 }
 
 // Epilogue drain shared by the large-tile kernels.  One wave has staged ROWS x COLS fp32

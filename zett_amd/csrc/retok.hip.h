@@ -458,7 +458,7 @@ int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(ZETT_E_INVALID, "device %d out of range", device);
-    HIP_TRY(hipSetDevice(device));
+    ZETT_ON_DEVICE(device);
     auto* r = new zett_retok();
     r->device = device;
     std::vector<int32_t> single(256, -1), bf(256, -1);
@@ -517,7 +517,7 @@ int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
 
 int zett_retok_destroy(zett_retok* r) {
     if (!r) return 0;
-    (void)hipSetDevice(r->device);
+    ::zett::DeviceScope _scope(r->device);
     for (void* p : r->owned) (void)hipFree(p);
     for (zett::DevBuf* b : {&r->raw, &r->raw_pos, &r->raw_off, &r->blk, &r->scratch, &r->misc}) b->release();
     if (r->host_pinned) (void)hipHostFree(r->host_pinned);
@@ -534,7 +534,7 @@ int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* of
     *n_truncated = 0;
     if (n_tokens == 0) return 0;
     if (!offsets || !out) return fail(ZETT_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(r->device));
+    ZETT_ON_DEVICE(r->device);
     hipStream_t st = (hipStream_t)stream;
     // total text length = offsets[n_tokens]
     int32_t* hp = r->host_pinned;

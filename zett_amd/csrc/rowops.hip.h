@@ -211,6 +211,10 @@ template <> __device__ __forceinline__ void store_lo4<f16_t>(f16_t* dst, float4 
     *(uint2*)dst = make_uint2(pack2_lo<f16_t>(v.x, v.y), pack2_lo<f16_t>(v.z, v.w));
 }
 
+template <> __device__ __forceinline__ void store_lo4<f16a_t>(f16a_t* dst, float4 v) {
+    *(uint2*)dst = make_uint2(pack2_lo<f16a_t>(v.x, v.y), pack2_lo<f16a_t>(v.z, v.w));
+}
+
 template <int SRC_DTYPE> __device__ __forceinline__ float4 load_src4(const void* base, size_t elem);
 template <> __device__ __forceinline__ float4 load_src4<0>(const void* base, size_t e) {
     return *(const float4*)((const float*)base + e);
@@ -381,6 +385,7 @@ template <typename T> __device__ __forceinline__ void load8_16bit(const T* p, fl
 }
 template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&o)[8]) { load8_16bit<bf16_t>(p, o); }
 template <> __device__ __forceinline__ void load8<f16_t>(const f16_t* p, float (&o)[8]) { load8_16bit<f16_t>(p, o); }
+template <> __device__ __forceinline__ void load8<f16a_t>(const f16a_t* p, float (&o)[8]) { load8_16bit<f16a_t>(p, o); }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&o)[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&o)[8]) {
     *(float4*)p = make_float4(o[0], o[1], o[2], o[3]);
@@ -391,6 +396,7 @@ template <typename T> __device__ __forceinline__ void store8_16bit(T* p, const f
 }
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&o)[8]) { store8_16bit<bf16_t>(p, o); }
 template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&o)[8]) { store8_16bit<f16_t>(p, o); }
+template <> __device__ __forceinline__ void store8<f16a_t>(f16a_t* p, const float (&o)[8]) { store8_16bit<f16a_t>(p, o); }
 
 // q: [T, ldq] per packed position, or (cls_only) [rows, ldq] holding the query of position 0
 // of each row; k, v: [T, ldkv]; ctx: [T or rows, H].  cls_only: compute query 0 only and

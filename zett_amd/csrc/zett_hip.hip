@@ -202,15 +202,16 @@ int zett_abi_version(void) { return ZETT_ABI_VERSION; }
 
 int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet** out) {
     if (!cfg || !out) return fail(ZETT_E_INVALID, "null argument");
-    if (precision != ZETT_PREC_BF16 && precision != ZETT_PREC_F32 && precision != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "unknown precision %d", precision);
+    if (precision != ZETT_PREC_BF16 && precision != ZETT_PREC_F32 && precision != ZETT_PREC_F16 && precision != ZETT_PREC_F16A9) return fail(ZETT_E_INVALID, "unknown precision %d", precision);
     if (int rc = validate_config(*cfg, precision)) return rc;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(ZETT_E_INVALID, "device %d out of range (%d visible)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
+    ZETT_ON_DEVICE(device);
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<f16a_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     auto* h = new zett_hypernet();
     h->cfg = *cfg;
     h->device = device;
@@ -221,7 +222,7 @@ int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet
 
 int zett_destroy(zett_hypernet* h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
+    ::zett::DeviceScope _scope(h->device);
     for (auto& kv : h->w) {
         if (kv.second.f32) (void)hipFree(kv.second.f32);
         if (kv.second.lo && kv.second.lo != (void*)kv.second.f32) (void)hipFree(kv.second.lo);
@@ -250,7 +251,7 @@ int zett_load_weight(zett_hypernet* h, const char* name, const void* data, int d
         for (auto v : it->second) b += std::to_string(v) + ",";
         return fail(ZETT_E_INVALID, "%s: shape [%s] does not match the config's [%s]", name, a.c_str(), b.c_str());
     }
-    HIP_TRY(hipSetDevice(h->device));
+    ZETT_ON_DEVICE(h->device);
     size_t numel = 1;
     for (auto v : got) numel *= (size_t)v;
     Tensor& t = h->w[n];
@@ -281,7 +282,7 @@ int zett_load_weight(zett_hypernet* h, const char* name, const void* data, int d
 int zett_finalize(zett_hypernet* h) {
     if (!h) return fail(ZETT_E_INVALID, "null handle");
     if (h->finalized) return 0;
-    HIP_TRY(hipSetDevice(h->device));
+    ZETT_ON_DEVICE(h->device);
     std::map<std::string, std::vector<int64_t>> exp;
     expected_shapes(h->cfg, exp);
     for (auto& kv : exp)
@@ -295,7 +296,7 @@ int zett_finalize(zett_hypernet* h) {
         if (h->precision == ZETT_PREC_F32) { t.lo = t.f32; continue; }
         HIP_TRY(hipMalloc(&t.lo, t.numel * 2));
         const int blocks = (int)std::min<size_t>((t.numel / 4 + 255) / 256 + 1, 65535);
-        if (h->precision == ZETT_PREC_F16)
+        if (h->precision == ZETT_PREC_F16 || h->precision == ZETT_PREC_F16A9)      // (F16A9 rounds activations only: weights keep 11 bits)
             hipLaunchKernelGGL(convert_f32_to_lo_kernel<f16_t>, dim3(blocks), dim3(256), 0, 0, t.f32, (f16_t*)t.lo, t.numel);
         else
             hipLaunchKernelGGL(convert_f32_to_lo_kernel<bf16_t>, dim3(blocks), dim3(256), 0, 0, t.f32, (bf16_t*)t.lo, t.numel);
@@ -401,8 +402,10 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
     if (v_src < c.original_vocab_size) return fail(ZETT_E_INDEX, "source_embeddings has %lld rows, config.original_vocab_size is %d", (long long)v_src, c.original_vocab_size);
     if (c.embed_lang && (lang_index < 0 || lang_index >= c.n_langs)) return fail(ZETT_E_INDEX, "lang_index %d outside [0,%d)", lang_index, c.n_langs);
     if (n_rows * (int64_t)(seq + 1) >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many positions for one call");
-    HIP_TRY(hipSetDevice(h->device));
+    ZETT_ON_DEVICE(h->device);
     hipStream_t st = (hipStream_t)stream;
+    if (h->precision == ZETT_PREC_F16A9)
+        return do_forward<f16a_t>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);
     if (h->precision == ZETT_PREC_F16)
         return do_forward<f16_t>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);
     if (h->precision == ZETT_PREC_BF16)
