@@ -40,7 +40,7 @@ sys.path.insert(0, REPO)
 from zett_amd import synth  # noqa: E402
 from zett_amd.dims import HypernetDims, weight_shapes  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16a9": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
 
 def device_weights(cfg, device, seed=0):
@@ -122,8 +122,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="mistral_gpt2_32k", choices=sorted(synth.WORKLOADS))
-    ap.add_argument("--precision", default="f16a9", choices=["bf16", "f16", "f16a9", "f32"],
-                    help="arithmetic of the dense contractions; f16a9 (half operands, 9-bit activations) is the library default (zett_amd/hypernet.py DEFAULT_PRECISION)")
+    ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "f32"],
+                    help="arithmetic of the dense contractions; f16 is the library default (zett_amd/hypernet.py DEFAULT_PRECISION)")
     ap.add_argument("--rows", type=int, default=0, help="override the vocab size of the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)

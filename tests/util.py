@@ -23,8 +23,6 @@ BF16_REL_L2 = 1e-2        # bf16-MFMA mode: ||y^ - y||_2 / ||y||_2 of a predicte
 BF16_REL_L2_VECTOR = 1.5e-2
 F16_COS = 0.99999         # f16-MFMA mode (11-bit significands): 8x tighter than bf16
 F16_REL_L2 = 2.5e-3
-F16A9_COS = 0.9999        # f16a9 mode (the default: half operands, activations rounded to 9 significant bits;
-F16A9_REL_L2 = 5e-3       # measured 1.5-3.6e-3): half the bf16 tolerance
 
 
 def golden_cases(pattern="fwd_*.npz"):
@@ -76,11 +74,7 @@ def assert_f16_close(got, want, what):
     assert_bf16_close(got, want, what, cos_min=F16_COS, rel_max=F16_REL_L2)
 
 
-def assert_f16a9_close(got, want, what):
-    assert_bf16_close(got, want, what, cos_min=F16A9_COS, rel_max=F16A9_REL_L2 if want.ndim > 1 else 1.5 * F16A9_REL_L2)
-
-
-CLOSE = {"f32": assert_f32_close, "bf16": assert_bf16_close, "f16": assert_f16_close, "f16a9": assert_f16a9_close}
+CLOSE = {"f32": assert_f32_close, "bf16": assert_bf16_close, "f16": assert_f16_close}
 
 
 def hip_model(cfg, weights, precision):

@@ -14,7 +14,7 @@ from .build import LIB_PATH
 ZETT_OK = 0
 E_INVALID, E_HIP, E_STATE, E_INDEX, E_NOT_IMPLEMENTED, E_KEY = -1, -2, -3, -4, -5, -6
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
-PREC_BF16, PREC_F32, PREC_F16, PREC_F16A9 = 0, 1, 2, 3
+PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
 RETOK_BPE, RETOK_UNIGRAM = 0, 1
 
 ABI_SYMBOLS = (

@@ -39,15 +39,6 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef uint16_t bf16_t;   // storage type of bf16 activations / weights
 typedef _Float16 f16_t;    // IEEE half: the third operand type (ZETT_PREC_F16)
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-// Fourth operand type (ZETT_PREC_F16A9): IEEE half operands on the f16 MFMAs, with every ACTIVATION the library
-// writes rounded to F16A_BITS significant bits (weights keep all 11).  Why: the GEMMs are power-limited, and the
-// energy of an MFMA grows with the significand bits that toggle in its activation operand.  Same box, headline
-// workload: bf16 590 k token-embeddings/s at rel-L2 0.97e-2 of the fp32 reference (1.04e-2 on a heavy-tailed
-// checkpoint: on the wrong side of the 1e-2 tolerance); f16 567 k (-3.9 %) at 0.12e-2; 9-bit activations 576 k
-// (-2.5 %) at 0.35e-2; 8-bit activations 583 k at 0.69e-2; rounding the WEIGHTS instead buys nothing
-// (gpurun_out/r2h).  A distinct type so that every kernel is instantiated for it like for the others.
-struct f16a_t { uint16_t bits; };
-constexpr int F16A_BITS = 9;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round to nearest even: v_cvt_pk_bf16_f32 on gfx950
@@ -71,15 +62,6 @@ template <> __device__ __forceinline__ uint32_t pack2_lo<f16_t>(float a, float b
     const h2 v = {(f16_t)a, (f16_t)b};
     return __builtin_bit_cast(uint32_t, v);
 }
-// round to nearest even at F16A_BITS significant bits (the activations of ZETT_PREC_F16A9)
-__device__ __forceinline__ float round_act_bits(float x) {
-    uint32_t u = __float_as_uint(x);
-    constexpr uint32_t drop = 24 - F16A_BITS;
-    u += ((1u << (drop - 1)) - 1u) + ((u >> drop) & 1u);
-    return __uint_as_float(u & ~((1u << drop) - 1u));
-}
-template <> __device__ __forceinline__ uint32_t pack2_lo<f16a_t>(float a, float b) { return pack2_lo<f16_t>(round_act_bits(a), round_act_bits(b)); }
-template <> __device__ __forceinline__ f16a_t to_lo<f16a_t>(float v) { return f16a_t{__builtin_bit_cast(uint16_t, (f16_t)round_act_bits(v))}; }
 template <typename T> __device__ __forceinline__ void unpack2_lo(uint32_t u, float& a, float& b);
 template <> __device__ __forceinline__ void unpack2_lo<bf16_t>(uint32_t u, float& a, float& b) { a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u); }
 template <> __device__ __forceinline__ void unpack2_lo<f16_t>(uint32_t u, float& a, float& b) {
@@ -87,7 +69,6 @@ template <> __device__ __forceinline__ void unpack2_lo<f16_t>(uint32_t u, float&
     const h2 v = __builtin_bit_cast(h2, u);
     a = (float)v[0]; b = (float)v[1];
 }
-template <> __device__ __forceinline__ void unpack2_lo<f16a_t>(uint32_t u, float& a, float& b) { unpack2_lo<f16_t>(u, a, b); }
 
 enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2 };
 
@@ -125,6 +106,15 @@ __device__ __forceinline__ float erf_as_f(float x) {      // Abramowitz & Stegun
 __device__ __forceinline__ float gelu_erf_f(float x) {    // F.gelu (erf form)
 #pragma clang fp contract(off)
     return (x * 0.5f) * (1.0f + erf_as_f(x * 0.70710678118654752440f));
+}
+
+// LayerNorm's affine step, the ONE definition shared by the LayerNorm kernel (which writes the 16-bit operand of the
+// next GEMM and two statistics per row) and by every consumer that needs the fp32 LayerNorm output again — the
+// residual epilogues below and the position-0 readout: they recompute it from the pre-LayerNorm sum they read
+// anyway, so the fp32 LayerNorm output is never stored (4 of the 10 bytes per element the LayerNorm kernel moved).
+__device__ __forceinline__ float ln_affine(float x, float mean, float rstd, float g, float b) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf((x - mean) * rstd, g, b);
 }
 
 // One output element of every GEMM epilogue (see GemmEpilogue below): the single definition all
@@ -249,7 +239,9 @@ __device__ __forceinline__ void epi_values(float (&vs)[NV], const float (&bias)[
 }
 
 // Row-wise epilogue description (all pointers device, nullable unless noted).
-//   v = acc + bias[col]; v = act(v); v += residual[row, col]; v = scale[col]*v + shift[col]
+//   v = acc + bias[col]; v = act(v); v += r[row, col]; v = scale[col]*v + shift[col]
+//   r = residual[row, col], or, with res_stats, the LayerNorm of that row recomputed on the fly:
+//       r = ln_affine(residual[row, col], res_stats[2*row], res_stats[2*row + 1], res_gamma[col], res_beta[col])
 //   col <  split_col -> out_f32[row*ld_f32 + col], out_lo[row*ld_lo + col]
 //   col >= split_col -> out_f32_b[row*ld_f32 + (col - split_col)]
 template <typename T>
@@ -258,6 +250,9 @@ struct GemmEpilogue {
     int act;
     const float* residual;
     int ld_res;
+    const float* res_stats;     // [M][2] (mean, rstd) of the residual rows, or null: the residual is used as stored
+    const float* res_gamma;     // [N]
+    const float* res_beta;      // [N]
     const float* scale;
     const float* shift;
     float* out_f32;
@@ -301,8 +296,6 @@ template <>
 __device__ __forceinline__ void mfma_chunk<f16_t>(const u32x4& a, const u32x4& b, f32x16& acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
-template <>
-__device__ __forceinline__ void mfma_chunk<f16a_t>(const u32x4& a, const u32x4& b, f32x16& acc) { mfma_chunk<f16_t>(a, b, acc); }
 template <>
 __device__ __forceinline__ void mfma_chunk<float>(const u32x4& a, const u32x4& b, f32x16& acc) {
 #pragma unroll
@@ -435,7 +428,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (row >= g.M) continue;
-                const float res = e.residual ? e.residual[(size_t)row * e.ld_res + col] : 0.f;
+                float res = e.residual ? e.residual[(size_t)row * e.ld_res + col] : 0.f;
+                if (e.residual && e.res_stats) res = ln_affine(res, e.res_stats[2 * (size_t)row], e.res_stats[2 * (size_t)row + 1], e.res_gamma[col], e.res_beta[col]);
                 const bool hr = e.residual != nullptr, hs = e.scale != nullptr;
                 const float v = e.act == ACT_GELU_TANH ? epi_value<ACT_GELU_TANH>(acc[i][j][r], bias, hr, res, hs, sc, sh)
                               : e.act == ACT_GELU_ERF ? epi_value<ACT_GELU_ERF>(acc[i][j][r], bias, hr, res, hs, sc, sh)

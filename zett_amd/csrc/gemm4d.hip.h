@@ -84,8 +84,6 @@ constexpr int G4D_EPI_REGION = 64 * G4D_EPI_STRIDE * 4;               // bytes p
 constexpr int G4D_LDS_BYTES = 4 * G4D_EPI_REGION;                     // 132 KiB (the K loop uses the first 128)
 static_assert(G4D_LDS_BYTES >= G256_LDS_BYTES && G4D_LDS_BYTES <= 160 * 1024, "LDS budget");
 
-template <> __device__ __forceinline__ void mfma16_agpr<f16a_t>(f32x4& c, const u32x4& a, const u32x4& b) { mfma16_agpr<f16_t>(c, a, b); }
-
 template <typename T, int ACT = ACT_NONE, bool RES = false, int EPI = G4D_EPI_GENERIC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4d_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -280,16 +278,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // (64 rows x 128 fp32), two passes, drained by EpiDrain (gemm_tile.hip.h).
         __syncthreads();
         float* region = (float*)(smem + wave * 32768);
-        typedef EpiDrain<T, ACT, RES, 64, 128, true, false> Drain;
+        typedef EpiDrain<T, ACT, RES, 64, 128, !RES, false> Drain;      // (no Rescaler behind a residual: the launcher refuses the pair)
         const int gcol = n0 + wn * 128 + (lane_e % Drain::LPR) * 8;
         const bool col_ok = gcol < g.N;
         float4 bias8[2], sc8[2], sh8[2];
         Drain::load_cols(g.epi, gcol, col_ok, bias8, sc8, sh8);
+        float4 lng[2], lnb[2];
+        Drain::load_ln_cols(g.epi, gcol, col_ok, lng, lnb);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             float4 oa[Drain::NIT], ob[Drain::NIT];
             const int row0 = m0 + wm * 128 + p * 64;
             Drain::load_res(g, row0, gcol, col_ok, lane_e, oa, ob);
+            float2 lnst;
+            Drain::load_res_stats(g, row0, lane_e, lnst);
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
@@ -298,6 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int r = 0; r < 4; ++r)
                         region[(i4 * 16 + kq * 4 + r) * 128 + j * 16 + l15] = acc[4 * p + i4][j][r];
             if (RES || p == 0) __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
+            Drain::ln_res(g, lane_e, lng, lnb, lnst, oa, ob);
             Drain::drain(g, region, row0, gcol, col_ok, lane_e, bias8, sc8, sh8, oa, ob);
         }
     } else {
@@ -325,6 +328,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const float4 a = *(const float4*)(e.scale + gcol + c4), b = *(const float4*)(e.shift + gcol + c4);
                     sc[c4] = a.x; sc[c4 + 1] = a.y; sc[c4 + 2] = a.z; sc[c4 + 3] = a.w;
                     sh[c4] = b.x; sh[c4 + 1] = b.y; sh[c4 + 2] = b.z; sh[c4 + 3] = b.w;
+                }
+            }
+        }
+        // LayerNorm'd residual (GemmEpilogue::res_stats): lane l holds the statistics of row l of each pass (two
+        // 8-byte loads per lane for the whole tile); instruction t of the drain covers rows 2t and 2t+1 of the pass and
+        // fetches theirs with v_readlane.  gamma / beta of the lane's four columns sit beside the bias.
+        // (no activation in front of a LayerNorm'd residual: gemm4d_epi_mode sends anything else to the generic drain)
+        const bool res_ln = RES && ACT == ACT_NONE && e.res_stats != nullptr;
+        float lg[4] = {1.f, 1.f, 1.f, 1.f}, lb[4] = {0.f, 0.f, 0.f, 0.f};
+        float2 pst[2] = {make_float2(0.f, 1.f), make_float2(0.f, 1.f)};
+        if constexpr (RES && ACT == ACT_NONE) {
+            if (res_ln) {
+                if (col_ok) {
+                    const float4 a = *(const float4*)(e.res_gamma + gcol), b = *(const float4*)(e.res_beta + gcol);
+                    lg[0] = a.x; lg[1] = a.y; lg[2] = a.z; lg[3] = a.w; lb[0] = b.x; lb[1] = b.y; lb[2] = b.z; lb[3] = b.w;
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    int srow = m0 + wm * 128 + p * 64 + lane_e; srow = srow < g.M ? srow : g.M - 1;
+                    pst[p] = *(const float2*)(e.res_stats + 2 * (size_t)srow);
                 }
             }
         }
@@ -373,6 +396,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if constexpr (RES) {
                         const float4 x = res[p][t0 + u];
                         rr[u * CPL] = x.x; rr[u * CPL + 1] = x.y; rr[u * CPL + 2] = x.z; rr[u * CPL + 3] = x.w;
+                        if (ACT == ACT_NONE && res_ln) {
+                            const int r0 = (t0 + u) * RPI;          // rows r0 (rsub = 0) and r0 + 1 (rsub = 1) of the pass
+                            const float mean0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pst[p].x), r0));
+                            const float mean1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pst[p].x), r0 + 1));
+                            const float rstd0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pst[p].y), r0));
+                            const float rstd1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pst[p].y), r0 + 1));
+                            const float mean = rsub ? mean1 : mean0, rstd = rsub ? rstd1 : rstd0;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) rr[u * CPL + c] = ln_affine(rr[u * CPL + c], mean, rstd, lg[c], lb[c]);
+                        }
                     }
                 }
                 epi_values<ACT, RES, SCALE, NV>(v, bb, rr, ss, hh);
@@ -446,6 +479,7 @@ template <typename T>
 inline int gemm4d_epi_mode(const GemmArgs<T>& g) {
     const GemmEpilogue<T>& e = g.epi;
     if (e.out_f32_b || e.split_col < g.N) return G4D_EPI_GENERIC;
+    if (e.res_stats && (e.act != ACT_NONE || !e.residual)) return G4D_EPI_GENERIC;
     if (e.out_lo && !e.out_f32 && !e.residual && !e.scale && !e.shift && g.N % 8 == 0 && e.ld_lo % 8 == 0) return G4D_EPI_LO;
     if (e.out_f32 && !e.out_lo && g.N % 4 == 0 && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0)) {
         if (e.scale && e.shift && !e.residual && e.act == ACT_NONE) return G4D_EPI_F32_SCALE;

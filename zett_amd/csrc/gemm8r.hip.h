@@ -177,16 +177,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- epilogue as in gemm256.hip.h: 16 KiB region per wave (64 rows x 64 fp32), two passes
     __syncthreads();
     float* region = (float*)(smem + wave * 16384);
-    typedef EpiDrain<T, ACT, RES, 64, 64> Drain;
+    typedef EpiDrain<T, ACT, RES, 64, 64, !RES> Drain;      // (no Rescaler behind a residual: the launcher refuses the pair)
     const int gcol = n0 + wn * 64 + (lane % Drain::LPR) * 8;
     const bool col_ok = gcol < g.N;
     float4 bias8[2], sc8[2], sh8[2];
     Drain::load_cols(g.epi, gcol, col_ok, bias8, sc8, sh8);
+    float4 lng[2], lnb[2];
+    Drain::load_ln_cols(g.epi, gcol, col_ok, lng, lnb);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         float4 oa[Drain::NIT], ob[Drain::NIT];
         const int row0 = m0 + wm * 128 + p * 64;
         Drain::load_res(g, row0, gcol, col_ok, lane, oa, ob);
+        float2 lnst;
+        Drain::load_res_stats(g, row0, lane, lnst);
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int r = 0; r < 16; ++r)
                     region[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + l31] = acc[2 * p + i2][j][r];
         if (RES || p == 0) __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
+        Drain::ln_res(g, lane, lng, lnb, lnst, oa, ob);
         Drain::drain(g, region, row0, gcol, col_ok, lane, bias8, sc8, sh8, oa, ob);
     }
 }

@@ -46,9 +46,6 @@ template <> __device__ __forceinline__ void store_out4<f16_t>(f16_t* dst, float4
     *(uint2*)dst = make_uint2(pack2_lo<f16_t>(v.x, v.y), pack2_lo<f16_t>(v.z, v.w));
 }
 
-template <> __device__ __forceinline__ void store_out4<f16a_t>(f16a_t* dst, float4 v) {
-    *(uint2*)dst = make_uint2(pack2_lo<f16a_t>(v.x, v.y), pack2_lo<f16a_t>(v.z, v.w));
-}
 template <typename T> __device__ __forceinline__ void store_out8(T* dst, float4 a, float4 b);
 template <> __device__ __forceinline__ void store_out8<float>(float* dst, float4 a, float4 b) { *(float4*)dst = a; *(float4*)(dst + 4) = b; }
 template <> __device__ __forceinline__ void store_out8<bf16_t>(bf16_t* dst, float4 a, float4 b) {
@@ -56,10 +53,6 @@ template <> __device__ __forceinline__ void store_out8<bf16_t>(bf16_t* dst, floa
 }
 template <> __device__ __forceinline__ void store_out8<f16_t>(f16_t* dst, float4 a, float4 b) {
     *(uint4*)dst = make_uint4(pack2_lo<f16_t>(a.x, a.y), pack2_lo<f16_t>(a.z, a.w), pack2_lo<f16_t>(b.x, b.y), pack2_lo<f16_t>(b.z, b.w));
-}
-
-template <> __device__ __forceinline__ void store_out8<f16a_t>(f16a_t* dst, float4 a, float4 b) {
-    *(uint4*)dst = make_uint4(pack2_lo<f16a_t>(a.x, a.y), pack2_lo<f16a_t>(a.z, a.w), pack2_lo<f16a_t>(b.x, b.y), pack2_lo<f16a_t>(b.z, b.w));
 }
 
 // Epilogue drain shared by the large-tile kernels.  One wave has staged ROWS x COLS fp32
@@ -93,6 +86,39 @@ struct EpiDrain {
             const float* src = g.epi.residual + (size_t)grow * g.epi.ld_res + gcol;
             oa[t] = ok ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
             ob[t] = ok ? *(const float4*)(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    // LayerNorm'd residual (GemmEpilogue::res_stats): the rows' statistics are requested with the residual rows,
+    // gamma / beta of the lane's eight columns before the first pass (load_ln_cols: a load issued behind a store
+    // could not be waited for without waiting for the store); ln_res applies the affine step to the staged rows
+    // once everything has landed
+    // (statistics: lane l of the wave holds those of row l of the pass — ROWS <= 64 — and the drain fetches the
+    //  row of each instruction with a wave shuffle: two registers instead of two per instruction)
+    static __device__ __forceinline__ void load_res_stats(const GemmArgs<T>& g, int row0, int lane, float2& st) {
+        st = make_float2(0.f, 1.f);
+        if (!RES || !g.epi.res_stats) return;
+        static_assert(ROWS <= 64, "one statistics row per lane");
+        int grow = row0 + (lane < ROWS ? lane : ROWS - 1);
+        grow = grow < g.M ? grow : g.M - 1;
+        st = *(const float2*)(g.epi.res_stats + 2 * (size_t)grow);
+    }
+    static __device__ __forceinline__ void load_ln_cols(const GemmEpilogue<T>& e, int gcol, bool col_ok, float4 (&gm)[2], float4 (&bt)[2]) {
+        gm[0] = gm[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+        bt[0] = bt[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!RES || !e.res_stats || !col_ok) return;
+        gm[0] = *(const float4*)(e.res_gamma + gcol); gm[1] = *(const float4*)(e.res_gamma + gcol + 4);
+        bt[0] = *(const float4*)(e.res_beta + gcol); bt[1] = *(const float4*)(e.res_beta + gcol + 4);
+    }
+    static __device__ __forceinline__ void ln_res(const GemmArgs<T>& g, int lane, const float4 (&gm)[2], const float4 (&bt)[2], float2 st, float4 (&oa)[NIT], float4 (&ob)[NIT]) {
+        if (!RES || !g.epi.res_stats) return;
+        const float4 g0 = gm[0], g1 = gm[1], b0 = bt[0], b1 = bt[1];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int lrow = t * RPI + lane / LPR;
+            const float m = __shfl(st.x, lrow, 64), r = __shfl(st.y, lrow, 64);
+            oa[t] = make_float4(ln_affine(oa[t].x, m, r, g0.x, b0.x), ln_affine(oa[t].y, m, r, g0.y, b0.y), ln_affine(oa[t].z, m, r, g0.z, b0.z), ln_affine(oa[t].w, m, r, g0.w, b0.w));
+            ob[t] = make_float4(ln_affine(ob[t].x, m, r, g1.x, b1.x), ln_affine(ob[t].y, m, r, g1.y, b1.y), ln_affine(ob[t].z, m, r, g1.z, b1.z), ln_affine(ob[t].w, m, r, g1.w, b1.w));
         }
     }
 

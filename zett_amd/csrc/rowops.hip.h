@@ -211,10 +211,6 @@ template <> __device__ __forceinline__ void store_lo4<f16_t>(f16_t* dst, float4 
     *(uint2*)dst = make_uint2(pack2_lo<f16_t>(v.x, v.y), pack2_lo<f16_t>(v.z, v.w));
 }
 
-template <> __device__ __forceinline__ void store_lo4<f16a_t>(f16a_t* dst, float4 v) {
-    *(uint2*)dst = make_uint2(pack2_lo<f16a_t>(v.x, v.y), pack2_lo<f16a_t>(v.z, v.w));
-}
-
 template <int SRC_DTYPE> __device__ __forceinline__ float4 load_src4(const void* base, size_t elem);
 template <> __device__ __forceinline__ float4 load_src4<0>(const void* base, size_t e) {
     return *(const float4*)((const float*)base + e);
@@ -286,11 +282,16 @@ constexpr int LN_MAX_VEC = 8;   // 8 float4 x 256 threads = 8192 columns in regi
 // TPR = threads per row: 256 (one workgroup per row, two LDS reductions) for wide rows, 64 (one wave per
 // row, four rows per workgroup, shuffle reductions only) for H <= 2048, where a 256-thread group would
 // leave lanes idle and spend its time in the two barriers.
+// Outputs (each optional): out_lo = the normalised row as the 16-bit operand of the next GEMM; out_f32 = the
+// normalised row in fp32 (hoisted table, output heads); stats_out = (mean, rstd) of the row, from which the residual
+// epilogues and the position-0 readout recompute the fp32 row with ln_affine instead of reading it back;
+// sum_out (embed variant) = the pre-LayerNorm sum itself, which those consumers then read.
 template <typename T, bool EMBED, int TPR = 256>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ in, int ld_in, int rows, int H,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps,
                                                              float* __restrict__ out_f32, T* __restrict__ out_lo,
+                                                             float* __restrict__ stats_out, float* __restrict__ sum_out,
                                                              LnEmbed emb, int tok0) {
     __shared__ float red[4];
     const int r = blockIdx.x * (256 / TPR) + (int)threadIdx.x / TPR;
@@ -347,11 +348,12 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     }
     const float var = row_sum(q) / (float)H;
     const float rstd = 1.0f / sqrtf(var + eps);
+    if (stats_out && tid == 0) *(float2*)(stats_out + 2 * (size_t)r) = make_float2(mean, rstd);
     auto emit = [&](int idx, float4 a) {
         const float4 g = *(const float4*)(gamma + idx * 4), b = *(const float4*)(beta + idx * 4);
-        float4 o;
-        o.x = (a.x - mean) * rstd * g.x + b.x; o.y = (a.y - mean) * rstd * g.y + b.y;
-        o.z = (a.z - mean) * rstd * g.z + b.z; o.w = (a.w - mean) * rstd * g.w + b.w;
+        const float4 o = make_float4(ln_affine(a.x, mean, rstd, g.x, b.x), ln_affine(a.y, mean, rstd, g.y, b.y),
+                                     ln_affine(a.z, mean, rstd, g.z, b.z), ln_affine(a.w, mean, rstd, g.w, b.w));
+        if (EMBED && sum_out) *(float4*)(sum_out + (size_t)r * H + idx * 4) = a;
         if (out_f32) *(float4*)(out_f32 + (size_t)r * H + idx * 4) = o;
         if (out_lo) store_lo4<T>(out_lo + (size_t)r * H + idx * 4, o);
     };
@@ -385,7 +387,6 @@ template <typename T> __device__ __forceinline__ void load8_16bit(const T* p, fl
 }
 template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&o)[8]) { load8_16bit<bf16_t>(p, o); }
 template <> __device__ __forceinline__ void load8<f16_t>(const f16_t* p, float (&o)[8]) { load8_16bit<f16_t>(p, o); }
-template <> __device__ __forceinline__ void load8<f16a_t>(const f16a_t* p, float (&o)[8]) { load8_16bit<f16a_t>(p, o); }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&o)[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&o)[8]) {
     *(float4*)p = make_float4(o[0], o[1], o[2], o[3]);
@@ -396,7 +397,6 @@ template <typename T> __device__ __forceinline__ void store8_16bit(T* p, const f
 }
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&o)[8]) { store8_16bit<bf16_t>(p, o); }
 template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&o)[8]) { store8_16bit<f16_t>(p, o); }
-template <> __device__ __forceinline__ void store8<f16a_t>(f16a_t* p, const float (&o)[8]) { store8_16bit<f16a_t>(p, o); }
 
 // q: [T, ldq] per packed position, or (cls_only) [rows, ldq] holding the query of position 0
 // of each row; k, v: [T, ldkv]; ctx: [T or rows, H].  cls_only: compute query 0 only and
@@ -460,28 +460,44 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
 
 // ---------------------------------------------------------------------------
 // Position-0 readout (modeling_hypernet.py:231-234) + bias head (:260-265).
-// src rows are either packed tokens (index row_offset[n] - tok0) or already compact.
+// src rows are either packed tokens (index row_offset[n] - tok0) or already compact.  The hidden state arrives as
+// the pre-LayerNorm sum `s` + per-row statistics (ln_stats) + the LayerNorm's gamma / beta: its fp32 value is
+// ln_affine(s, ...), recomputed here (with ln_stats == null, `s` IS the fp32 hidden state).
+//   c_stats != null : forward the row as it is — c_f32 = s, c_stats = statistics (the position-0 rows of the last
+//                     layer's input, whose consumer is again a residual epilogue that applies ln_affine itself)
+//   c_stats == null : c_f32 = the fp32 hidden state (input of the output heads), bias head on it
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict__ z_f32, const T* __restrict__ z_lo,
+__global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict__ s_f32, const T* __restrict__ z_lo,
                                                          int H, const int32_t* __restrict__ row_offset, int64_t row0,
                                                          int rows, int tok0, int compact,
-                                                         float* __restrict__ c_f32, T* __restrict__ c_lo,
+                                                         const float* __restrict__ ln_stats, const float* __restrict__ ln_gamma,
+                                                         const float* __restrict__ ln_beta,
+                                                         float* __restrict__ c_f32, T* __restrict__ c_lo, float* __restrict__ c_stats,
                                                          const float* __restrict__ bias_w, const float* __restrict__ bias_b,
                                                          float* __restrict__ out_bias) {
     __shared__ float red[4];
     const int r = blockIdx.x;
     if (r >= rows) return;
     const size_t srow = compact ? (size_t)r : (size_t)(row_offset[row0 + r] - tok0);
-    const float* zf = z_f32 + srow * H;
+    const float* zf = s_f32 + srow * H;
+    float mean = 0.f, rstd = 1.f;
+    if (ln_stats) { const float2 st = *(const float2*)(ln_stats + 2 * srow); mean = st.x; rstd = st.y; }
+    if (c_stats && threadIdx.x == 0) *(float2*)(c_stats + 2 * (size_t)r) = make_float2(mean, rstd);
+    const bool normalise = ln_stats != nullptr && c_stats == nullptr;
     float dot = 0.f;
     for (int c = threadIdx.x * 4; c < H; c += 1024) {
-        const float4 a = *(const float4*)(zf + c);
+        float4 a = *(const float4*)(zf + c);
+        if (normalise) {
+            const float4 g = *(const float4*)(ln_gamma + c), b = *(const float4*)(ln_beta + c);
+            a = make_float4(ln_affine(a.x, mean, rstd, g.x, b.x), ln_affine(a.y, mean, rstd, g.y, b.y),
+                            ln_affine(a.z, mean, rstd, g.z, b.z), ln_affine(a.w, mean, rstd, g.w, b.w));
+        }
         if (c_f32) *(float4*)(c_f32 + (size_t)r * H + c) = a;
         if (c_lo) {
             if (z_lo) {
                 if constexpr (sizeof(T) == 2) *(uint2*)(c_lo + (size_t)r * H + c) = *(const uint2*)(z_lo + srow * H + c);
-                else *(float4*)(c_lo + (size_t)r * H + c) = a;
+                else *(float4*)(c_lo + (size_t)r * H + c) = *(const float4*)(z_lo + srow * H + c);
             } else {
                 store_lo4<T>(c_lo + (size_t)r * H + c, a);
             }

@@ -72,7 +72,7 @@ struct zett_hypernet {
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
                                       // 7 = 256x256 four-wave direct-to-LDS, 8 = as 7 with the generic epilogue drain
     // workspace
-    DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct;
+    DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct, lnstats;
     int32_t* host_pinned = nullptr;
     size_t host_pinned_ints = 0;
     std::vector<hipEvent_t> ev;
@@ -162,8 +162,8 @@ int validate_config(const zett_config& c, int precision) {
 // Ttot, distinct ids D).  One definition shared by do_forward and zett_workspace_bytes.
 struct WorkspaceSizes {
     int64_t chunk_tokens;
-    size_t table, x0, f32_rows, lo_rows, big;
-    size_t total() const { return table + x0 + 3 * f32_rows + 3 * lo_rows + big; }
+    size_t table, x0, f32_rows, lo_rows, big, stats;
+    size_t total() const { return table + x0 + 3 * f32_rows + 3 * lo_rows + big + stats; }
 };
 
 static size_t plan_i32_bytes(const zett_config& c, int64_t N, int seq) {
@@ -185,6 +185,7 @@ static WorkspaceSizes workspace_sizes(const zett_config& c, size_t es, int seq, 
     w.f32_rows = MC * c.hidden * 4;
     w.lo_rows = MCS * c.hidden * es;
     w.big = MCS * wide * es;
+    w.stats = 3 * MC * 2 * sizeof(float);          // (mean, rstd) per row: two LayerNorms in flight + the position-0 rows
     return w;
 }
 
@@ -202,7 +203,7 @@ int zett_abi_version(void) { return ZETT_ABI_VERSION; }
 
 int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet** out) {
     if (!cfg || !out) return fail(ZETT_E_INVALID, "null argument");
-    if (precision != ZETT_PREC_BF16 && precision != ZETT_PREC_F32 && precision != ZETT_PREC_F16 && precision != ZETT_PREC_F16A9) return fail(ZETT_E_INVALID, "unknown precision %d", precision);
+    if (precision != ZETT_PREC_BF16 && precision != ZETT_PREC_F32 && precision != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "unknown precision %d", precision);
     if (int rc = validate_config(*cfg, precision)) return rc;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -211,7 +212,6 @@ int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<f16a_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     auto* h = new zett_hypernet();
     h->cfg = *cfg;
     h->device = device;
@@ -228,7 +228,7 @@ int zett_destroy(zett_hypernet* h) {
         if (kv.second.lo && kv.second.lo != (void*)kv.second.f32) (void)hipFree(kv.second.lo);
     }
     for (void* p : h->owned) (void)hipFree(p);
-    for (DevBuf* b : {&h->plan_i32, &h->plan_u8, &h->table, &h->x0, &h->yf, &h->yt, &h->big, &h->pre, &h->ctx, &h->cf, &h->ct})
+    for (DevBuf* b : {&h->plan_i32, &h->plan_u8, &h->table, &h->x0, &h->yf, &h->yt, &h->big, &h->pre, &h->ctx, &h->cf, &h->ct, &h->lnstats})
         b->release();
     if (h->host_pinned) (void)hipHostFree(h->host_pinned);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -296,7 +296,7 @@ int zett_finalize(zett_hypernet* h) {
         if (h->precision == ZETT_PREC_F32) { t.lo = t.f32; continue; }
         HIP_TRY(hipMalloc(&t.lo, t.numel * 2));
         const int blocks = (int)std::min<size_t>((t.numel / 4 + 255) / 256 + 1, 65535);
-        if (h->precision == ZETT_PREC_F16 || h->precision == ZETT_PREC_F16A9)      // (F16A9 rounds activations only: weights keep 11 bits)
+        if (h->precision == ZETT_PREC_F16)
             hipLaunchKernelGGL(convert_f32_to_lo_kernel<f16_t>, dim3(blocks), dim3(256), 0, 0, t.f32, (f16_t*)t.lo, t.numel);
         else
             hipLaunchKernelGGL(convert_f32_to_lo_kernel<bf16_t>, dim3(blocks), dim3(256), 0, 0, t.f32, (bf16_t*)t.lo, t.numel);
@@ -404,8 +404,6 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
     if (n_rows * (int64_t)(seq + 1) >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many positions for one call");
     ZETT_ON_DEVICE(h->device);
     hipStream_t st = (hipStream_t)stream;
-    if (h->precision == ZETT_PREC_F16A9)
-        return do_forward<f16a_t>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);
     if (h->precision == ZETT_PREC_F16)
         return do_forward<f16_t>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);
     if (h->precision == ZETT_PREC_BF16)
@@ -488,6 +486,7 @@ struct Runner {
         const bool wide_ok = N % 8 == 0 && (!e.out_lo || e.ld_lo % 8 == 0) && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0) &&
                              (e.split_col >= N || e.split_col % 8 == 0);
         if (variant != 1 && !wide_ok) variant = 1;
+        if (e.residual && (e.scale || e.shift)) variant = 1;      // the large tiles compile their residual epilogues without the Rescaler
         if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
         hipError_t err;
         switch (variant) {
@@ -509,14 +508,14 @@ struct Runner {
         if (e != hipSuccess) rc = fail(ZETT_E_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
     }
 
-    void layernorm(const float* in, int rows, const float* gamma, const float* beta, float eps, float* of, T* ol) {
+    void layernorm(const float* in, int rows, const float* gamma, const float* beta, float eps, float* of, T* ol, float* stats = nullptr) {
         if (rc || rows <= 0) return;
         if (h->cfg.hidden <= 2048)       // a wave per row, four rows per workgroup
             hipLaunchKernelGGL((layernorm_rows_kernel<T, false, 64>), dim3((rows + 3) / 4), dim3(256), 0, st, in, h->cfg.hidden, rows,
-                               h->cfg.hidden, gamma, beta, eps, of, ol, LnEmbed{}, 0);
+                               h->cfg.hidden, gamma, beta, eps, of, ol, stats, (float*)nullptr, LnEmbed{}, 0);
         else
             hipLaunchKernelGGL((layernorm_rows_kernel<T, false, 256>), dim3(rows), dim3(256), 0, st, in, h->cfg.hidden, rows,
-                               h->cfg.hidden, gamma, beta, eps, of, ol, LnEmbed{}, 0);
+                               h->cfg.hidden, gamma, beta, eps, of, ol, stats, (float*)nullptr, LnEmbed{}, 0);
         check("layernorm");
     }
 
@@ -617,6 +616,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     if (int rc = h->ctx.reserve(ws.lo_rows)) return rc;
     if (int rc = h->cf.reserve(ws.f32_rows)) return rc;
     if (int rc = h->ct.reserve(ws.lo_rows)) return rc;
+    if (int rc = h->lnstats.reserve(ws.stats)) return rc;
     float* TBL = h->table.as<float>();
     T* X0 = h->x0.as<T>();
     float* Zf = h->yf.as<float>();
@@ -626,6 +626,13 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     T* CTX = h->ctx.as<T>();
     float* Cf = h->cf.as<float>();
     T* Ct = h->ct.as<T>();
+    // LayerNorm statistics.  The encoder keeps its hidden state as (pre-LayerNorm sum, statistics, gamma, beta):
+    // the LayerNorm kernel writes the 16-bit GEMM operand and the two statistics, and whoever needs the fp32
+    // LayerNorm output (the next residual epilogue, the position-0 readout) recomputes it with ln_affine from the
+    // sum it reads anyway.  Zf and PRE alternate as the sum buffers.
+    float* STa = h->lnstats.as<float>();
+    float* STb = STa + 2 * (size_t)MC;
+    float* STc = STb + 2 * (size_t)MC;
 
     Runner<T> R{h, st};
     R.a_rows_readable = (long)MCS;
@@ -662,22 +669,26 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
 
         LnEmbed emb{TBL, p.tok_slot, p.tok_pos, R.Wf("model.embeddings.token_type_embeddings.weight"),
                     R.Wf("model.embeddings.position_embeddings.weight"), lang_vec, seq};
+        // hidden state = (sum buffer, statistics, gamma, beta); the embeddings' LayerNorm starts it in (Zf, STb)
+        float* hs_sum = Zf;
+        float* hs_stats = STb;
+        const float* hs_gamma = R.Wf("model.embeddings.LayerNorm.weight");
+        const float* hs_beta = R.Wf("model.embeddings.LayerNorm.bias");
         if (H <= 2048)
             hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 64>), dim3((m + 3) / 4), dim3(256), 0, st, (const float*)nullptr, H, m, H,
-                               R.Wf("model.embeddings.LayerNorm.weight"), R.Wf("model.embeddings.LayerNorm.bias"),
-                               c.ln_eps_encoder, Zf, Zt, emb, tok0);
+                               hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, Zt, hs_stats, hs_sum, emb, tok0);
         else
             hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 256>), dim3(m), dim3(256), 0, st, (const float*)nullptr, H, m, H,
-                               R.Wf("model.embeddings.LayerNorm.weight"), R.Wf("model.embeddings.LayerNorm.bias"),
-                               c.ln_eps_encoder, Zf, Zt, emb, tok0);
+                               hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, Zt, hs_stats, hs_sum, emb, tok0);
         R.check("embed_layernorm");
 
         int zrows = m;            // rows of the current hidden state (m packed, or `rows` once compact)
         bool compact = false;
+        auto other = [&](float* b) { return b == Zf ? PRE : Zf; };
+        auto other_stats = [&](float* b) { return b == STa ? STb : STa; };
         for (int l = 0; l < c.layers && !R.rc; ++l) {
             const std::string lp = "model.encoder.layer." + std::to_string(l) + ".";
             const bool cls_only = h->cls_only_last && l == c.layers - 1;
-            const float* resid = Zf;
             const T* wqkv = (const T*)h->qkv_w[l];
             const int64_t waves = (int64_t)rows * groups;
             if (!cls_only) {
@@ -691,9 +702,10 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             } else {
                 // Only hidden[:,0] is consumed after this layer (modeling_hypernet.py:234): keys and
                 // values for every position, the query (and everything downstream) for position 0.
-                hipLaunchKernelGGL((cls_gather_kernel<T>), dim3(rows), dim3(256), 0, st, (const float*)Zf, (const T*)Zt, H,
-                                   p.row_offset, r0, rows, tok0, 0, Cf, Ct, (const float*)nullptr,
-                                   (const float*)nullptr, (float*)nullptr);
+                // The position-0 rows of the hidden state move to (Cf, STc) as they are (sum + statistics).
+                hipLaunchKernelGGL((cls_gather_kernel<T>), dim3(rows), dim3(256), 0, st, (const float*)hs_sum, (const T*)Zt, H,
+                                   p.row_offset, r0, rows, tok0, 0, (const float*)hs_stats, hs_gamma, hs_beta, Cf, Ct, STc,
+                                   (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
                 R.check("cls_gather(layer input)");
                 T* KV = BIG;                              // [m, 2H]
                 T* Q = BIG + (size_t)m * 2 * H;           // [rows, H]  (rows <= m, BIG holds >= m x 3H)
@@ -707,29 +719,43 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                                    (const T*)Q, (size_t)H, (const T*)KV, (const T*)KV + H, (size_t)2 * H,
                                    H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 1, CTX);
                 R.check("attention(position 0)");
-                resid = Cf;
+                hs_sum = Cf; hs_stats = STc;              // the compact hidden state; Zf / PRE / STa / STb are free again
                 zrows = rows;
                 compact = true;
             }
+            // attention output: sum = dense(ctx) + LN(hidden)   (the residual is the LayerNorm of hs_sum, recomputed)
+            float* s1 = hs_sum == Cf ? PRE : other(hs_sum);
+            float* st1 = hs_stats == STc ? STa : other_stats(hs_stats);
             GemmEpilogue<T> eo = R.epi();
-            eo.bias = R.Wf(lp + "attention.output.dense.bias"); eo.residual = resid; eo.ld_res = H; eo.out_f32 = PRE; eo.ld_f32 = H;
+            eo.bias = R.Wf(lp + "attention.output.dense.bias"); eo.residual = hs_sum; eo.ld_res = H;
+            eo.res_stats = hs_stats; eo.res_gamma = hs_gamma; eo.res_beta = hs_beta;
+            eo.out_f32 = s1; eo.ld_f32 = H;
             R.gemm(CTX, H, R.Wlo(lp + "attention.output.dense.weight"), H, zrows, H, H, eo);
-            R.layernorm(PRE, zrows, R.Wf(lp + "attention.output.LayerNorm.weight"), R.Wf(lp + "attention.output.LayerNorm.bias"),
-                        c.ln_eps_encoder, Zf, Zt);
+            const float* g1 = R.Wf(lp + "attention.output.LayerNorm.weight");
+            const float* b1 = R.Wf(lp + "attention.output.LayerNorm.bias");
+            R.layernorm(s1, zrows, g1, b1, c.ln_eps_encoder, nullptr, Zt, st1);
             GemmEpilogue<T> ei = R.epi();
             ei.bias = R.Wf(lp + "intermediate.dense.bias"); ei.act = ACT_GELU_ERF; ei.out_lo = BIG; ei.ld_lo = I;
             R.gemm(Zt, H, R.Wlo(lp + "intermediate.dense.weight"), H, zrows, I, H, ei);
+            // FFN output: sum = dense(gelu) + LN(s1)
+            float* s2 = other(s1);
+            float* st2 = other_stats(st1);
             GemmEpilogue<T> ef = R.epi();
-            ef.bias = R.Wf(lp + "output.dense.bias"); ef.residual = Zf; ef.ld_res = H; ef.out_f32 = PRE; ef.ld_f32 = H;
+            ef.bias = R.Wf(lp + "output.dense.bias"); ef.residual = s1; ef.ld_res = H;
+            ef.res_stats = st1; ef.res_gamma = g1; ef.res_beta = b1;
+            ef.out_f32 = s2; ef.ld_f32 = H;
             R.gemm(BIG, I, R.Wlo(lp + "output.dense.weight"), I, zrows, H, I, ef);
-            R.layernorm(PRE, zrows, R.Wf(lp + "output.LayerNorm.weight"), R.Wf(lp + "output.LayerNorm.bias"),
-                        c.ln_eps_encoder, Zf, Zt);
+            hs_gamma = R.Wf(lp + "output.LayerNorm.weight");
+            hs_beta = R.Wf(lp + "output.LayerNorm.bias");
+            R.layernorm(s2, zrows, hs_gamma, hs_beta, c.ln_eps_encoder, nullptr, Zt, st2);
+            hs_sum = s2; hs_stats = st2;
         }
         if (R.rc) break;
 
-        // position-0 readout + bias head (modeling_hypernet.py:231-234, 260-265)
-        hipLaunchKernelGGL((cls_gather_kernel<T>), dim3(rows), dim3(256), 0, st, (const float*)Zf, (const T*)Zt, H,
-                           p.row_offset, r0, rows, tok0, compact ? 1 : 0, Cf, Ct,
+        // position-0 readout + bias head (modeling_hypernet.py:231-234, 260-265): Cf = fp32 hidden[:,0], Ct its operand copy
+        // (hs_sum is never Cf here: the last layer writes Zf / PRE)
+        hipLaunchKernelGGL((cls_gather_kernel<T>), dim3(rows), dim3(256), 0, st, (const float*)hs_sum, (const T*)Zt, H,
+                           p.row_offset, r0, rows, tok0, compact ? 1 : 0, (const float*)hs_stats, hs_gamma, hs_beta, Cf, Ct, (float*)nullptr,
                            c.predict_bias ? R.Wf("bias_projection.weight") : (const float*)nullptr,
                            c.predict_bias ? R.Wf("bias_projection.bias") : (const float*)nullptr, out_bias);
         R.check("cls_gather");

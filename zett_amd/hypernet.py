@@ -30,10 +30,10 @@ from .config import ZettHypernetConfig
 from .dims import PROJECTOR_LN_EPS, ROBERTA_LN_EPS, ROBERTA_MAX_POSITIONS, HypernetDims, weight_shapes
 
 _TORCH_TO_ZETT = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
-DEFAULT_PRECISION = "f16a9"
+DEFAULT_PRECISION = "f16"
 _PRECISIONS = {"bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16, "f32": _lib.PREC_F32,
                "fp32": _lib.PREC_F32, "float32": _lib.PREC_F32, "f16": _lib.PREC_F16, "fp16": _lib.PREC_F16,
-               "float16": _lib.PREC_F16, "f16a9": _lib.PREC_F16A9}
+               "float16": _lib.PREC_F16}
 
 
 def _backbone_settings(name_or_path: str) -> Tuple[int, float]:
@@ -173,12 +173,12 @@ class ZettHypernet(PreTrainedModel):
         max_pos, ln_eps = _backbone_settings(getattr(config, "hn_model_name_or_path", "roberta-base"))
         self._ln_eps_encoder = ln_eps
         self.dims = HypernetDims.from_config(config, max_positions=max_pos)
-        # arithmetic of the dense contractions: "f16a9" / "f16" / "bf16" (MFMA operands, fp32 accumulate) or "f32".
-        # Default f16a9 (half operands, activations rounded to 9 significant bits, include/zett_hip.h): rel-L2
-        # 0.35e-2 of the fp32 reference at the 4096-wide shapes.  bf16 sits at 0.97e-2 on N(0, 0.02^2) weights and
-        # 1.04e-2 on a heavy-tailed checkpoint, i.e. on the edge of the 1e-2 tolerance (tests/test_full_size_gpu.py),
-        # and is 2.5 % faster; full f16 (0.12e-2) is 1.4 % slower: the MFMA rate is the same for all three, the
-        # chip is power-limited and significand bits cost energy.
+        # arithmetic of the dense contractions: "f16" / "bf16" (MFMA operands, fp32 accumulate) or "f32".
+        # Default f16: 11-bit significands put the predicted embeddings at rel-L2 1.2e-3 of the fp32 reference at
+        # the 4096-wide shapes; bf16 sits at 0.97e-2 on N(0, 0.02^2) weights and 1.04e-2 on a heavy-tailed
+        # checkpoint, i.e. on the edge of the 1e-2 tolerance (tests/test_full_size_gpu.py), and is ~4 % faster
+        # (same MFMA rate: the chip is power-limited and significand bits cost energy; rounding the f16
+        # activations to 9 bits recovered 0.5-1.4 % of that by box at 3x the error and was dropped).
         self.precision = os.environ.get("ZETT_PRECISION", getattr(config, "zett_precision", None) or DEFAULT_PRECISION)
         for name, shape in weight_shapes(self.dims).items():
             _attach(self, name, nn.Parameter(torch.empty(shape, dtype=torch.float32), requires_grad=False))
