@@ -1,6 +1,6 @@
 // trace4d.hip — per-tile timeline of gemm4d (wall_clock64 stamps, 100 MHz): prologue / K loop / epilogue per tile,
 // idle gap between consecutive tiles of a CU, and how many CUs are inside an epilogue at the same time.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DG4D_TRACE -I zett_amd/csrc tools/experiments/trace4d.hip -o tools/trace4d
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DG4D_TRACE -I zett_amd/csrc -I tools/experiments tools/experiments/trace4d.hip -o tools/trace4d
 //   tools/trace4d M N K epi      (epi: 0 = bf16 out, 1 = bias + GELU(erf) bf16 out, 5 = bias + residual, fp32 out)
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -8,7 +8,7 @@
 #include <cstdlib>
 #include <map>
 #include <vector>
-#include "gemm4d.hip.h"
+#include "gemm4p.hip.h"
 using namespace zett;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 __global__ void fill(bf16_t* p, size_t n, uint32_t seed) {
@@ -32,9 +32,11 @@ int main(int argc, char** argv) {
         printf("stagger %d us mode %d\n", ticks / 100, mode);
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) CK(launch_gemm4d<bf16_t>(g, 0));
+    const bool persistent = getenv("PERSISTENT") != nullptr;      // PERSISTENT=1: gemm4p (the timeline then has no separate prologue, and the fine-grained epilogue milestones are gemm4d's)
+    auto launch = [&]() { return persistent ? launch_gemm4p<bf16_t>(g, 0) : launch_gemm4d<bf16_t>(g, 0); };
+    for (int i = 0; i < 3; ++i) CK(launch());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 5; ++i) CK(launch_gemm4d<bf16_t>(g, 0));
+    for (int i = 0; i < 5; ++i) CK(launch());
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
     printf("M=%d N=%d K=%d epi=%d: %.3f ms  %.0f TF\n", M, N, K, epi, ms, 2.0 * M * N * K / ms / 1e9);

@@ -438,7 +438,6 @@ struct Runner {
         if constexpr (std::is_same<T, float>::value) return hipErrorInvalidValue;
         else return launch_gemm4d<T>(g, s, generic_epilogue);
     }
-
     void gemm(const T* A, int lda, const T* Wp, int ldw, int M, int N, int K, const GemmEpilogue<T>& e) {
         if (rc || M <= 0) return;
         GemmArgs<T> g{A, lda, Wp, ldw, M, N, K, e};
