@@ -4,11 +4,14 @@
     python bench.py --gpus N --steps K --warmup W [--workload NAME] [--precision bf16|f32]
 
 One "step" = one pass of the embedding-prediction hot path over the whole target
-vocab: the vocab's surface-form rows are partitioned contiguously over the N ranks
-(one process per GPU), every rank runs plan -> hoisted input projection -> packed
-encoder -> output heads on its shard through libzett_hip.so, and an RCCL all-gather
-reassembles the full [V, E] matrices (+ bias) on every GPU.  Inputs (surface forms,
-source embeddings, weights) are resident in HBM before the timed region.
+vocab.  At N = 1 that is one forward (retokenization -> plan -> hoisted input projection
+-> packed encoder -> output heads) through libzett_hip.so.  At N > 1 (one process per
+GPU) the vocab's rows are cut into row blocks, every block is sharded over the ranks,
+and the RCCL all-gather that puts a block's rows on every GPU runs under the forward
+of the next block (zett_amd/sharding.py) — all inside the step: nothing overlaps
+across steps, every step ends with the full [V, E] matrices (+ bias) on every GPU.
+Inputs (surface forms, source embeddings, weights) are resident in HBM before the
+timed region.
 
 Default workload = the north-star headline of BASELINE.json: Mistral-7B hypernetwork
 shape (E 4096, E_in 8192, H 4096, I 8192, 32 heads, 2 output heads), 32 768-row
@@ -38,7 +41,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from zett_amd import synth  # noqa: E402
-from zett_amd.dims import HypernetDims, weight_shapes  # noqa: E402
+from zett_amd.dims import HypernetDims, as_written_flops_per_row, weight_shapes  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
@@ -128,12 +131,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--max-chunk-tokens", type=int, default=0, help="A/B only: zett_set_option max_chunk_tokens (0 = library default)")
+    ap.add_argument("--gemm4d-min-k", type=int, default=0, help="A/B only: K threshold of the four-wave direct-to-LDS tile (zett_set_option gemm4d_min_k)")
     ap.add_argument("--gemm-tile-order", type=int, default=0, help="A/B only: zett_set_option gemm_tile_order (0 = default)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force one GEMM tile variant (zett_set_option gemm_variant); 0 = per-launch choice")
     ap.add_argument("--no-retokenize", action="store_true", help="A/B only: start every step from the id matrix instead of the surface forms")
-    ap.add_argument("--serial-allgather", action="store_true",
-                    help="N > 1: wait for the all-gather of a step before the next forward starts (default: the RCCL "
-                         "all-gather of step i runs on its own stream under the forward of step i+1, outputs double-buffered)")
+    ap.add_argument("--chunks", type=int, default=2, help="N > 1: row blocks per step (zett_amd/sharding.py: the all-gather of a block overlaps the next block's forward)")
+    ap.add_argument("--serial-allgather", action="store_true", help="N > 1: one block per step, i.e. forward, then all-gather (A/B)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,7 +163,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
 
     from zett_amd.hypernet import HipEngine
-    from zett_amd.sharding import all_gather_rows, shard_bounds
+    from zett_amd.sharding import RowGather, plan_blocks
 
     cfg, rows, src_dtype, hist = synth.workload(args.workload)
     if args.rows:
@@ -171,9 +174,12 @@ def main():
     weights = device_weights(cfg, device, seed=0)
     engine = HipEngine(dims, 1e-5, device, args.precision)
     engine.load_weights(weights)
-    engine.set_option("time_gemm", 1)
+    if world == 1:
+        engine.set_option("time_gemm", 1)      # (brackets every GEMM with HIP events and synchronises at the end of a forward: kept out of the N > 1 overlap)
     if args.gemm_variant:
         engine.set_option("gemm_variant", args.gemm_variant)
+    if args.gemm4d_min_k:
+        engine.set_option("gemm4d_min_k", args.gemm4d_min_k)
     if args.gemm_tile_order:
         engine.set_option("gemm_tile_order", args.gemm_tile_order)
     if args.max_chunk_tokens:
@@ -185,62 +191,48 @@ def main():
     del weights
 
     ids_all = synth.make_surface_forms(cfg, rows, seed=0, hist=hist)
-    lo, hi = shard_bounds(rows, world, rank)
-    ids = torch.from_numpy(ids_all[lo:hi]).to(device)
+    # Row blocks of this rank (zett_amd/sharding.py): at N = 1 the whole vocabulary in one forward; at N > 1 the
+    # vocabulary is cut into `--chunks` row blocks, each sharded over the ranks, and the all-gather of a block runs
+    # on RCCL's stream under the forward of the next one — inside ONE step, which is what a caller with a single
+    # vocabulary gets from predict_sharded.  Nothing is carried across steps.
+    chunks = 1 if (world == 1 or args.serial_allgather) else args.chunks
+    blocks = plan_blocks(rows, world, rank, chunks)
+    assert all(b.hi > b.lo for b in blocks), "fewer rows than ranks"
+    ids_blocks = [torch.from_numpy(ids_all[b.lo:b.hi]).to(device) for b in blocks]
     # The step starts from SURFACE FORMS: the byte-level strings of this rank's target tokens and the tables of a
     # synthetic hn tokenizer (Unigram, one 3-byte piece per source id) are resident on the device; every step
     # retokenizes them on the GPU (zett_retokenize: byte table, Viterbi) into the [rows, L] id matrix the forward
-    # consumes.  The strings are built so that this matrix is exactly `ids` (checked below, untimed).
+    # consumes.  The strings are built so that this matrix is exactly the workload's (checked below, untimed).
     retok = None
+    texts = []
+    seq_len = int(ids_all.shape[1])
     if not args.no_retokenize:
         from zett_amd.surface_forms import DeviceRetokenizer, HnTokenizerSpec
         spec = HnTokenizerSpec.from_model_json(synth.make_hn_unigram_model(cfg), ["<unk>", "<s>", "</s>"], [0, 1, 2], dims.pad_token_id)
         retok = DeviceRetokenizer(spec, device)
-        d_text, d_off, n_tok = retok.encode(synth.tokens_for_surface_forms(cfg, ids_all[lo:hi]))
-        seq_len = int(ids_all.shape[1])
-        sfm0, n_trunc0 = retok.run(d_text, d_off, n_tok, seq_len)
-        if n_trunc0 != 0 or not torch.equal(sfm0, ids):
-            raise SystemExit("the retokenized surface forms differ from the workload's id matrix")
+        for b, ids_b in zip(blocks, ids_blocks):
+            d_text, d_off, n_tok = retok.encode(synth.tokens_for_surface_forms(cfg, ids_all[b.lo:b.hi]))
+            sfm0, n_trunc0 = retok.run(d_text, d_off, n_tok, seq_len)
+            if n_trunc0 != 0 or not torch.equal(sfm0, ids_b):
+                raise SystemExit("the retokenized surface forms differ from the workload's id matrix")
+            texts.append((d_text, d_off, n_tok))
     src = torch.from_numpy(synth.make_source_embeddings(cfg, seed=0, dtype=src_dtype)).to(device)
-    per = shard_bounds(rows, world, 0)[1]      # rows of the largest shard (all-gather pads to it)
+    lang_arg = -1 if lang is None else lang
 
-    def gather_async(local):
-        """One RCCL all-gather of a row shard into a fresh [world*per, ...] buffer; returns (full, work)."""
-        if local.shape[0] != per:                      # short last shard: pad to the nominal height
-            pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=device)
-            local = torch.cat([local, pad], dim=0)
-        local = local.contiguous()
-        full = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=device)
-        return full, dist.all_gather_into_tensor(full, local, async_op=True), local
-
-    in_flight = []          # [(fulls, works, locals)] of the previous step (N > 1, overlapped mode)
-
-    def finish(entry):
-        for w in entry[1]:
-            w.wait()        # makes the compute stream wait for the collective; does not block the host
-        return tuple(None if f is None else f[:rows] for f in entry[0])
+    acc = {"gemm_ms": 0.0, "gemm_flops_timed": 0.0, "gemm_launches": 0}
 
     def step():
-        sfm = ids if retok is None else retok.run(d_text, d_off, n_tok, seq_len)[0]
-        o_in, o_out, o_bias = engine.forward(sfm, src, -1 if lang is None else lang)
-        if world == 1:
-            return o_in, o_out, o_bias
-        fulls, works, keep = [], [], []
-        for t in (o_in, o_out, o_bias):
-            if t is None:
-                fulls.append(None)
-                continue
-            f, w, loc = gather_async(t)
-            fulls.append(f); works.append(w); keep.append(loc)
-        entry = (fulls, works, keep)
-        if args.serial_allgather:
-            return finish(entry)
-        prev = in_flight.pop() if in_flight else None
-        in_flight.append(entry)
-        return finish(prev) if prev is not None else None
-
-    def drain():
-        return finish(in_flight.pop()) if in_flight else None
+        gather = RowGather(blocks) if world > 1 else None
+        outs = None
+        for k, b in enumerate(blocks):
+            sfm = ids_blocks[k] if retok is None else retok.run(*texts[k], seq_len)[0]
+            outs = engine.forward(sfm, src, lang_arg)
+            st_k = engine.stats()
+            for key in acc:
+                acc[key] += st_k[key]
+            if gather is not None:
+                gather.add(b, outs)            # async all-gather of this block; the next block's forward runs meanwhile
+        return outs if gather is None else gather.finish(rows)
 
     gemm_ms = gemm_fl = 0.0
     launches = 0
@@ -248,22 +240,17 @@ def main():
     for _ in range(args.warmup):
         out = step()        # the previous outputs stay referenced while the next step runs, as in the timed loop: the
                             # caching allocator gets both output sets it will alternate between before the clock starts
-    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    for key in acc:
+        acc[key] = 0
     for _ in range(args.steps):
         out = step()
-        st = engine.stats()
-        gemm_ms += st["gemm_ms"]
-        gemm_fl += st["gemm_flops_timed"]
-        launches += st["gemm_launches"]
-    last = drain()          # the all-gather of the last step is inside the timed region
-    if last is not None:
-        out = last
-    torch.cuda.synchronize()
+    gemm_ms, gemm_fl, launches = acc["gemm_ms"], acc["gemm_flops_timed"], acc["gemm_launches"]
+    torch.cuda.synchronize()   # (every step ends with its own all-gathers complete on the compute stream)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -273,10 +260,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # untimed: the gathered matrix must hold this rank's rows bit for bit (rows are shard-independent)
-        chk = engine.forward(ids, src, -1 if lang is None else lang)          # `ids` == the retokenized matrix (checked above)
-        for full, loc in zip(out, chk):
-            if full is not None and not torch.equal(full[lo:hi], loc):
-                raise SystemExit(f"rank {rank}: all-gathered rows [{lo}, {hi}) differ from the local forward")
+        for b, ids_b in zip(blocks, ids_blocks):
+            chk = engine.forward(ids_b, src, lang_arg)          # `ids_b` == the retokenized matrix (checked above)
+            for full, loc in zip(out, chk):
+                if full is not None and not torch.equal(full[b.lo:b.hi], loc):
+                    raise SystemExit(f"rank {rank}: all-gathered rows [{b.lo}, {b.hi}) differ from the local forward")
     st = engine.stats()
 
     ms_per_step = dt / args.steps * 1e3
@@ -295,8 +283,7 @@ def main():
     except Exception:
         traffic = None
 
-    from oracle.hypernet_ref import flops_per_row
-    f_ref = flops_per_row(cfg, ids_all.shape[1])
+    f_ref = as_written_flops_per_row(dims, int(ids_all.shape[1]))
 
     result = {
         "metric": "predicted token-embeddings/sec (full target vocab)",
@@ -306,7 +293,8 @@ def main():
         "config": {"workload": f"{args.workload}: {rows}-row target vocab, hypernet E={dims.n_embd} E_in={dims.n_in_embd} "
                                f"H={dims.hidden} I={dims.intermediate} heads={dims.heads} layers={dims.layers} "
                                f"L={ids_all.shape[1]}, source_embeddings {src_dtype}",
-                   "rows": rows, "rows_per_gpu": hi - lo, "parallelism": f"vocab-row shards x{world} + RCCL all-gather" + ("" if world == 1 else (" (after each forward)" if args.serial_allgather else " (step i's gather on the RCCL stream under the forward of step i+1; last one inside the timed region)")),
+                   "rows": rows, "rows_per_gpu": sum(b.hi - b.lo for b in blocks),
+                   "parallelism": f"vocab-row shards x{world} + RCCL all-gather" + ("" if world == 1 else (" (after the forward)" if chunks == 1 else f" ({len(blocks)} row blocks per step: the all-gather of a block runs on the RCCL stream under the next block's forward; nothing overlaps across steps)")),
                    "precision": f"{args.precision} MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision != "f32" else "fp32 MFMA",
                    "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"],
                    "step": ("surface forms (byte strings resident on the device) -> GPU retokenization -> hypernet forward" if retok is not None

@@ -12,16 +12,16 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [[], ["--serial-allgather"]], ids=["overlapped", "serial"])
+@pytest.mark.parametrize("extra", [[], ["--serial-allgather"]], ids=["two-blocks", "serial"])
 def test_two_ranks_on_one_device(extra):
     env = dict(os.environ, ZETT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--workload", "tiny", "--rows", "3001", "--no-cpu-baseline"] + extra
+           "--workload", "tiny", "--rows", "20001", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]              # rank 0 prints ONE JSON line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["rows"] == 3001 and d["config"]["rows_per_gpu"] == 1501
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["rows"] == 20001 and d["config"]["rows_per_gpu"] == 10001
     assert d["value"] > 0 and "TEST HOOK" in d["data"]

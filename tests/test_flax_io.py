@@ -1,4 +1,5 @@
-"""Flax msgpack reader / name map — round trip through the in-repo writer."""
+"""Flax msgpack reader / name map: round trip through the in-repo writer, and a checkpoint
+assembled by hand in flax's on-disk layout with the Flax-side parameter names (tests/flax_fixture.py)."""
 import os
 
 import numpy as np
@@ -56,3 +57,28 @@ def test_hypernet_from_flax_checkpoint(tmp_path):
     for k, v in w.items():
         if k != "model.embeddings.word_embeddings.weight":
             assert torch.equal(model.state_dict()[k], torch.from_numpy(v)), k
+
+
+def test_hand_assembled_flax_checkpoint(tmp_path):
+    """Bytes laid out as flax.serialization writes them (ExtType 1 leaves, a bfloat16 leaf, a chunked array whose shape
+    is a {"0": .., "1": ..} dict), names as the Flax modules spell them: the loader must return the PyTorch state dict."""
+    import torch
+
+    from tests.flax_fixture import write_flax_checkpoint
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg, *_ = synth.workload("tiny")
+    w = synth.make_weights(cfg, 8)
+    ZettHypernetConfig(**cfg).save_pretrained(tmp_path)
+    expected = write_flax_checkpoint(str(tmp_path), cfg, w)
+    model = ZettHypernet.from_flax_checkpoint(str(tmp_path))
+    state = model.state_dict()
+    assert set(expected) | {"model.embeddings.word_embeddings.weight"} >= set(state) - {"model.embeddings.word_embeddings.weight"}
+    for k, v in expected.items():
+        assert torch.equal(state[k], torch.from_numpy(v)), k
+    # the bfloat16 leaf really was stored in two bytes per element, the chunked one in pieces
+    import msgpack
+    raw = msgpack.unpackb(open(os.path.join(tmp_path, "flax_model.msgpack"), "rb").read(), raw=False, strict_map_key=False)
+    shape, dtype_name, buf = msgpack.unpackb(raw["model"]["embeddings"]["position_embeddings"]["embedding"].data, raw=False)
+    assert dtype_name == "bfloat16" and len(buf) == 2 * int(np.prod(shape))
+    assert raw["fallback_embeddings"]["embedding"]["__msgpack_chunked_array__"] and isinstance(raw["fallback_embeddings"]["embedding"]["shape"], dict)

@@ -184,12 +184,34 @@ def test_transfer_cli_flags_match_reference():
 
 # ---- vocab-row sharding over ranks (gloo, world_size 2 and 3) --------------------------------------
 def test_shard_bounds_cover_rows():
-    from zett_amd.sharding import shard_bounds
+    from zett_amd.sharding import padded_rows, plan_blocks, shard_bounds
     for n in (0, 1, 7, 8, 1001, 32768):
         for world in (1, 2, 3, 8):
             spans = [shard_bounds(n, world, r) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    # row blocks: every global row belongs to exactly one (block, rank); block k starts where the gathered shards of the
+    # blocks before it end, so shards land in place; small vocabularies are not cut below 4 096 rows per shard
+    for n in (1, 7, 1001, 4096, 32768, 50370, 262144):
+        for world in (1, 2, 3, 8):
+            for chunks in (1, 2, 4):
+                per_rank = [plan_blocks(n, world, r, chunks) for r in range(world)]
+                nb = len(per_rank[0])
+                assert all(len(b) == nb for b in per_rank) and 1 <= nb <= chunks
+                owner = [0] * n
+                for r, blocks in enumerate(per_rank):
+                    off = 0
+                    for b in blocks:
+                        assert b.start == off and (b.start, b.rows, b.per) == (per_rank[0][blocks.index(b)].start, per_rank[0][blocks.index(b)].rows, per_rank[0][blocks.index(b)].per)
+                        assert b.lo == min(b.start + r * b.per, b.start + b.rows) and b.hi - b.lo <= b.per
+                        for i in range(b.lo, b.hi):
+                            owner[i] += 1
+                        off += world * b.per
+                    assert padded_rows(blocks, world) == off >= n
+                assert all(c == 1 for c in owner)
+                assert all(b.rows == world * b.per for b in per_rank[0][:-1])
+                if nb > 1:
+                    assert per_rank[0][0].per >= 4096
 
 
 _WORKER = r"""
@@ -217,6 +239,14 @@ def fake(rows):
     return x.sum(1, keepdim=True) * e, None, x[:, 0].clone()
 f_full = predict_sharded(fake, torch.from_numpy(ids)); f_single = fake(torch.from_numpy(ids))
 ok = ok and torch.equal(f_full[0], f_single[0]) and f_full[1] is None and torch.equal(f_full[2], f_single[2])
+# several row blocks per rank (the all-gather of a block overlaps the next block's forward): 5 003 rows, 2 and 3 blocks
+big = torch.arange(40003 * 7, dtype=torch.int64).reshape(40003, 7) % 1000
+for chunks in (1, 2, 3):
+    b_full = predict_sharded(fake, big, chunks=chunks); b_single = fake(big)
+    ok = ok and torch.equal(b_full[0], b_single[0]) and b_full[1] is None and torch.equal(b_full[2], b_single[2])
+from zett_amd.sharding import plan_blocks
+blocks = plan_blocks(40003, world, rank, 3)
+ok = ok and len(blocks) == 3 and all(b.rows == world * b.per for b in blocks[:-1]) and sum(b.rows for b in blocks) == 40003
 shapes = [tuple(t.shape) for t in full]
 if rank == 0:
     json.dump({{"ok": ok, "shapes": shapes}}, open({out!r}, "w"))

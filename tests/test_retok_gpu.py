@@ -111,3 +111,23 @@ def test_full_size_vocab_matches_oracle():
     got, got_tr = get_surface_form_matrix(tokens, 7, _spec(g))
     np.testing.assert_array_equal(got, want)
     assert got_tr == want_tr
+
+
+def test_special_tokens_outside_the_byte_alphabet_match_by_string():
+    """zett/utils.py:671-673 tests `token in all_special_tokens` on the character string BEFORE the byte lookup: a special
+    token holding characters outside the byte-level alphabet ('▁', a space) is matched, not a KeyError — and an
+    ordinary token with such a character still is one."""
+    import torch
+
+    from zett_amd.surface_forms import DeviceRetokenizer, HnTokenizerSpec
+    model = {"type": "Unigram", "unk_id": 0, "byte_fallback": False,
+             "vocab": [["<unk>", 0.0], ["<|begin▁of▁sentence|>", 0.0], ["<pad token>", 0.0], ["<s>", 0.0]] + [[c, -1.0] for c in "abcdef"] + [["ab", -0.5]]}
+    specials = ["<|begin▁of▁sentence|>", "<pad token>", "<s>"]
+    spec = HnTokenizerSpec.from_model_json(model, specials, [1, 2, 3], pad_token_id=2)
+    assert dict(spec.host_specials) == {"<|begin▁of▁sentence|>": 1, "<pad token>": 2}
+    rt = DeviceRetokenizer(spec, torch.device("cuda:0"))
+    out, n_trunc = rt(["abc", "<|begin▁of▁sentence|>", "<s>", "<pad token>", "fe"], 4)
+    want = [[10, 6, 2, 2], [1, 2, 2, 2], [3, 2, 2, 2], [2, 2, 2, 2], [9, 8, 2, 2]]
+    assert out.cpu().tolist() == want and n_trunc == 0
+    with pytest.raises(KeyError):
+        rt(["a▁b"], 4)

@@ -69,6 +69,7 @@ struct zett_hypernet {
     int time_gemm = 0;
     int cls_only_last = 1;
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
+    int gemm4d_min_k = 2048;          // 16-bit launches with K >= this take the four-wave direct-to-LDS tile
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
                                       // 7 = 256x256 four-wave direct-to-LDS, 8 = as 7 with the generic epilogue drain
     // workspace
@@ -358,6 +359,9 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "gemm_tile_order") {
         if (value < 0 || value > 1) return fail(ZETT_E_INVALID, "gemm_tile_order must be 0 or 1");
         h->gemm_tile_order = (int)value;
+    } else if (k == "gemm4d_min_k") {
+        if (value < 64) return fail(ZETT_E_INVALID, "gemm4d_min_k must be >= 64");
+        h->gemm4d_min_k = (int)value;
     } else if (k == "gemm_variant") {
         if (value != 0 && value != 1 && value != 2 && value != 3 && value != 7 && value != 8)
             return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto), 1 (128x128), 2 (256x256 register-staged), 3 (384x256), 7 (256x256 four-wave direct-to-LDS) or 8 (7 with the generic epilogue drain)");
@@ -479,7 +483,7 @@ struct Runner {
         if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift || e.residual)) variant = 2;
         // 16-bit operands, K >= 2048: the four-wave direct-to-LDS tile on 16x16x32 MFMAs (4-8 % ahead of the
         // register-staged eight-wave kernels on the launches of the benchmark step; identical bits).
-        if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= 2048) variant = 7;
+        if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= h->gemm4d_min_k) variant = 7;
         if ((variant == 7 || variant == 8) && is_f32) variant = 2;
         // the large tiles drain eight columns per lane with 16-byte accesses
         const bool wide_ok = N % 8 == 0 && (!e.out_lo || e.ld_lo % 8 == 0) && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0) &&

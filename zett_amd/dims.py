@@ -145,3 +145,17 @@ def weight_shapes(cfg) -> "OrderedDict[str, tuple]":
         s["bias_projection.weight"] = (1, h)
         s["bias_projection.bias"] = (1,)
     return s
+
+
+def as_written_flops_per_row(dims: "HypernetDims", seq: int) -> int:
+    """Algorithmic FLOPs the reference spends per target row (SURVEY.md §8d F_ref): every (row, position) through the
+    input projection and all encoder layers, pads included — what the throughput-derived "as written" TFLOP/s of
+    bench.py is quoted in.  (oracle/hypernet_ref.py:flops_per_row is the same formula on the oracle's side;
+    tests/test_oracle_golden.py pins both to the survey's three figures.)"""
+    e, e_in, h, i = dims.n_embd, dims.n_in_embd, dims.hidden, dims.intermediate
+    lp = seq + (1 if dims.embed_lang else 0)
+    heads_out = 1 if (dims.single_head or not dims.separate_out) else 2
+    e_out = e_in if dims.single_head else e
+    return (seq * (2 * e_in * h + 4 * h * i)
+            + dims.layers * (lp * (8 * h * h + 4 * h * i) + 4 * lp * lp * h)
+            + heads_out * (4 * h * i + 2 * h * e_out) + 2 * h)

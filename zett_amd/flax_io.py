@@ -6,14 +6,16 @@ layout).  This module does both steps with ``msgpack`` + numpy only (SURVEY.md Â
 
 * the wire format of ``flax.serialization`` â€” msgpack maps with ExtType 1 for ndarrays
   (``msgpack((shape, dtype name, C-order bytes))``), ExtType 3 for numpy scalars, and the
-  ``__msgpack_chunked_array__`` wrapper used for arrays above 2 GiB;
+  ``__msgpack_chunked_array__`` wrapper flax uses for arrays above 2**30 bytes, whose ``shape`` and ``chunks``
+  are tuples written as dicts ``{"0": ..., "1": ...}`` (flax's ``_tuple_to_dict``; a plain list is accepted too);
 * the name map of convert_to_pt.py: ``layers_N`` -> ``N``; ``kernel`` [in,out] -> ``weight`` [out,in];
   ``scale`` / ``embedding`` -> ``weight``; ``model.embeddings.lang_embedding`` -> ``lang_embeddings``;
   the 1-row Flax ``word_embeddings`` table (never read by the forward) is skipped.
 
-No Flax installation exists in the build image, so the reader is exercised on files produced by the
-writer below (round trip + name map against the PyTorch state dict); it has not been run on a file
-written by flax itself.
+No Flax installation exists in the build image, so the reader is exercised on (a) files produced by the
+writer below (round trip + name map against the PyTorch state dict) and (b) a checkpoint whose bytes
+tests/flax_fixture.py assembles by hand in flax's layout, with the Flax-side parameter names spelled out
+(tests/test_flax_io.py); it has not been run on a file written by flax itself.
 """
 from __future__ import annotations
 
@@ -48,7 +50,10 @@ def _unchunk(tree):
     if isinstance(tree, dict):
         if tree.get(_CHUNK_KEY):
             flat = np.concatenate([np.asarray(tree["chunks"][str(i)]).reshape(-1) for i in range(len(tree["chunks"]))])
-            return flat.reshape(tuple(tree["shape"]))
+            shape = tree["shape"]
+            if isinstance(shape, dict):                      # flax: _tuple_to_dict(arr.shape)
+                shape = [shape[str(i)] for i in range(len(shape))]
+            return flat.reshape(tuple(int(d) for d in shape))
         return {k: _unchunk(v) for k, v in tree.items()}
     return tree
 
@@ -65,7 +70,7 @@ def _pack_array(a: np.ndarray):
     if a.nbytes > _MAX_CHUNK:
         flat = a.reshape(-1)
         step = _MAX_CHUNK // a.dtype.itemsize
-        return {_CHUNK_KEY: True, "shape": list(a.shape),
+        return {_CHUNK_KEY: True, "shape": {str(i): int(d) for i, d in enumerate(a.shape)},
                 "chunks": {str(i): _pack_array(flat[o:o + step]) for i, o in enumerate(range(0, flat.size, step))}}
     return msgpack.ExtType(1, msgpack.packb((list(a.shape), a.dtype.name, a.tobytes("C")), use_bin_type=True))
 

@@ -1,17 +1,22 @@
 """Vocab-row sharding across the GPUs of one node (one process per GPU).
 
-Target-vocab rows are independent in every configuration the kept API supports, so
-the path shards by rows: rank p computes rows [p*ceil(N/P), (p+1)*ceil(N/P)) with
-replicated weights and source embeddings, and ONE all-gather per output matrix
-(RCCL over xGMI; backend "nccl" is RCCL on ROCm) reassembles the full [N, E]
-matrices on every GPU.  The reference shards the row batch over local devices the
-same way (scripts/transfer.py:90-91, zett/utils.py:26) and pads the last shard
-(scripts/transfer.py:63-67).  Per-row results do not depend on the shard a row
-lands in, so the gathered matrix is bit-identical for every P.
+Target-vocab rows are independent in every configuration the kept API supports, so the path shards by rows with
+replicated weights and source embeddings, and the only data-path collective is the all-gather that reassembles the
+full [N, E] matrices on every GPU (RCCL over xGMI; backend "nccl" is RCCL on ROCm).  The reference shards the row
+batch over local devices the same way (scripts/transfer.py:90-91, zett/utils.py:26) and pads the last shard
+(scripts/transfer.py:63-67).  Per-row results do not depend on the shard a row lands in, so the gathered matrix is
+bit-identical for every P (tests/test_full_size_gpu.py).
+
+Overlap.  A plain "compute the shard, then gather" leaves the GPUs idle for the whole exchange: at 8 GPUs the headline
+vocabulary is ~10 ms of compute per rank against ~0.94 GB received per rank.  A caller has ONE vocabulary, so there is
+no "next step" to hide the exchange under.  Instead the vocabulary is cut into `chunks` row blocks (multiples of the
+world size), each block is sharded over the ranks, and the all-gather of block k runs on RCCL's stream while the
+forward of block k + 1 computes; block k is gathered straight into its place of the final matrix (rank shards of one
+block are adjacent rows), so no re-assembly copy follows.  Only the last block's exchange is exposed.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Callable, List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -21,6 +26,86 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     per = -(-int(n_rows) // int(world))
     lo = min(rank * per, n_rows)
     return lo, min(lo + per, n_rows)
+
+
+class Block(NamedTuple):
+    """One row block of the vocabulary as this rank sees it."""
+    start: int      # first global row of the block
+    rows: int       # global rows in the block
+    per: int        # nominal shard height: every rank contributes `per` rows to the gather (the last ranks pad)
+    lo: int         # this rank's global rows [lo, hi) of the block (hi - lo <= per, 0 for surplus ranks)
+    hi: int
+
+
+def plan_blocks(n_rows: int, world: int, rank: int, chunks: int = 2, min_rows_per_shard: int = 4096) -> List[Block]:
+    """Cut [0, n_rows) into at most `chunks` blocks of equal size (a multiple of `world`, so that block k starts at row
+    k * world * per and its gathered shards land in place); fewer blocks when a shard would drop under
+    `min_rows_per_shard` rows: small forwards waste the GPU (256-row GEMM tiles on ~2.4 packed positions per row, the
+    per-distinct-id table that shrinks more slowly than the rows: a 4 096-row forward of the headline workload runs at
+    76 % of the 32 768-row rate per row, a 2 048-row one lower still), which would cost more than the exchange it hides.
+    At 8 GPUs the headline vocabulary (4 096 rows per rank) therefore stays one block per rank; 2 and 4 GPUs, and the
+    50 k / 262 k-row vocabularies, get two."""
+    n_rows, world, chunks = int(n_rows), int(world), max(1, int(chunks))
+    if n_rows <= 0:
+        return []
+    chunks = max(1, min(chunks, n_rows // max(1, world * min_rows_per_shard)))
+    per = -(-n_rows // (world * chunks))              # shard height of a full block
+    step = per * world
+    out = []
+    start = 0
+    while start < n_rows:
+        rows = min(step, n_rows - start)
+        p = per if rows == step else -(-rows // world)
+        lo = min(start + rank * p, start + rows)
+        hi = min(lo + p, start + rows)
+        out.append(Block(start, rows, p, lo, hi))
+        start += rows
+    return out
+
+
+def padded_rows(blocks: Sequence[Block], world: int) -> int:
+    """Rows of the buffers the blocks are gathered into (>= n_rows: the last block may carry padding rows at its end)."""
+    return sum(b.per * world for b in blocks)
+
+
+class RowGather:
+    """Asynchronous all-gather of row blocks into full matrices.  `add(block, tensors)` pads this rank's shard of the
+    block to its nominal height and starts one all_gather_into_tensor per tensor into rows [block.start, block.start +
+    world * block.per) of the corresponding full buffer; `finish(n_rows)` waits for everything and returns the full
+    tensors cut to n_rows.  Blocks must be added in order; every block but the last has rows == world * per, so the
+    shards of a block are adjacent rows of the final matrix and nothing has to be re-assembled."""
+
+    def __init__(self, blocks: Sequence[Block], group=None):
+        self.blocks = list(blocks)
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.total = padded_rows(self.blocks, self.world)
+        self.full: Optional[List[Optional[torch.Tensor]]] = None
+        self._works = []
+        self._keep = []
+
+    def add(self, block: Block, tensors: Sequence[Optional[torch.Tensor]]) -> None:
+        if self.full is None:
+            self.full = [None if t is None else torch.empty((self.total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in tensors]
+        for t, full in zip(tensors, self.full):
+            if t is None:
+                continue
+            t = t[: block.hi - block.lo]
+            if t.shape[0] != block.per:                  # short shard (end of the vocabulary, or a surplus rank): pad
+                pad = torch.zeros((block.per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                t = torch.cat([t, pad], dim=0)
+            t = t.contiguous()
+            dst = full[block.start: block.start + self.world * block.per]
+            self._works.append(dist.all_gather_into_tensor(dst, t, group=self.group, async_op=True))
+            self._keep.append(t)
+
+    def finish(self, n_rows: int):
+        for w in self._works:
+            w.wait()           # the compute stream waits for the collective; the host does not block (nccl)
+        self._works.clear()
+        self._keep.clear()
+        assert self.full is not None
+        return tuple(None if f is None else f[:n_rows] for f in self.full)
 
 
 def all_gather_rows(local: torch.Tensor, n_rows: int, per: int, group=None) -> torch.Tensor:
@@ -35,9 +120,10 @@ def all_gather_rows(local: torch.Tensor, n_rows: int, per: int, group=None) -> t
     return full[:n_rows]
 
 
-def predict_sharded(predict, target_surface_forms: torch.Tensor, group=None):
-    """Run `predict(rows) -> (pred_in, pred_out | None, bias)` on this rank's row shard
-    and all-gather the full result on every rank.
+def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group=None, chunks: int = 2):
+    """Run `predict(rows) -> (pred_in, pred_out | None, bias)` on this rank's rows and return the full result on every
+    rank.  The vocabulary is processed in `chunks` row blocks whose all-gathers overlap the next block's forward (module
+    docstring); chunks = 1 is the plain shard-then-gather.
 
     `predict` is typically ``lambda rows: hypernet(rows, source_embeddings=..., lang_index=...)``.
     Without an initialised process group this is just ``predict(target_surface_forms)``.
@@ -45,17 +131,17 @@ def predict_sharded(predict, target_surface_forms: torch.Tensor, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return predict(target_surface_forms)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    n = target_surface_forms.shape[0]
-    lo, hi = shard_bounds(n, world, rank)
-    per = shard_bounds(n, world, 0)[1]
-    rows = target_surface_forms[lo:hi]
-    if hi - lo == 0:                               # more ranks than rows: compute one dummy row
-        rows = target_surface_forms[:1]
-    pred_in, pred_out, bias = predict(rows)
-    if hi - lo == 0:
-        pred_in, bias = pred_in[:0], bias[:0]
-        pred_out = None if pred_out is None else pred_out[:0]
-    full_in = all_gather_rows(pred_in, n, per, group)
-    full_out: Optional[torch.Tensor] = None if pred_out is None else all_gather_rows(pred_out, n, per, group)
-    full_bias = all_gather_rows(bias, n, per, group)
-    return full_in, full_out, full_bias
+    n = int(target_surface_forms.shape[0])
+    blocks = plan_blocks(n, world, rank, chunks)
+    if not blocks:
+        return predict(target_surface_forms)
+    gather = RowGather(blocks, group)
+    for b in blocks:
+        rows = target_surface_forms[b.lo:b.hi]
+        if b.hi - b.lo == 0:                           # more ranks than rows in the block: compute one dummy row, contribute none
+            rows = target_surface_forms[:1]
+        outs = predict(rows)
+        if b.hi - b.lo == 0:
+            outs = tuple(None if t is None else t[:0] for t in outs)
+        gather.add(b, outs)
+    return gather.finish(n)

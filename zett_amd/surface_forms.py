@@ -72,6 +72,10 @@ class HnTokenizerSpec:
     special_ids: np.ndarray
     pad_token_id: int
     special_tokens: Tuple[str, ...] = ()
+    # special tokens the device table cannot hold (a character outside the byte-level alphabet, e.g. a space or
+    # '▁' inside '<|begin▁of▁sentence|>'): matched on the host BEFORE the byte lookup, as the reference does
+    # (zett/utils.py:671-673 tests `token in all_special_tokens` on the character string)
+    host_specials: Tuple[Tuple[str, int], ...] = ()
 
     @staticmethod
     def _pack(items: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
@@ -143,7 +147,8 @@ class HnTokenizerSpec:
                    fuse_unk=fuse_unk, byte_fallback=bool(model.get("byte_fallback", False)), byte_fallback_ids=bf_ids,
                    ignore_merges=bool(model.get("ignore_merges", False)), special_bytes=sb, special_offsets=so,
                    special_ids=np.asarray([i for _, i in sp], dtype=np.int32), pad_token_id=int(pad_token_id),
-                   special_tokens=tuple(special_tokens))
+                   special_tokens=tuple(special_tokens),
+                   host_specials=tuple((s, int(i)) for s, i in zip(special_tokens, special_ids) if not _raw(s)))
 
     @classmethod
     def from_tokenizer(cls, tokenizer) -> "HnTokenizerSpec":
@@ -213,8 +218,21 @@ class DeviceRetokenizer:
 
     def __call__(self, tokens: Sequence[str], maxlen: int) -> Tuple[torch.Tensor, int]:
         """int32 [len(tokens), maxlen] on the device + number of truncated tokens."""
+        host = dict(self.spec.host_specials)
+        patches = []
+        if host:                                   # exact string match first (zett/utils.py:671-673): such a token never reaches the byte table
+            tokens = list(tokens)
+            for i, t in enumerate(tokens):
+                sid = host.get(t)
+                if sid is not None:
+                    patches.append((i, sid))
+                    tokens[i] = ""                 # an empty token retokenizes to an all-pad row; column 0 is set below
         d_text, d_off, n = self.encode(tokens)
-        return self.run(d_text, d_off, n, maxlen, tokens)
+        out, n_trunc = self.run(d_text, d_off, n, maxlen, tokens)
+        if patches:
+            rows = torch.tensor([i for i, _ in patches], dtype=torch.long, device=out.device)
+            out[rows, 0] = torch.tensor([sid for _, sid in patches], dtype=out.dtype, device=out.device)
+        return out, n_trunc
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -149,6 +149,20 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
                              target_priors, args.min_k, args.n_samples, rng)
 
 
+def target_priors_of(tokenizer) -> np.ndarray:
+    """scripts/transfer.py:210-219: the Unigram scores of the target tokenizer where its model has them (padded with
+    0.0 for added tokens), uniform otherwise.  Rows are independent, so the priors only steer which rows share a batch
+    under --sample_batches."""
+    model = tokenizer._tokenizer.model
+    if hasattr(model, "get_scores"):
+        priors = list(model.get_scores())
+    else:
+        print("WARNING: using uniform priors, get_scores() not available.")
+        priors = [0.0] * len(tokenizer)
+    priors += [0.0] * (len(tokenizer) - len(priors))          # for added special tokens
+    return np.array(priors)
+
+
 def main(argv=None):
     import transformers
     from transformers import AutoConfig, AutoModel, AutoTokenizer, HfArgumentParser
@@ -172,7 +186,15 @@ def main(argv=None):
             langs = [x.strip() for x in open(args.lang_path).readlines()]
         lang_index = torch.tensor(langs.index(args.lang_code), dtype=torch.int32)
 
-    hypernet = AutoModel.from_pretrained(args.checkpoint_path).to(device)
+    # PyTorch weights if the checkpoint has them, else the reference's canonical flax_model.msgpack (scripts/transfer.py:
+    # 145-151 restores exactly that file), read without jax / flax by zett_amd/flax_io.py
+    has_pt = any(os.path.exists(os.path.join(args.checkpoint_path, f)) for f in
+                 ("model.safetensors", "pytorch_model.bin", "model.safetensors.index.json", "pytorch_model.bin.index.json"))
+    if not has_pt and os.path.exists(os.path.join(args.checkpoint_path, "flax_model.msgpack")):
+        from zett_amd.hypernet import ZettHypernet
+        hypernet = ZettHypernet.from_flax_checkpoint(args.checkpoint_path).to(device)
+    else:
+        hypernet = AutoModel.from_pretrained(args.checkpoint_path).to(device)
     hypernet.precision = {"bfloat16": "bf16", "float32": "f32", "float16": "f16"}.get(args.dtype, "bf16")
 
     source_tokenizer = AutoTokenizer.from_pretrained(args.target_model)
@@ -198,8 +220,7 @@ def main(argv=None):
     sfm, n_truncated = surface_form_matrix_device(tokens, config.hn_surface_maxlen, hn_tokenizer, device)  # :204-206
     print(f"Truncated {n_truncated} tokens.")
 
-    print("WARNING: using uniform priors, get_scores() not available.")
-    target_priors = np.zeros(len(tokenizer))
+    target_priors = target_priors_of(tokenizer)                                                          # :210-219
     pred_in, pred_out, pred_bias = predict_vocabulary(hypernet, sfm.long(), source_embeddings, lang_index, args, target_priors)
 
     special_src = list(source_tokenizer.all_special_ids)                                                  # :274-300
