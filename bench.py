@@ -272,13 +272,16 @@ def main():
     achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.precision]
 
-    # HBM traffic of the dominant kernel comes from PMC counters, which cannot be read from inside this
-    # process: the figure is the one measured by the committed rocprofv3 passes (profiles/r1l_pmc.md,
-    # tools/pmc_summary.py --json) for this same command, and only quoted for the workload it was taken on.
+    # HBM traffic of the dominant kernel comes from PMC counters, which cannot be read from inside this process: the
+    # figure is the one measured by the committed rocprofv3 passes (profiles/*_pmc.md, tools/pmc_summary.py --json) for
+    # this same command.  It is only quoted for the workload and precision it was taken on AND while the HIP sources
+    # still hash to what was profiled (zett_amd.build.source_hash): a stale file yields null, not an old number.
     traffic = None
     try:
+        from zett_amd.build import source_hash
         pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-        if args.workload == "mistral_gpt2_32k" and args.precision == "bf16" and world == 1 and not args.rows:
+        if (args.workload == "mistral_gpt2_32k" and args.precision == pmc.get("precision") and world == 1 and not args.rows
+                and pmc.get("source_hash") == source_hash()):
             traffic = pmc["hbm_bytes_per_launch"]
     except Exception:
         traffic = None

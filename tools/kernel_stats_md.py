@@ -8,9 +8,14 @@ import re
 import sys
 
 
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from kname import short as _short
+
+
 def short(name):
-    name = re.sub(r"\(.*$", "", name).replace("void ", "").replace("unsigned short", "bf16")
-    return name if name.startswith("zett::") else name[:40]
+    return _short(name, 40)
 
 
 def main(path):

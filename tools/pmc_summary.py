@@ -11,12 +11,18 @@ import collections
 import csv
 import glob
 import re
+import os
 import sys
 
 
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from kname import short as _short
+
+
 def short(name):
-    name = re.sub(r"\(.*$", "", name).replace("void ", "").replace("unsigned short", "bf16")
-    return name[:60]
+    return _short(name, 0)[:60]
 
 
 def main(dirs):
@@ -56,7 +62,10 @@ def main(dirs):
                 tot_n += n
         out = {"kernel": "zett::gemm*_tn_kernel (all instances, launch-weighted)", "hbm_bytes_per_launch": tot_b / max(tot_n, 1),
                "launches": int(tot_n), "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)",
-               "workload": "bench.py default (mistral_gpt2_32k, bf16)"}
+               "workload": "bench.py default (mistral_gpt2_32k)", "precision": os.environ.get("ZETT_PMC_PRECISION", "f16")}
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from zett_amd.build import source_hash
+        out["source_hash"] = source_hash()
         json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
     f = lambda x, fmt: "" if x is None else fmt % x
     for _, k, n, dur, rd, wr, bw, util, clk in sorted(rows):

@@ -11,7 +11,8 @@ bench="python $GRAFT_REPO_ROOT/bench.py"
 $bench 2>/dev/null | tail -1 > $out/bench_default.json
 for w in xlmr_gpt2 tinyllama_neox mistral_neox llama3_256k; do $bench --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_$w.json; done
 $bench --precision f32 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_default_f32.json
-$bench --precision f16 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_default_f16.json
+$bench --precision bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_default_bf16.json
+for r in 16384 8192 4096; do $bench --rows $r --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_rows_$r.json; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o $tag -- $bench --steps 3 --warmup 1 --no-cpu-baseline > $out/prof_bench.json 2> $out/prof.err
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   d=$out/pmc_$(echo $c | cut -d' ' -f1)

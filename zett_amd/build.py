@@ -19,6 +19,17 @@ HEADERS = tuple(sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))) + ("../
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC")
 
 
+def source_hash() -> str:
+    """sha256 over the HIP sources the library is built from: ties a measurement (profiles/pmc_traffic.json) to the
+    kernels it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in sorted(SOURCES + tuple(f for f in HEADERS if not f.startswith(".."))):
+        with open(os.path.join(CSRC, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
