@@ -5,12 +5,14 @@ Runs only in the build container (it imports /root/reference, which does not
 exist on the GPU box).  Nothing of the reference is copied: the fixtures hold
 inputs (or the seeds that regenerate them) and the reference's outputs.
 
-    python tests/golden/make_golden.py [forward] [retok]
+    python tests/golden/make_golden.py [forward] [big] [retok]
 
 forward  ->  fwd_*.npz   outputs of hf_hypernet.modeling_hypernet.ZettHypernet
              (reference hf_hypernet/modeling_hypernet.py:156-267) with the inner
              RobertaModel forced to eager attention, weights and
              inputs from zett_amd.synth seeds.
+big      ->  fwd_big_*.npz  the same reference forward on 640 rows of the four real shapes; outputs kept for a
+             32-row sample (the batch is what makes the GPU path take its 256x256 GEMM tiles).
 retok    ->  retok_*.json outputs of zett.utils.get_surface_form_matrix
              (reference zett/utils.py:651-689) on synthetic hn tokenizers, with
              jax/flax/optax stubbed by MagicMock so the module imports.
@@ -141,8 +143,28 @@ def gen_forward():
         del w, src
 
 
+def gen_forward_big():
+    """Real shapes at a batch large enough that the GPU path takes its 256x256 GEMM tiles (M = packed positions >= 1 400):
+    640 rows go through the REFERENCE, the fixture keeps the inputs of all of them and the reference's outputs for a
+    32-row sample (`sample` holds the row indices) — the tiles that carry the benchmark meet reference outputs directly."""
+    for name in ("xlmr_gpt2", "tinyllama_neox", "mistral_gpt2_32k", "llama3_256k"):
+        cfg, _, src_dtype, hist = synth.workload(name)
+        seed, rows = 11, 640
+        w = synth.make_weights(cfg, seed)
+        src = synth.make_source_embeddings(cfg, seed, dtype=src_dtype)
+        ids = synth.make_surface_forms(cfg, rows, seed=seed, hist=hist, n_special=2)
+        lang = 7 if cfg.get("hn_embed_lang_id") else None
+        out = _reference_forward(cfg, w, ids, src, lang)
+        sample = np.sort(np.concatenate([[0, 2, rows - 1], np.random.default_rng(seed).choice(np.arange(3, rows - 1), 29, replace=False)]))
+        out = [None if o is None else o[sample] for o in out]
+        _save(f"fwd_big_{name}", cfg, seed, ids, src_dtype, lang, out, extra=dict(sample=sample.astype(np.int32)))
+        del w, src
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["forward", "retok"]
+    if "big" in what:
+        gen_forward_big()
     if "forward" in what:
         gen_forward()
     if "retok" in what:

@@ -29,10 +29,26 @@ def test_forward_oracle_matches_reference(path):
         np.testing.assert_allclose(out[1], case["pred_out"], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("path", util.golden_cases("fwd_big_xlmr*.npz") + util.golden_cases("fwd_big_tinyllama*.npz"),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_forward_oracle_matches_reference_big_batch(path):
+    """The 640-row fixtures (outputs of the reference for a 32-row sample): the oracle on the same rows."""
+    case = util.load_case(path)
+    w = synth.make_weights(case["cfg"], case["seed"])
+    src = synth.make_source_embeddings(case["cfg"], case["seed"], dtype=case["src_dtype"])
+    out = hypernet_ref.forward(w, case["cfg"], case["ids"][case["sample"]], src, case["lang"])
+    np.testing.assert_allclose(out[0], case["pred_in"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out[2], case["bias"], rtol=0, atol=2e-5)
+    if case["pred_out"] is not None:
+        np.testing.assert_allclose(out[1], case["pred_out"], rtol=0, atol=2e-5)
+
+
 def test_flops_per_row_matches_survey():
     for name, want in (("xlmr_gpt2", 0.2743e9), ("tinyllama_neox", 1.8467e9), ("mistral_neox", 7.3844e9)):
         cfg, *_ = synth.workload(name)
         assert abs(hypernet_ref.flops_per_row(cfg, 7) - want) / want < 1e-3
+        from zett_amd.dims import HypernetDims, as_written_flops_per_row
+        assert as_written_flops_per_row(HypernetDims.from_config(cfg), 7) == hypernet_ref.flops_per_row(cfg, 7)
 
 
 def test_byte_table_matches_reference():

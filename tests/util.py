@@ -36,7 +36,8 @@ def load_case(path):
     return dict(
         name=os.path.basename(path)[:-4], cfg=cfg, seed=int(g["seed"]), ids=g["ids"],
         src_dtype=str(g["src_dtype"]), lang=None if lang < 0 else lang,
-        pred_in=g["pred_in"], pred_out=g["pred_out"] if "pred_out" in g.files else None, bias=g["bias"])
+        pred_in=g["pred_in"], pred_out=g["pred_out"] if "pred_out" in g.files else None, bias=g["bias"],
+        sample=g["sample"].astype(np.int64) if "sample" in g.files else None)      # fwd_big_*: outputs kept for these rows only
 
 
 def all_pad_rows(cfg, ids):
