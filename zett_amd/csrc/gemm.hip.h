@@ -272,6 +272,7 @@ struct GemmArgs {
     int M, N, K;
     GemmEpilogue<T> epi;
     int tile_order = 0;     // gemm4d only: 0 = column-tile-major groups (default), 1 = row-tile-major groups (A/B option)
+    int group = 0;          // gemm4d only: column tiles per group (order 0) / row tiles per group (order 1); 0 = the default (4)
 };
 
 constexpr int GEMM_BM = 128;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // tiles and its next 32 are the next 8 row tiles of the SAME 4 column tiles: the W panels (the small operand, MALL-
     // resident) stay, the A panels stream.  Against row-major groups of 4 (what gemm8r/gemm8x use): +5 % on the
     // K = 8192 launches, equal on the others (tools/gemm_bench g4dv, G4DX_MAP / G4DX_GROUP_M sweep).
-    constexpr int GROUP_N = 4;
+    const int GROUP_N = g.group > 0 ? g.group : 4;
     int tm, tn;
     if (g.tile_order == 0) {
         const int group_size = GROUP_N * tiles_m;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         tn = first_n + (wg % group_size) % gn;
         tm = (wg % group_size) / gn;
     } else {                      // zett_set_option("gemm_tile_order", 1): ZETT_GROUP_M row tiles first, as gemm8r / gemm8x
-        constexpr int GROUP_M = ZETT_GROUP_M;
+        const int GROUP_M = g.group > 0 ? g.group : ZETT_GROUP_M;
         const int group_size = GROUP_M * tiles_n;
         const int first_m = (wg / group_size) * GROUP_M;
         const int gm = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
