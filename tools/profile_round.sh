@@ -13,11 +13,11 @@ for w in xlmr_gpt2 tinyllama_neox mistral_neox llama3_256k; do $bench --workload
 $bench --precision f32 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_default_f32.json
 $bench --precision bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_default_bf16.json
 for r in 16384 8192 4096; do $bench --rows $r --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_rows_$r.json; done
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o $tag -- $bench --steps 3 --warmup 1 --no-cpu-baseline > $out/prof_bench.json 2> $out/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o $tag -- $bench --steps 3 --warmup 1 --no-cpu-baseline --no-alt-precision > $out/prof_bench.json 2> $out/prof.err
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   d=$out/pmc_$(echo $c | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o t -- $bench --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $d.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o t -- $bench --steps 1 --warmup 1 --no-cpu-baseline --no-alt-precision > /dev/null 2> $d.err
 done
-ZETT_GEMM_LOG=1 $bench --steps 1 --warmup 1 --no-cpu-baseline 2> $out/gemm_launch_log.txt > /dev/null
+ZETT_GEMM_LOG=1 $bench --steps 1 --warmup 1 --no-cpu-baseline --no-alt-precision 2> $out/gemm_launch_log.txt > /dev/null
 find $out -name "*.db" -delete; find $out -name "*agent_info*" -delete
 du -sh $out
