@@ -140,7 +140,7 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
  * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "gemm_variant"
  * (0 = choose per launch, 1 = 128x128, 2 = 256x256 register-staged eight-wave,
  * 3 = 384x256 LDS-DMA, 7 = 256x256 four-wave direct-to-LDS (the choice for 16-bit
- * operands and K >= 2048), 8 = as 7 with the generic epilogue drain; all produce
+ * operands and K >= "gemm4d_min_k", default 512), 8 = as 7 with the generic epilogue drain; all produce
  * identical bits; a forced variant falls back to 2 where its preconditions do not
  * hold), "gemm_tile_order" (A/B only: 0 = the order in which gemm4d walks column
  * tiles first, default; 1 = row tiles first; same bits). */

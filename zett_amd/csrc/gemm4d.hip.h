@@ -78,7 +78,8 @@ __device__ int g4d_stagger_ticks, g4d_stagger_mode;
 //   LO         only the 16-bit output (out_lo), bias + ACT            (QKV, FFN up, ProjectorBlock dense1)
 //   F32        only the fp32 output (out_f32), bias + ACT + residual  (attention output, FFN down, dense2, heads)
 //   F32_SCALE  as F32 with the Rescaler (scale, shift)                (output heads)
-enum { G4D_EPI_GENERIC = 0, G4D_EPI_LO = 1, G4D_EPI_F32 = 2, G4D_EPI_F32_SCALE = 3 };
+//   BOTH       fp32 AND 16-bit output of the same values, bias only   (input_projection.0: residual + operand of the ProjectorBlock)
+enum { G4D_EPI_GENERIC = 0, G4D_EPI_LO = 1, G4D_EPI_F32 = 2, G4D_EPI_F32_SCALE = 3, G4D_EPI_BOTH = 4 };
 constexpr int G4D_EPI_STRIDE = 132;                                   // floats per staged row: 128 columns + 4 of padding
 constexpr int G4D_EPI_REGION = 64 * G4D_EPI_STRIDE * 4;               // bytes per wave
 constexpr int G4D_LDS_BYTES = 4 * G4D_EPI_REGION;                     // 132 KiB (the K loop uses the first 128)
@@ -422,6 +423,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const f32x4 x = {v[u * 4], v[u * 4 + 1], v[u * 4 + 2], v[u * 4 + 3]};
                         if (RES) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(d), "v"(x) : "memory");
                         else *(f32x4*)d = x;
+                        if constexpr (EPI == G4D_EPI_BOTH)      // the same four values as the next GEMM's operand: 8 bytes per lane, 256 per row
+                            store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, make_float4(x[0], x[1], x[2], x[3]));
                     }
                 }
             }
@@ -481,6 +484,8 @@ inline int gemm4d_epi_mode(const GemmArgs<T>& g) {
     if (e.out_f32_b || e.split_col < g.N) return G4D_EPI_GENERIC;
     if (e.res_stats && (e.act != ACT_NONE || !e.residual)) return G4D_EPI_GENERIC;
     if (e.out_lo && !e.out_f32 && !e.residual && !e.scale && !e.shift && g.N % 8 == 0 && e.ld_lo % 8 == 0) return G4D_EPI_LO;
+    if (e.out_f32 && e.out_lo && !e.residual && !e.scale && !e.shift && e.act == ACT_NONE && g.N % 4 == 0 && e.ld_f32 % 4 == 0 && e.ld_lo % 4 == 0)
+        return G4D_EPI_BOTH;
     if (e.out_f32 && !e.out_lo && g.N % 4 == 0 && e.ld_f32 % 4 == 0 && (!e.residual || e.ld_res % 4 == 0)) {
         if (e.scale && e.shift && !e.residual && e.act == ACT_NONE) return G4D_EPI_F32_SCALE;
         // (instantiated: no activation with or without the residual, tanh-GELU with it; anything else is generic)
@@ -523,6 +528,7 @@ template <typename T>
 inline hipError_t launch_gemm4d(const GemmArgs<T>& g, hipStream_t stream, bool force_generic = false) {
     const int mode = force_generic ? G4D_EPI_GENERIC : gemm4d_epi_mode(g);
     if (mode == G4D_EPI_F32_SCALE) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE>(g, stream);
+    if (mode == G4D_EPI_BOTH) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_BOTH>(g, stream);
     switch (g.epi.act) {
         case ACT_GELU_TANH: return launch_gemm4d_act<T, ACT_GELU_TANH>(g, stream, mode);
         case ACT_GELU_ERF: return launch_gemm4d_act<T, ACT_GELU_ERF>(g, stream, mode);

@@ -69,7 +69,7 @@ struct zett_hypernet {
     int time_gemm = 0;
     int cls_only_last = 1;
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
-    int gemm4d_min_k = 2048;          // 16-bit launches with K >= this take the four-wave direct-to-LDS tile
+    int gemm4d_min_k = 512;           // 16-bit launches with K >= this take the four-wave direct-to-LDS tile (r2: with the streamlined epilogues it is ahead of gemm8r down to K = 768: +1.8 % on the XLM-R workload)
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
                                       // 7 = 256x256 four-wave direct-to-LDS, 8 = as 7 with the generic epilogue drain
     // workspace
