@@ -135,7 +135,8 @@ int zett_get_stats(const zett_hypernet* h, zett_stats* out);
  * against free HBM before the first forward. */
 int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, int64_t* out_bytes);
 
-/* Options: "max_chunk_tokens" (default 131072), "time_gemm" (0/1: bracket every
+/* Options: "max_chunk_tokens" (packed positions per encoder chunk, >= 1024; default: 12 GiB of per-position
+ * workspace, at least 131072 positions: 131072 at H = 4096, ~640 k at H = 768), "time_gemm" (0/1: bracket every
  * GEMM launch with HIP events on the launch stream and report the sum in
  * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "gemm_variant"
  * (0 = choose per launch, 1 = 128x128, 2 = 256x256 register-staged eight-wave,

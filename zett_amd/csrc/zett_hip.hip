@@ -65,7 +65,7 @@ struct zett_hypernet {
     float* head_shift = nullptr;
     std::vector<void*> owned;         // everything to hipFree at destroy
     // options
-    int64_t max_chunk_tokens = 131072;     // ~90 KB of workspace per packed position at H = 4096: 11.8 GB per chunk
+    int64_t max_chunk_tokens = 0;          // 0 = auto: chunk_token_cap() below (131 072 at H = 4096, more for narrower hypernets)
     int time_gemm = 0;
     int cls_only_last = 1;
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
@@ -175,9 +175,20 @@ static size_t plan_i32_bytes(const zett_config& c, int64_t N, int seq) {
     return ((size_t)N + (N + 1) + V + (V + 1) + V + 2 * (size_t)max_tok + 1 + scan_scratch) * 4;
 }
 
+// Packed positions per encoder chunk when the caller has not set "max_chunk_tokens": 12 GiB of per-position workspace,
+// never under 131 072 positions.  That is 131 072 at H = 4096 (112 KB per position), 230 k at H = 2048, 640 k at
+// H = 768: a narrow hypernet's vocabulary stays ONE chunk (the 50 350-row XLM-R workload packs 169 283 positions; cut at
+// 131 072 it ran a second, 38 211-position chunk whose GEMMs and ~35 extra launches cost 5 % of the step).
+static int64_t chunk_token_cap(const zett_config& c, size_t es) {
+    const size_t wide = (size_t)std::max(c.intermediate, 3 * c.hidden);
+    const size_t per_token = (size_t)c.n_in_embd * es + 3 * (size_t)c.hidden * 4 + 3 * (size_t)c.hidden * es + wide * es + 24;
+    return std::max<int64_t>(131072, (int64_t)(((size_t)12 << 30) / per_token));
+}
+
 static WorkspaceSizes workspace_sizes(const zett_config& c, size_t es, int seq, int64_t Ttot, int64_t D, int64_t cap) {
     const int lam = c.embed_lang ? 1 : 0;
     WorkspaceSizes w{};
+    if (cap <= 0) cap = chunk_token_cap(c, es);
     w.chunk_tokens = std::max<int64_t>(std::min<int64_t>(cap, std::max<int64_t>(Ttot, D)), seq + lam);
     const size_t MC = (size_t)w.chunk_tokens, MCS = MC + 384;
     const size_t wide = (size_t)std::max(c.intermediate, 3 * c.hidden);
