@@ -4,7 +4,7 @@
 //   gather_src      A2/A3: source-embedding gather + in_scaler + fallback select
 //   layernorm_rows  LayerNorm over H (+ the RobertaEmbeddings add for the embed variant)
 //   attention_rows  per-row bidirectional attention over <= L' packed positions
-//   cls_gather      position-0 readout + bias head
+//   (the position-0 readout + bias head is the last LayerNorm launch: layernorm_rows with LnReadout)
 //
 // All of them are one-pass streaming kernels: 16-byte vector accesses, one
 // workgroup (or wave) per row, no inter-workgroup communication.
@@ -38,6 +38,7 @@ struct PlanArrays {
     int32_t* id_list;       // [<=V] slot -> id
     int32_t* tok_slot;      // [T]   table slot of the token, -1 = language token
     int32_t* tok_pos;       // [T]   position index (for position_embeddings)
+    int32_t* tok_row;       // [T]   row the packed position belongs to
     uint8_t* tok_key;       // [T]   visible as key
     int32_t* err;           // [1]   set to 1 + row on an out-of-range id
 };
@@ -168,6 +169,7 @@ __global__ void plan_tokens_kernel(const int32_t* __restrict__ sfm, int64_t n_ro
         if (uniform || vis || j == 0) {
             p.tok_slot[t] = p.id_slot[id];
             p.tok_pos[t] = j;
+            p.tok_row[t] = (int32_t)n;
             p.tok_key[t] = vis ? 1 : 0;
             ++t;
         }
@@ -175,6 +177,7 @@ __global__ void plan_tokens_kernel(const int32_t* __restrict__ sfm, int64_t n_ro
     if (lam) {
         p.tok_slot[t] = -1;
         p.tok_pos[t] = seq;
+        p.tok_row[t] = (int32_t)n;
         p.tok_key[t] = 1;
     }
 }
@@ -275,6 +278,28 @@ struct LnEmbed {
     const float* pos_emb;      // [max_positions, H]
     const float* lang;         // [H] or null
     int lang_pos;              // L
+    const int32_t* tok_row;    // [T] row of a packed position             } where the embed variant writes a position:
+    const int32_t* row_offset; // [N+1]                                     } chunk_row() below
+    int64_t row0;              // first vocabulary row of the chunk
+    int rows;                  // vocabulary rows in the chunk
+};
+
+// Row order of a chunk's hidden-state buffers: POSITION 0 FIRST.  A chunk covers vocabulary rows [row0, row0 + rows) =
+// packed positions [tok0, tok0 + m) of the plan.  Buffer row r < rows holds position 0 of vocabulary row row0 + r; the other
+// m - rows packed positions follow in plan order.  Only position 0 is read out (modeling_hypernet.py:234), so what the
+// last layer and the output heads consume is then simply the first `rows` rows of every buffer — no gather in front of
+// the last layer's query GEMM, none in front of the heads; GEMMs and LayerNorms do not care about the order of rows.
+//   t_rel = packed position - tok0, row_rel = its vocabulary row - row0, first = it is the row's position 0
+__device__ __forceinline__ int chunk_row(int t_rel, int row_rel, bool first, int rows) {
+    return first ? row_rel : rows + t_rel - row_rel - 1;
+}
+
+// Position-0 readout fused into the LAST LayerNorm launch (which runs on the first `rows` buffer rows only): the bias
+// head (modeling_hypernet.py:260-265) is a dot product of the fp32 LayerNorm output the kernel holds anyway.
+struct LnReadout {
+    const float* bias_w;       // [H] bias_projection.weight, or null (predict_bias off: the bias output is 0)
+    const float* bias_b;       // [1]
+    float* out_bias;           // [rows] (already offset to the chunk's first row), or null: no readout
 };
 
 constexpr int LN_MAX_VEC = 8;   // 8 float4 x 256 threads = 8192 columns in registers
@@ -286,13 +311,15 @@ constexpr int LN_MAX_VEC = 8;   // 8 float4 x 256 threads = 8192 columns in regi
 // normalised row in fp32 (hoisted table, output heads); stats_out = (mean, rstd) of the row, from which the residual
 // epilogues and the position-0 readout recompute the fp32 row with ln_affine instead of reading it back;
 // sum_out (embed variant) = the pre-LayerNorm sum itself, which those consumers then read.
-template <typename T, bool EMBED, int TPR = 256>
+// The embed variant takes packed position tok0 + r and writes buffer row chunk_row(...) (position 0 first).
+// READOUT: the instantiation that also carries the bias head (LnReadout); the others ignore the argument.
+template <typename T, bool EMBED, int TPR = 256, bool READOUT = false>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ in, int ld_in, int rows, int H,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps,
                                                              float* __restrict__ out_f32, T* __restrict__ out_lo,
                                                              float* __restrict__ stats_out, float* __restrict__ sum_out,
-                                                             LnEmbed emb, int tok0) {
+                                                             LnEmbed emb, int tok0, LnReadout readout) {
     __shared__ float red[4];
     const int r = blockIdx.x * (256 / TPR) + (int)threadIdx.x / TPR;
     if (r >= rows) return;                 // TPR = 64: whole waves leave, and no barrier follows
@@ -302,11 +329,14 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     const float* x = nullptr;
     const float* posr = nullptr;
     bool is_lang = false;
+    int ro = r;                            // output row
     if constexpr (EMBED) {
         const int slot = emb.tok_slot[tok0 + r];
         is_lang = slot < 0;
         x = is_lang ? emb.lang : emb.table + (size_t)slot * H;
         posr = emb.pos_emb + (size_t)emb.tok_pos[tok0 + r] * H;
+        const int n = emb.tok_row[tok0 + r];
+        ro = chunk_row(r, (int)(n - emb.row0), emb.row_offset[n] == tok0 + r, emb.rows);
     } else {
         x = in + (size_t)r * ld_in;
     }
@@ -348,14 +378,19 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     }
     const float var = row_sum(q) / (float)H;
     const float rstd = 1.0f / sqrtf(var + eps);
-    if (stats_out && tid == 0) *(float2*)(stats_out + 2 * (size_t)r) = make_float2(mean, rstd);
+    if (stats_out && tid == 0) *(float2*)(stats_out + 2 * (size_t)ro) = make_float2(mean, rstd);
+    float dot = 0.f;
     auto emit = [&](int idx, float4 a) {
         const float4 g = *(const float4*)(gamma + idx * 4), b = *(const float4*)(beta + idx * 4);
         const float4 o = make_float4(ln_affine(a.x, mean, rstd, g.x, b.x), ln_affine(a.y, mean, rstd, g.y, b.y),
                                      ln_affine(a.z, mean, rstd, g.z, b.z), ln_affine(a.w, mean, rstd, g.w, b.w));
-        if (EMBED && sum_out) *(float4*)(sum_out + (size_t)r * H + idx * 4) = a;
-        if (out_f32) *(float4*)(out_f32 + (size_t)r * H + idx * 4) = o;
-        if (out_lo) store_lo4<T>(out_lo + (size_t)r * H + idx * 4, o);
+        if (EMBED && sum_out) *(float4*)(sum_out + (size_t)ro * H + idx * 4) = a;
+        if (out_f32) *(float4*)(out_f32 + (size_t)ro * H + idx * 4) = o;
+        if (out_lo) store_lo4<T>(out_lo + (size_t)ro * H + idx * 4, o);
+        if (READOUT && readout.bias_w) {
+            const float4 w = *(const float4*)(readout.bias_w + idx * 4);
+            dot += (o.x * w.x + o.y * w.y) + (o.z * w.z + o.w * w.w);
+        }
     };
 #pragma unroll
     for (int j = 0; j < LN_MAX_VEC; ++j) {
@@ -363,6 +398,12 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
         if (idx < nvec) emit(idx, v[j]);
     }
     for (int idx = tid + TPR * LN_MAX_VEC; idx < nvec; idx += TPR) emit(idx, load(idx));
+    if constexpr (READOUT) {
+        if (readout.out_bias) {            // (uniform over the launch: every thread of the row takes the reduction)
+            const float tot = row_sum(dot);
+            if (tid == 0) readout.out_bias[r] = readout.bias_w ? tot + readout.bias_b[0] : 0.f;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -401,6 +442,7 @@ template <typename T> __device__ __forceinline__ void store8_16bit(T* p, const f
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&o)[8]) { store8_16bit<bf16_t>(p, o); }
 template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&o)[8]) { store8_16bit<f16_t>(p, o); }
 
+// Rows of q / k / v / ctx are BUFFER rows (position 0 first, chunk_row above); the plan arrays are indexed by packed position.
 // q: [T, ldq] per packed position, or (cls_only) [rows, ldq] holding the query of position 0
 // of each row; k, v: [T, ldkv]; ctx: [T or rows, H].  cls_only: compute query 0 only and
 // write it at ctx[row_local] (compact [rows, H] output for the last layer).
@@ -426,9 +468,11 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
     const bool uniform = row_uniform[n];
     const int nq = cls_only ? 1 : (t1 - t0);
     const int ccol = active ? col : 0;
+    // buffer row of packed position t of this row (position 0 first: chunk_row above)
+    auto brow = [&](int t) -> size_t { return (size_t)chunk_row(t, rl, t == t0, rows); };
     for (int qi = 0; qi < nq; ++qi) {
         float q[8];
-        load8<T>(qbase + (cls_only ? (size_t)rl : (size_t)(t0 + qi)) * ldq + ccol, q);
+        load8<T>(qbase + (cls_only ? (size_t)rl : brow(t0 + qi)) * ldq + ccol, q);
         // one pass over the keys with a running maximum (online softmax): K and V are read once
         float mx = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
@@ -436,8 +480,9 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
         for (int kj = t0; kj < t1; ++kj) {
             if (!uniform && !tok_key[tok0 + kj]) continue;
             float k[8], v[8];
-            load8<T>(kbase + (size_t)kj * ldkv + ccol, k);
-            load8<T>(vbase + (size_t)kj * ldkv + ccol, v);
+            const size_t kr = brow(kj);
+            load8<T>(kbase + kr * ldkv + ccol, k);
+            load8<T>(vbase + kr * ldkv + ccol, v);
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) s = fmaf(q[c], k[c], s);
@@ -455,64 +500,9 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] *= inv;
         if (active) {
-            const size_t orow = cls_only ? (size_t)rl : (size_t)(t0 + qi);
+            const size_t orow = cls_only ? (size_t)rl : brow(t0 + qi);
             store8<T>(ctx + orow * H + col, acc);
         }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Position-0 readout (modeling_hypernet.py:231-234) + bias head (:260-265).
-// src rows are either packed tokens (index row_offset[n] - tok0) or already compact.  The hidden state arrives as
-// the pre-LayerNorm sum `s` + per-row statistics (ln_stats) + the LayerNorm's gamma / beta: its fp32 value is
-// ln_affine(s, ...), recomputed here (with ln_stats == null, `s` IS the fp32 hidden state).
-//   c_stats != null : forward the row as it is — c_f32 = s, c_stats = statistics (the position-0 rows of the last
-//                     layer's input, whose consumer is again a residual epilogue that applies ln_affine itself)
-//   c_stats == null : c_f32 = the fp32 hidden state (input of the output heads), bias head on it
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict__ s_f32, const T* __restrict__ z_lo,
-                                                         int H, const int32_t* __restrict__ row_offset, int64_t row0,
-                                                         int rows, int tok0, int compact,
-                                                         const float* __restrict__ ln_stats, const float* __restrict__ ln_gamma,
-                                                         const float* __restrict__ ln_beta,
-                                                         float* __restrict__ c_f32, T* __restrict__ c_lo, float* __restrict__ c_stats,
-                                                         const float* __restrict__ bias_w, const float* __restrict__ bias_b,
-                                                         float* __restrict__ out_bias) {
-    __shared__ float red[4];
-    const int r = blockIdx.x;
-    if (r >= rows) return;
-    const size_t srow = compact ? (size_t)r : (size_t)(row_offset[row0 + r] - tok0);
-    const float* zf = s_f32 + srow * H;
-    float mean = 0.f, rstd = 1.f;
-    if (ln_stats) { const float2 st = *(const float2*)(ln_stats + 2 * srow); mean = st.x; rstd = st.y; }
-    if (c_stats && threadIdx.x == 0) *(float2*)(c_stats + 2 * (size_t)r) = make_float2(mean, rstd);
-    const bool normalise = ln_stats != nullptr && c_stats == nullptr;
-    float dot = 0.f;
-    for (int c = threadIdx.x * 4; c < H; c += 1024) {
-        float4 a = *(const float4*)(zf + c);
-        if (normalise) {
-            const float4 g = *(const float4*)(ln_gamma + c), b = *(const float4*)(ln_beta + c);
-            a = make_float4(ln_affine(a.x, mean, rstd, g.x, b.x), ln_affine(a.y, mean, rstd, g.y, b.y),
-                            ln_affine(a.z, mean, rstd, g.z, b.z), ln_affine(a.w, mean, rstd, g.w, b.w));
-        }
-        if (c_f32) *(float4*)(c_f32 + (size_t)r * H + c) = a;
-        if (c_lo) {
-            if (z_lo) {
-                if constexpr (sizeof(T) == 2) *(uint2*)(c_lo + (size_t)r * H + c) = *(const uint2*)(z_lo + srow * H + c);
-                else *(float4*)(c_lo + (size_t)r * H + c) = *(const float4*)(z_lo + srow * H + c);
-            } else {
-                store_lo4<T>(c_lo + (size_t)r * H + c, a);
-            }
-        }
-        if (bias_w) {
-            const float4 w = *(const float4*)(bias_w + c);
-            dot += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
-        }
-    }
-    if (out_bias) {
-        const float tot = block_sum_256(dot, red);
-        if (threadIdx.x == 0) out_bias[row0 + r] = bias_w ? tot + bias_b[0] : 0.f;
     }
 }
 

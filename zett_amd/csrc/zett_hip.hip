@@ -170,9 +170,9 @@ struct WorkspaceSizes {
 static size_t plan_i32_bytes(const zett_config& c, int64_t N, int seq) {
     const int64_t V = (int64_t)c.original_vocab_size + c.n_extra;
     const int64_t max_tok = N * (int64_t)(seq + (c.embed_lang ? 1 : 0));
-    // row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] err[1] scan scratch
+    // row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] tok_row[T] err[1] scan scratch
     const size_t scan_scratch = 2 * ((size_t)std::max<int64_t>(N, V) / SCAN_CHUNK + 2) + 1;
-    return ((size_t)N + (N + 1) + V + (V + 1) + V + 2 * (size_t)max_tok + 1 + scan_scratch) * 4;
+    return ((size_t)N + (N + 1) + V + (V + 1) + V + 3 * (size_t)max_tok + 1 + scan_scratch) * 4;
 }
 
 // Packed positions per encoder chunk when the caller has not set "max_chunk_tokens": 12 GiB of per-position workspace,
@@ -197,7 +197,7 @@ static WorkspaceSizes workspace_sizes(const zett_config& c, size_t es, int seq, 
     w.f32_rows = MC * c.hidden * 4;
     w.lo_rows = MCS * c.hidden * es;
     w.big = MCS * wide * es;
-    w.stats = 3 * MC * 2 * sizeof(float);          // (mean, rstd) per row: two LayerNorms in flight + the position-0 rows
+    w.stats = 2 * MC * 2 * sizeof(float);          // (mean, rstd) per row: two LayerNorms in flight
     return w;
 }
 
@@ -522,14 +522,15 @@ struct Runner {
         if (e != hipSuccess) rc = fail(ZETT_E_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
     }
 
-    void layernorm(const float* in, int rows, const float* gamma, const float* beta, float eps, float* of, T* ol, float* stats = nullptr) {
+    void layernorm(const float* in, int rows, const float* gamma, const float* beta, float eps, float* of, T* ol, float* stats = nullptr,
+                   LnReadout readout = LnReadout{}) {
         if (rc || rows <= 0) return;
-        if (h->cfg.hidden <= 2048)       // a wave per row, four rows per workgroup
-            hipLaunchKernelGGL((layernorm_rows_kernel<T, false, 64>), dim3((rows + 3) / 4), dim3(256), 0, st, in, h->cfg.hidden, rows,
-                               h->cfg.hidden, gamma, beta, eps, of, ol, stats, (float*)nullptr, LnEmbed{}, 0);
-        else
-            hipLaunchKernelGGL((layernorm_rows_kernel<T, false, 256>), dim3(rows), dim3(256), 0, st, in, h->cfg.hidden, rows,
-                               h->cfg.hidden, gamma, beta, eps, of, ol, stats, (float*)nullptr, LnEmbed{}, 0);
+        const int H = h->cfg.hidden;
+        const dim3 grid = H <= 2048 ? dim3((rows + 3) / 4) : dim3(rows);      // H <= 2048: a wave per row, four rows per workgroup
+#define ZETT_LN_LAUNCH(TPR, RO) hipLaunchKernelGGL((layernorm_rows_kernel<T, false, TPR, RO>), grid, dim3(256), 0, st, in, H, rows, H, gamma, beta, eps, of, ol, stats, (float*)nullptr, LnEmbed{}, 0, readout)
+        if (readout.out_bias) { if (H <= 2048) ZETT_LN_LAUNCH(64, true); else ZETT_LN_LAUNCH(256, true); }
+        else { if (H <= 2048) ZETT_LN_LAUNCH(64, false); else ZETT_LN_LAUNCH(256, false); }
+#undef ZETT_LN_LAUNCH
         check("layernorm");
     }
 
@@ -571,7 +572,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     h->ev_shape.clear();
 
     // ---- plan ---------------------------------------------------------------------
-    // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] err[1] scan scratch
+    // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] tok_row[T] err[1] scan scratch
     if (int rc = h->plan_i32.reserve(plan_i32_bytes(c, N, seq))) return rc;
     if (int rc = h->plan_u8.reserve((size_t)N + (size_t)max_tok)) return rc;
     PlanArrays p{};
@@ -583,6 +584,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     p.id_list = base; base += V;
     p.tok_slot = base; base += max_tok;
     p.tok_pos = base; base += max_tok;
+    p.tok_row = base; base += max_tok;
     p.err = base; base += 1;
     int32_t* scan_tmp = base;
     p.row_uniform = h->plan_u8.as<uint8_t>();
@@ -642,11 +644,10 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     T* Ct = h->ct.as<T>();
     // LayerNorm statistics.  The encoder keeps its hidden state as (pre-LayerNorm sum, statistics, gamma, beta):
     // the LayerNorm kernel writes the 16-bit GEMM operand and the two statistics, and whoever needs the fp32
-    // LayerNorm output (the next residual epilogue, the position-0 readout) recomputes it with ln_affine from the
-    // sum it reads anyway.  Zf and PRE alternate as the sum buffers.
+    // LayerNorm output (the next residual epilogue) recomputes it with ln_affine from the sum it reads anyway.
+    // Zf and PRE alternate as the sum buffers, STa and STb as their statistics.
     float* STa = h->lnstats.as<float>();
     float* STb = STa + 2 * (size_t)MC;
-    float* STc = STb + 2 * (size_t)MC;
 
     Runner<T> R{h, st};
     R.a_rows_readable = (long)MCS;
@@ -669,6 +670,9 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     if (R.rc) return R.rc;
 
     // ---- encoder + heads over row chunks -----------------------------------------------
+    // Buffer rows of a chunk are ordered POSITION 0 FIRST (rowops.hip.h chunk_row): rows [0, rows) are position 0 of the
+    // chunk's vocabulary rows, the other packed positions follow.  What the last layer and the heads consume — position 0
+    // only (modeling_hypernet.py:234) — is then the first `rows` rows of every buffer, with no gather in between.
     const float* lang_vec = lam ? R.Wf("lang_embeddings.weight") + (size_t)lang_index * H : nullptr;
     const float scaling = 1.0f / std::sqrt((float)(H / c.heads));
     const int groups = (H + 511) / 512;
@@ -682,7 +686,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         h->stats.chunks += 1;
 
         LnEmbed emb{TBL, p.tok_slot, p.tok_pos, R.Wf("model.embeddings.token_type_embeddings.weight"),
-                    R.Wf("model.embeddings.position_embeddings.weight"), lang_vec, seq};
+                    R.Wf("model.embeddings.position_embeddings.weight"), lang_vec, seq, p.tok_row, p.row_offset, r0, rows};
         // hidden state = (sum buffer, statistics, gamma, beta); the embeddings' LayerNorm starts it in (Zf, STb)
         float* hs_sum = Zf;
         float* hs_stats = STb;
@@ -690,19 +694,19 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         const float* hs_beta = R.Wf("model.embeddings.LayerNorm.bias");
         if (H <= 2048)
             hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 64>), dim3((m + 3) / 4), dim3(256), 0, st, (const float*)nullptr, H, m, H,
-                               hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, Zt, hs_stats, hs_sum, emb, tok0);
+                               hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, Zt, hs_stats, hs_sum, emb, tok0, LnReadout{});
         else
             hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 256>), dim3(m), dim3(256), 0, st, (const float*)nullptr, H, m, H,
-                               hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, Zt, hs_stats, hs_sum, emb, tok0);
+                               hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, Zt, hs_stats, hs_sum, emb, tok0, LnReadout{});
         R.check("embed_layernorm");
 
-        int zrows = m;            // rows of the current hidden state (m packed, or `rows` once compact)
-        bool compact = false;
+        int zrows = m;            // rows of the current hidden state: m, or `rows` (position 0 only) in a position-0-only last layer
         auto other = [&](float* b) { return b == Zf ? PRE : Zf; };
         auto other_stats = [&](float* b) { return b == STa ? STb : STa; };
         for (int l = 0; l < c.layers && !R.rc; ++l) {
             const std::string lp = "model.encoder.layer." + std::to_string(l) + ".";
-            const bool cls_only = h->cls_only_last && l == c.layers - 1;
+            const bool last = l == c.layers - 1;
+            const bool cls_only = h->cls_only_last && last;
             const T* wqkv = (const T*)h->qkv_w[l];
             const int64_t waves = (int64_t)rows * groups;
             if (!cls_only) {
@@ -714,13 +718,9 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                                    H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 0, CTX);
                 R.check("attention");
             } else {
-                // Only hidden[:,0] is consumed after this layer (modeling_hypernet.py:234): keys and
-                // values for every position, the query (and everything downstream) for position 0.
-                // The position-0 rows of the hidden state move to (Cf, STc) as they are (sum + statistics).
-                hipLaunchKernelGGL((cls_gather_kernel<T>), dim3(rows), dim3(256), 0, st, (const float*)hs_sum, (const T*)Zt, H,
-                                   p.row_offset, r0, rows, tok0, 0, (const float*)hs_stats, hs_gamma, hs_beta, Cf, Ct, STc,
-                                   (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
-                R.check("cls_gather(layer input)");
+                // Only hidden[:,0] is consumed after this layer (modeling_hypernet.py:234): keys and values for every
+                // position, the query (and everything downstream) for position 0 = the first `rows` rows of the
+                // hidden state (sum, statistics and 16-bit operand alike).
                 T* KV = BIG;                              // [m, 2H]
                 T* Q = BIG + (size_t)m * 2 * H;           // [rows, H]  (rows <= m, BIG holds >= m x 3H)
                 GemmEpilogue<T> ekv = R.epi();
@@ -728,18 +728,16 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 R.gemm(Zt, H, wqkv + (size_t)H * H, H, m, 2 * H, H, ekv);
                 GemmEpilogue<T> eq = R.epi();
                 eq.bias = h->qkv_b[l]; eq.out_lo = Q; eq.ld_lo = H;
-                R.gemm(Ct, H, wqkv, H, rows, H, H, eq);
+                R.gemm(Zt, H, wqkv, H, rows, H, H, eq);
                 hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                                    (const T*)Q, (size_t)H, (const T*)KV, (const T*)KV + H, (size_t)2 * H,
                                    H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 1, CTX);
                 R.check("attention(position 0)");
-                hs_sum = Cf; hs_stats = STc;              // the compact hidden state; Zf / PRE / STa / STb are free again
                 zrows = rows;
-                compact = true;
             }
             // attention output: sum = dense(ctx) + LN(hidden)   (the residual is the LayerNorm of hs_sum, recomputed)
-            float* s1 = hs_sum == Cf ? PRE : other(hs_sum);
-            float* st1 = hs_stats == STc ? STa : other_stats(hs_stats);
+            float* s1 = other(hs_sum);
+            float* st1 = other_stats(hs_stats);
             GemmEpilogue<T> eo = R.epi();
             eo.bias = R.Wf(lp + "attention.output.dense.bias"); eo.residual = hs_sum; eo.ld_res = H;
             eo.res_stats = hs_stats; eo.res_gamma = hs_gamma; eo.res_beta = hs_beta;
@@ -761,18 +759,19 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             R.gemm(BIG, I, R.Wlo(lp + "output.dense.weight"), I, zrows, H, I, ef);
             hs_gamma = R.Wf(lp + "output.LayerNorm.weight");
             hs_beta = R.Wf(lp + "output.LayerNorm.bias");
-            R.layernorm(s2, zrows, hs_gamma, hs_beta, c.ln_eps_encoder, nullptr, Zt, st2);
             hs_sum = s2; hs_stats = st2;
+            // (the last layer's output LayerNorm is the readout below: position 0 only, whatever the layer computed)
+            if (!last) R.layernorm(s2, zrows, hs_gamma, hs_beta, c.ln_eps_encoder, nullptr, Zt, st2);
         }
         if (R.rc) break;
 
-        // position-0 readout + bias head (modeling_hypernet.py:231-234, 260-265): Cf = fp32 hidden[:,0], Ct its operand copy
-        // (hs_sum is never Cf here: the last layer writes Zf / PRE)
-        hipLaunchKernelGGL((cls_gather_kernel<T>), dim3(rows), dim3(256), 0, st, (const float*)hs_sum, (const T*)Zt, H,
-                           p.row_offset, r0, rows, tok0, compact ? 1 : 0, (const float*)hs_stats, hs_gamma, hs_beta, Cf, Ct, (float*)nullptr,
-                           c.predict_bias ? R.Wf("bias_projection.weight") : (const float*)nullptr,
-                           c.predict_bias ? R.Wf("bias_projection.bias") : (const float*)nullptr, out_bias);
-        R.check("cls_gather");
+        // position-0 readout + bias head (modeling_hypernet.py:231-234, 260-265) = the last LayerNorm, on the first `rows`
+        // buffer rows: Cf = fp32 hidden[:,0] (residual of the heads' ProjectorBlocks), Ct its operand copy, bias head fused.
+        // (no encoder layer: the embeddings' LayerNorm is simply taken again for those rows)
+        R.layernorm(hs_sum, rows, hs_gamma, hs_beta, c.ln_eps_encoder, Cf, Ct, nullptr,
+                    LnReadout{c.predict_bias ? R.Wf("bias_projection.weight") : (const float*)nullptr,
+                              c.predict_bias ? R.Wf("bias_projection.bias") : (const float*)nullptr, out_bias + r0});
+        R.check("readout");
 
         // output heads (modeling_hypernet.py:236-258)
         {
