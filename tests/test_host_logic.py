@@ -270,6 +270,58 @@ def test_predict_sharded_gloo(tmp_path, world):
     assert res["shapes"] == [[37, 64], [37, 64], [37]]
 
 
+_CLI_WORKER = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r})
+from zett_amd.transfer import Args, predict_vocabulary
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+class Cfg: n_embd = 4
+class Fake:                      # a row-wise deterministic stand-in for the hypernetwork: this test covers the CLI's sharding
+    config = Cfg()
+    calls = 0
+    def __call__(self, rows, source_embeddings=None, lang_index=None):
+        Fake.calls += rows.shape[0]
+        x = rows.float(); e = torch.arange(1, 5, dtype=torch.float32)
+        return x.sum(1, keepdim=True) * e, (x.sum(1, keepdim=True) + 1) * e, x[:, 0].clone()
+sfm = (torch.arange(1003 * 7, dtype=torch.int64).reshape(1003, 7) * 7919) % 1000
+want = Fake()(sfm); Fake.calls = 0
+ok = True
+# every rank draws a DIFFERENT local generator: the batch order must still agree (seed broadcast from rank 0)
+got = predict_vocabulary(Fake(), sfm, None, None, Args(output="", batch_size=128), rng=np.random.default_rng(100 + rank))
+ok = ok and all(torch.equal(a, b) for a, b in zip(got, want))
+per_rank_rows = Fake.calls; Fake.calls = 0
+got = predict_vocabulary(Fake(), sfm, None, None, Args(output="", do_batching=False))
+ok = ok and all(torch.equal(a, b) for a, b in zip(got, want))
+pri = -np.abs(np.random.default_rng(3).standard_normal(1003))
+got = predict_vocabulary(Fake(), sfm, None, None, Args(output="", batch_size=128, sample_batches=True, n_samples=40, min_k=5), target_priors=pri)
+ok = ok and all(torch.allclose(a, b, rtol=1e-6, atol=0) for a, b in zip(got, want))
+flag = torch.tensor([1 if ok else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+rows = torch.tensor([per_rank_rows]); dist.all_reduce(rows)
+if rank == 0:
+    json.dump({{"ok": bool(flag.item()), "rows_all_ranks": int(rows.item())}}, open({out!r}, "w"))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_cli_prediction_shards_batches_over_ranks_gloo(tmp_path):
+    """zett_amd.transfer.predict_vocabulary under torchrun: every batch is cut over the ranks (scripts/transfer.py:90-91),
+    all ranks end with the whole result, and the ranks together compute each batch once (not once per rank)."""
+    import json
+    out = os.path.join(tmp_path, "res.json")
+    script = os.path.join(tmp_path, "worker.py")
+    open(script, "w").write(_CLI_WORKER.format(repo=REPO, out=out))
+    port = str(29700 + (os.getpid() % 200))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                    "--master-addr", "127.0.0.1", "--master-port", port, script],
+                   check=True, env=env, timeout=600, cwd="/tmp")
+    res = json.load(open(out))
+    assert res["ok"], "sharded CLI prediction differs from the single-process result"
+    assert res["rows_all_ranks"] == 8 * 128          # 1003 rows in 8 batches of 128 (the last one padded), each computed once
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/hf_hypernet"), reason="reference only exists in the build container")
 def test_install_remote_code_routes_reference_checkpoint(tmp_path):
     """AutoModel(..., trust_remote_code=True) on a reference-written checkpoint returns the zett_amd class."""

@@ -40,17 +40,14 @@ def _lines(seed):
     return out[:3000]
 
 
-@pytest.mark.parametrize("fmt", ["pt", "flax"])
-def test_transfer_cli_end_to_end(tmp_path, fmt):
-    """fmt = "flax": the hypernet checkpoint directory holds config.json + flax_model.msgpack only (the reference's
-    canonical format, scripts/transfer.py:145-151), written byte by byte in flax's layout by tests/flax_fixture.py."""
-    from transformers import AutoModelForCausalLM, AutoTokenizer, GPT2Config, GPT2LMHeadModel
+def _make_checkpoints(tmp_path, fmt):
+    """A tiny GPT-2 language model + tokenizer, a second tokenizer as transfer target, and a hypernetwork checkpoint in
+    PyTorch or flax layout.  Returns (dirs, cfg, weights, lm, src_tok)."""
+    from transformers import GPT2Config, GPT2LMHeadModel
 
     import zett_amd  # noqa: F401
-    from zett_amd.byte_level import convert_to_byte_level
     from zett_amd.config import ZettHypernetConfig
     from zett_amd.hypernet import ZettHypernet
-    from zett_amd.transfer import main
 
     src_dir, hn_dir, tgt_dir, out_dir = (str(tmp_path / d) for d in ("lm", "hypernet", "target_tok", "out"))
     src_tok = _train_bpe(_lines(1), 600)
@@ -75,9 +72,28 @@ def test_transfer_cli_end_to_end(tmp_path, fmt):
         weights = dict(weights, **write_flax_checkpoint(hn_dir, cfg, weights))      # (position embeddings come back bf16-rounded)
         assert not any(f.endswith((".safetensors", ".bin")) for f in os.listdir(hn_dir))
     src_tok.save_pretrained(hn_dir)                       # the checkpoint ships its hn tokenizer (transfer.py:153-157)
+    return (src_dir, hn_dir, tgt_dir, out_dir), cfg, weights, lm, src_tok
 
-    main(["--output", out_dir, "--checkpoint_path", hn_dir, "--tokenizer_name", tgt_dir, "--target_model", src_dir,
-          "--model_class", "AutoModelForCausalLM", "--dtype", "float32", "--batch_size", "256"])
+
+def _cli_args(dirs, out_dir=None):
+    src_dir, hn_dir, tgt_dir, out = dirs
+    return ["--output", out_dir or out, "--checkpoint_path", hn_dir, "--tokenizer_name", tgt_dir, "--target_model", src_dir,
+            "--model_class", "AutoModelForCausalLM", "--dtype", "float32", "--batch_size", "256"]
+
+
+@pytest.mark.parametrize("fmt", ["pt", "flax"])
+def test_transfer_cli_end_to_end(tmp_path, fmt):
+    """fmt = "flax": the hypernet checkpoint directory holds config.json + flax_model.msgpack only (the reference's
+    canonical format, scripts/transfer.py:145-151), written byte by byte in flax's layout by tests/flax_fixture.py."""
+    from transformers import AutoModelForCausalLM, AutoTokenizer
+
+    from zett_amd.byte_level import convert_to_byte_level
+    from zett_amd.transfer import main
+
+    dirs, cfg, weights, lm, src_tok = _make_checkpoints(tmp_path, fmt)
+    src_dir, hn_dir, tgt_dir, out_dir = dirs
+
+    main(_cli_args(dirs))
 
     new_tok = AutoTokenizer.from_pretrained(out_dir)
     new_lm = AutoModelForCausalLM.from_pretrained(out_dir)
@@ -101,3 +117,33 @@ def test_transfer_cli_end_to_end(tmp_path, fmt):
     util.assert_f32_close(emb, want, "spliced input embeddings")
     assert np.array_equal(emb[special_id], source[src_tok.eos_token_id])
     assert os.path.exists(os.path.join(out_dir, "bias.safetensors"))
+
+
+def test_transfer_cli_two_processes_match_one(tmp_path):
+    """`torchrun --nproc-per-node 2 scripts/transfer.py ...`: every batch is sharded over the ranks and all-gathered
+    (scripts/transfer.py:90-91), rank 0 writes the model, and the written embeddings equal the single-process run bit for
+    bit.  On a 1-GPU box both ranks share cuda:0 and the collectives go through gloo (ZETT_ONE_DEVICE_TEST); with two or
+    more GPUs the same command runs on RCCL (tests/test_multi_gpu.py covers the nccl collectives)."""
+    import subprocess
+    import sys
+
+    from safetensors.torch import load_file
+
+    from zett_amd.transfer import main
+
+    dirs, *_ = _make_checkpoints(tmp_path, "pt")
+    one, two = str(tmp_path / "out1"), str(tmp_path / "out2")
+    main(_cli_args(dirs, one))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 2:
+        env["ZETT_ONE_DEVICE_TEST"] = "1"
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29620 + os.getpid() % 100), os.path.join(repo, "scripts", "transfer.py")] + _cli_args(dirs, two),
+                         cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    a, b = load_file(os.path.join(one, "model.safetensors")), load_file(os.path.join(two, "model.safetensors"))
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(load_file(os.path.join(one, "bias.safetensors"))["bias"], load_file(os.path.join(two, "bias.safetensors"))["bias"])

@@ -139,14 +139,66 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
     """The whole-vocabulary prediction of scripts/transfer.py:221-270 (batching flags honoured)."""
     args = args or Args(output="")
 
-    def predict(rows):
+    def predict_local(rows):
         return hypernet(rows, source_embeddings=source_embeddings, lang_index=lang_index)
+
+    # One process per GPU (torchrun): every batch is cut into row shards over the ranks and all-gathered, as the reference
+    # shards every batch over its local devices (scripts/transfer.py:90-91, zett/utils.py:26).  All ranks then hold the
+    # whole result; they must walk the SAME batches, so the batch order comes from one seed, broadcast from rank 0.
+    predict = predict_local
+    if _world_size() > 1:
+        from zett_amd.sharding import predict_sharded
+
+        def predict(rows):
+            return predict_sharded(predict_local, rows)
+
+        rng = _shared_rng(rng, target_surface_form_matrix.device)
 
     if not args.do_batching:   # scripts/transfer.py:243-262 pads to a multiple of 128 for XLA; no need here
         return predict(target_surface_form_matrix)
     n_embd = hypernet.config.n_embd
     return batched_inference(predict, target_surface_form_matrix, n_embd, args.batch_size, args.sample_batches,
                              target_priors, args.min_k, args.n_samples, rng)
+
+
+def _world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _shared_rng(rng, device) -> np.random.Generator:
+    """A generator every rank seeds identically: rank 0 draws the seed (from `rng` when the caller gave one)."""
+    import torch.distributed as dist
+    seed = int((rng or np.random.default_rng()).integers(0, 2 ** 62))
+    t = torch.tensor([seed], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=0)
+    return np.random.default_rng(int(t.item()))
+
+
+def init_distributed(device_index_from_env: bool = True):
+    """torchrun launch (WORLD_SIZE > 1 in the environment): bind this process to its GPU and join the RCCL group
+    (backend "nccl" is RCCL on ROCm).  Returns the device; a plain `python scripts/transfer.py` stays single-GPU."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # ZETT_ONE_DEVICE_TEST=1 (test hook, as in bench.py): every rank uses cuda:0 and the collectives go through gloo, so
+    # that the multi-process control flow runs on a 1-GPU box; never set otherwise.
+    one_device = os.environ.get("ZETT_ONE_DEVICE_TEST") == "1"
+    if world > 1 and device_index_from_env:
+        torch.cuda.set_device(0 if one_device else int(os.environ.get("LOCAL_RANK", "0")))
+    device = torch.device("cuda", torch.cuda.current_device())
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    return device
 
 
 def target_priors_of(tokenizer) -> np.ndarray:
@@ -174,7 +226,7 @@ def main(argv=None):
     (args,) = HfArgumentParser([Args]).parse_args_into_dataclasses(argv)
     if not torch.cuda.is_available():
         raise SystemExit("scripts/transfer.py needs an MI355X: torch.cuda.is_available() is False")
-    device = torch.device("cuda", torch.cuda.current_device())
+    device = init_distributed()          # one process per GPU under torchrun; a single process otherwise
 
     tokenizer = AutoTokenizer.from_pretrained(args.tokenizer_name)
     config = AutoConfig.from_pretrained(args.checkpoint_path)
@@ -223,6 +275,10 @@ def main(argv=None):
     target_priors = target_priors_of(tokenizer)                                                          # :210-219
     pred_in, pred_out, pred_bias = predict_vocabulary(hypernet, sfm.long(), source_embeddings, lang_index, args, target_priors)
 
+    if _rank() != 0:          # every rank holds the whole prediction; one of them writes the model
+        import torch.distributed as dist
+        dist.barrier()
+        return
     special_src = list(source_tokenizer.all_special_ids)                                                  # :274-300
     special_dst = [tokenizer.get_vocab()[t] for t in source_tokenizer.all_special_tokens]
     os.makedirs(args.output, exist_ok=True)
@@ -242,6 +298,9 @@ def main(argv=None):
         save_file({"bias": pred_bias.cpu()}, os.path.join(args.output, "bias.safetensors"))
     downstream.config.vocab_size = len(tokenizer)
     downstream.save_pretrained(args.output, max_shard_size="20GB")
+    if _world_size() > 1:
+        import torch.distributed as dist
+        dist.barrier()
 
 
 if __name__ == "__main__":
