@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--gemm-tile-order", type=int, default=0, help="A/B only: zett_set_option gemm_tile_order (0 = default)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force one GEMM tile variant (zett_set_option gemm_variant); 0 = per-launch choice")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the side measurement of the same steps in the other 16-bit arithmetic (N = 1; reported as alt_precision, never as value)")
+    ap.add_argument("--no-pair-dedupe", action="store_true", help="A/B only: layer 0's Q/K/V per packed position instead of per distinct (source id, position) pair (zett_set_option pair_dedupe 0; same bits)")
     ap.add_argument("--no-retokenize", action="store_true", help="A/B only: start every step from the id matrix instead of the surface forms")
     ap.add_argument("--chunks", type=int, default=2, help="N > 1: row blocks per step (zett_amd/sharding.py: the all-gather of a block overlaps the next block's forward)")
     ap.add_argument("--serial-allgather", action="store_true", help="N > 1: one block per step, i.e. forward, then all-gather (A/B)")
@@ -185,6 +186,8 @@ def main():
         engine.set_option("gemm_tile_order", args.gemm_tile_order)
     if args.max_chunk_tokens:
         engine.set_option("max_chunk_tokens", args.max_chunk_tokens)
+    if args.no_pair_dedupe:
+        engine.set_option("pair_dedupe", 0)
     # the same weights in the OTHER 16-bit arithmetic, for the side measurement after the timed region (N = 1 only)
     alt_precision = {"f16": "bf16", "bf16": "f16"}.get(args.precision) if (world == 1 and not args.no_alt_precision) else None
     alt_engine = None
@@ -192,6 +195,8 @@ def main():
         alt_engine = HipEngine(dims, 1e-5, device, alt_precision)
         alt_engine.load_weights(weights)
         alt_engine.set_option("time_gemm", 1)
+        if args.no_pair_dedupe:
+            alt_engine.set_option("pair_dedupe", 0)
     if rank != 0 or args.no_cpu_baseline or world > 1:
         weights_keep = None
     else:
@@ -308,6 +313,7 @@ def main():
                    "parallelism": f"vocab-row shards x{world} + RCCL all-gather" + ("" if world == 1 else (" (after the forward)" if chunks == 1 else f" ({len(blocks)} row blocks per step: the all-gather of a block runs on the RCCL stream under the next block's forward; nothing overlaps across steps)")),
                    "precision": f"{args.precision} MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision != "f32" else "fp32 MFMA",
                    "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"],
+                   "distinct_id_position_pairs_rank0": st["distinct_positions"],
                    "step": ("surface forms (byte strings resident on the device) -> GPU retokenization -> hypernet forward" if retok is not None
                             else "id matrix -> hypernet forward [A/B: --no-retokenize]") + ("" if world == 1 else " -> all-gather")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ZETT_ABI_VERSION 1
+#define ZETT_ABI_VERSION 2      /* 2: zett_stats gained distinct_positions */
 
 enum zett_status {
     ZETT_OK = 0,
@@ -89,6 +89,8 @@ typedef struct zett_stats {
     double gemm_ms;               /* sum of GEMM launch durations (timing on)      */
     int64_t gemm_launches;
     double gemm_flops_timed;      /* flops of the launches counted in gemm_ms      */
+    int64_t distinct_positions;   /* rows of layer 0's Q/K/V launch: distinct (source id, position) pairs when that
+                                     lever is taken (one chunk, >= 15 % repeats), else packed_tokens            */
 } zett_stats;
 
 typedef struct zett_hypernet zett_hypernet;

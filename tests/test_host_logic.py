@@ -25,13 +25,13 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.zett_abi_version() == 1
+    assert lib.zett_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     from zett_amd import _lib
     assert ctypes.sizeof(_lib.ZettConfig) == 16 * 4 + 2 * 4
-    assert ctypes.sizeof(_lib.ZettStats) == 8 * 8
+    assert ctypes.sizeof(_lib.ZettStats) == 9 * 8
     # zett_retok_model: int,int,4 ptr,double,int,ptr,3 int,ptr,int,int,3 ptr  (natural alignment)
     assert _lib.ZettRetokModel.piece_scores.offset == 32
     assert _lib.ZettRetokModel.unigram_min_score.offset == 40

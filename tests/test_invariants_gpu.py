@@ -59,6 +59,17 @@ def test_row_order_shard_and_chunk_independence_tiny(precision):
     for a, b in zip(ref, full):
         if a is not None:
             torch.testing.assert_close(a, b, rtol=0, atol=0)
+    # layer 0's Q/K/V once per distinct (source id, position) pair vs once per packed position
+    assert _eq(_run(eng, ids, src, 2), full)
+    st_on = eng.stats()
+    assert st_on["distinct_positions"] < 0.85 * st_on["packed_tokens"], st_on          # (the lever is taken on this workload)
+    eng.set_option("pair_dedupe", 0)
+    ref = _run(eng, ids, src, 2)
+    st_off = eng.stats()
+    eng.set_option("pair_dedupe", 1)
+    assert _eq(ref, full)
+    assert st_off["distinct_positions"] == st_off["packed_tokens"] == st_on["packed_tokens"]
+    assert st_off["executed_flops"] > st_on["executed_flops"]
 
 
 @pytest.mark.parametrize("precision,name,rows", [("bf16", "tiny", 3000), ("f16", "tiny", 3000), ("f32", "tiny", 1500),

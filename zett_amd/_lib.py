@@ -32,10 +32,13 @@ class ZettConfig(C.Structure):
         ("ln_eps_encoder", C.c_float), ("ln_eps_projector", C.c_float)]
 
 
+ABI_VERSION = 2      # ZETT_ABI_VERSION of include/zett_hip.h
+
+
 class ZettStats(C.Structure):
     _fields_ = [("rows", C.c_int64), ("packed_tokens", C.c_int64), ("distinct_ids", C.c_int64),
                 ("chunks", C.c_int64), ("executed_flops", C.c_double), ("gemm_ms", C.c_double),
-                ("gemm_launches", C.c_int64), ("gemm_flops_timed", C.c_double)]
+                ("gemm_launches", C.c_int64), ("gemm_flops_timed", C.c_double), ("distinct_positions", C.c_int64)]
 
 
 class ZettRetokModel(C.Structure):
@@ -92,6 +95,9 @@ def load():
             fn = getattr(lib, name)
             if name != "zett_last_error":
                 fn.restype = C.c_int
+        if lib.zett_abi_version() != ABI_VERSION:      # struct layouts below are those of this version
+            raise RuntimeError(f"{path} has ABI version {lib.zett_abi_version()}, this package expects {ABI_VERSION}: "
+                               "rebuild it (`python -m zett_amd.build`)")
         _lib = lib
     return _lib
 

@@ -39,6 +39,13 @@ struct PlanArrays {
     int32_t* tok_slot;      // [T]   table slot of the token, -1 = language token
     int32_t* tok_pos;       // [T]   position index (for position_embeddings)
     int32_t* tok_row;       // [T]   row the packed position belongs to
+    // distinct (source id, position) pairs: what the embeddings' output — and so layer 0's Q/K/V — depends on
+    int32_t* tok_pkey;      // [T]   id * Lp + position (Lp = L + lang; the language token counts as id V)
+    int32_t* pair_flag;     // [(V+1)*Lp]   1 if the pair occurs (null: the lever is off for this call)
+    int32_t* pair_slot;     // [(V+1)*Lp+1] exclusive scan of pair_flag; last = distinct pairs
+    int32_t* tok_pair;      // [T]   pair slot of the packed position
+    int32_t* pair_tslot;    // [P]   table slot of the pair (-1 = language token)
+    int32_t* pair_pos;      // [P]   its position index
     uint8_t* tok_key;       // [T]   visible as key
     int32_t* err;           // [1]   set to 1 + row on an out-of-range id
 };
@@ -156,13 +163,14 @@ inline void launch_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, in
 }
 
 __global__ void plan_tokens_kernel(const int32_t* __restrict__ sfm, int64_t n_rows, int seq, int pad, int lam,
-                                   PlanArrays p) {
+                                   int n_ids, PlanArrays p) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_rows) return;
     const int32_t* row = sfm + n * seq;
     int t = p.row_offset[n];
     if (p.row_uniform[n] == 2) return;
     const bool uniform = p.row_uniform[n] == 1;
+    const int lp = seq + lam;
     for (int j = 0; j < seq; ++j) {
         const int id = row[j];
         const bool vis = id != pad;
@@ -171,6 +179,7 @@ __global__ void plan_tokens_kernel(const int32_t* __restrict__ sfm, int64_t n_ro
             p.tok_pos[t] = j;
             p.tok_row[t] = (int32_t)n;
             p.tok_key[t] = vis ? 1 : 0;
+            if (p.pair_flag) { const int key = id * lp + j; p.tok_pkey[t] = key; p.pair_flag[key] = 1; }
             ++t;
         }
     }
@@ -179,7 +188,18 @@ __global__ void plan_tokens_kernel(const int32_t* __restrict__ sfm, int64_t n_ro
         p.tok_pos[t] = seq;
         p.tok_row[t] = (int32_t)n;
         p.tok_key[t] = 1;
+        if (p.pair_flag) { const int key = n_ids * lp + seq; p.tok_pkey[t] = key; p.pair_flag[key] = 1; }
     }
+}
+
+// pair slot of every packed position, and (table slot, position) of every pair (tokens of one pair write the same values)
+__global__ void plan_pairs_kernel(int64_t n_rows, PlanArrays p) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.row_offset[n_rows]) return;          // (the grid covers the worst case: the host does not know T yet)
+    const int ps = p.pair_slot[p.tok_pkey[t]];
+    p.tok_pair[t] = ps;
+    p.pair_tslot[ps] = p.tok_slot[t];
+    p.pair_pos[ps] = p.tok_pos[t];
 }
 
 __global__ void plan_idlist_kernel(int n_ids, PlanArrays p) {
@@ -335,8 +355,10 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
         is_lang = slot < 0;
         x = is_lang ? emb.lang : emb.table + (size_t)slot * H;
         posr = emb.pos_emb + (size_t)emb.tok_pos[tok0 + r] * H;
-        const int n = emb.tok_row[tok0 + r];
-        ro = chunk_row(r, (int)(n - emb.row0), emb.row_offset[n] == tok0 + r, emb.rows);
+        if (emb.tok_row) {                 // (null: rows are pairs, written in place)
+            const int n = emb.tok_row[tok0 + r];
+            ro = chunk_row(r, (int)(n - emb.row0), emb.row_offset[n] == tok0 + r, emb.rows);
+        }
     } else {
         x = in + (size_t)r * ld_in;
     }
@@ -454,7 +476,7 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
                                                              const uint8_t* __restrict__ row_uniform,
                                                              const uint8_t* __restrict__ tok_key, int64_t row0,
                                                              int rows, int tok0, float scaling, int cls_only,
-                                                             T* __restrict__ ctx) {
+                                                             const int32_t* __restrict__ tok_pair, T* __restrict__ ctx) {
     const int groups = (H + 511) >> 9;
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -470,9 +492,12 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
     const int ccol = active ? col : 0;
     // buffer row of packed position t of this row (position 0 first: chunk_row above)
     auto brow = [&](int t) -> size_t { return (size_t)chunk_row(t, rl, t == t0, rows); };
+    // row of q / k / v of packed position t: its buffer row, or — layer 0 with the pair lever — the row of its
+    // (source id, position) pair, whose Q/K/V were computed once
+    auto qrow = [&](int t) -> size_t { return tok_pair ? (size_t)tok_pair[tok0 + t] : brow(t); };
     for (int qi = 0; qi < nq; ++qi) {
         float q[8];
-        load8<T>(qbase + (cls_only ? (size_t)rl : brow(t0 + qi)) * ldq + ccol, q);
+        load8<T>(qbase + (cls_only ? (size_t)rl : qrow(t0 + qi)) * ldq + ccol, q);
         // one pass over the keys with a running maximum (online softmax): K and V are read once
         float mx = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
@@ -480,7 +505,7 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
         for (int kj = t0; kj < t1; ++kj) {
             if (!uniform && !tok_key[tok0 + kj]) continue;
             float k[8], v[8];
-            const size_t kr = brow(kj);
+            const size_t kr = qrow(kj);
             load8<T>(kbase + kr * ldkv + ccol, k);
             load8<T>(vbase + kr * ldkv + ccol, v);
             float s = 0.f;

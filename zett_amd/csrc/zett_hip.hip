@@ -68,6 +68,7 @@ struct zett_hypernet {
     int64_t max_chunk_tokens = 0;          // 0 = auto: chunk_token_cap() below (131 072 at H = 4096, more for narrower hypernets)
     int time_gemm = 0;
     int cls_only_last = 1;
+    int pair_dedupe = 1;              // layer 0's Q/K/V once per distinct (source id, position) pair (do_forward)
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
     int gemm4d_min_k = 512;           // 16-bit launches with K >= this take the four-wave direct-to-LDS tile (r2: with the streamlined epilogues it is ahead of gemm8r down to K = 768: +1.8 % on the XLM-R workload)
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
@@ -167,12 +168,18 @@ struct WorkspaceSizes {
     size_t total() const { return table + x0 + 3 * f32_rows + 3 * lo_rows + big + stats; }
 };
 
+static int64_t pair_keys(const zett_config& c, int seq) {
+    return ((int64_t)c.original_vocab_size + c.n_extra + 1) * (int64_t)(seq + (c.embed_lang ? 1 : 0));
+}
+
 static size_t plan_i32_bytes(const zett_config& c, int64_t N, int seq) {
     const int64_t V = (int64_t)c.original_vocab_size + c.n_extra;
     const int64_t max_tok = N * (int64_t)(seq + (c.embed_lang ? 1 : 0));
     // row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] tok_row[T] err[1] scan scratch
-    const size_t scan_scratch = 2 * ((size_t)std::max<int64_t>(N, V) / SCAN_CHUNK + 2) + 1;
-    return ((size_t)N + (N + 1) + V + (V + 1) + V + 3 * (size_t)max_tok + 1 + scan_scratch) * 4;
+    // + the pair plan: tok_pkey[T] tok_pair[T] pair_tslot[T] pair_pos[T] pair_flag[K] pair_slot[K+1], K = (V+1)(L+lang)
+    const int64_t K = pair_keys(c, seq);
+    const size_t scan_scratch = 2 * ((size_t)std::max<int64_t>(std::max<int64_t>(N, V), K) / SCAN_CHUNK + 2) + 1;
+    return ((size_t)N + (N + 1) + V + (V + 1) + V + 7 * (size_t)max_tok + 2 * (size_t)K + 2 + scan_scratch) * 4;
 }
 
 // Packed positions per encoder chunk when the caller has not set "max_chunk_tokens": 12 GiB of per-position workspace,
@@ -367,6 +374,8 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
         h->time_gemm = value != 0;
     } else if (k == "cls_only_last_layer") {
         h->cls_only_last = value != 0;
+    } else if (k == "pair_dedupe") {
+        h->pair_dedupe = value != 0;
     } else if (k == "gemm_tile_order") {
         if (value < 0 || value > 1) return fail(ZETT_E_INVALID, "gemm_tile_order must be 0 or 1");
         h->gemm_tile_order = (int)value;
@@ -585,21 +594,39 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     p.tok_slot = base; base += max_tok;
     p.tok_pos = base; base += max_tok;
     p.tok_row = base; base += max_tok;
+    // Pair plan (lever 4, below): only where it can pay — at least two encoder layers (layer 0 must not be the position-0-only
+    // one), and a key space not much larger than the batch (a 250 k-id source vocabulary against 50 k rows repeats few pairs
+    // and would pay for clearing and scanning 2 M flags).
+    const int64_t PK = pair_keys(c, seq);
+    const bool pair_plan = h->pair_dedupe && c.layers >= 2 && PK <= 4 * max_tok && PK < (int64_t)0x7fffffff;
+    if (pair_plan) {
+        p.tok_pkey = base; base += max_tok;
+        p.tok_pair = base; base += max_tok;
+        p.pair_tslot = base; base += max_tok;
+        p.pair_pos = base; base += max_tok;
+        p.pair_flag = base; base += PK;
+        p.pair_slot = base; base += PK + 1;
+    }
     p.err = base; base += 1;
     int32_t* scan_tmp = base;
     p.row_uniform = h->plan_u8.as<uint8_t>();
     p.tok_key = p.row_uniform + N;
     HIP_TRY(hipMemsetAsync(p.id_flag, 0, (size_t)V * 4, st));
     HIP_TRY(hipMemsetAsync(p.err, 0, 4, st));
+    if (pair_plan) HIP_TRY(hipMemsetAsync(p.pair_flag, 0, (size_t)PK * 4, st));
     const int rb = (int)((N + 255) / 256);
     hipLaunchKernelGGL(plan_rows_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
     launch_exclusive_scan(p.row_count, p.row_offset, N, scan_tmp, st);
     launch_exclusive_scan(p.id_flag, p.id_slot, (int64_t)V, scan_tmp, st);
-    hipLaunchKernelGGL(plan_tokens_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, p);
+    hipLaunchKernelGGL(plan_tokens_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
+    if (pair_plan) {
+        launch_exclusive_scan(p.pair_flag, p.pair_slot, PK, scan_tmp, st);
+        hipLaunchKernelGGL(plan_pairs_kernel, dim3((unsigned)((max_tok + 255) / 256)), dim3(256), 0, st, N, p);
+    }
     hipLaunchKernelGGL(plan_idlist_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, p);
     HIP_TRY(hipGetLastError());
     // bring the row offsets, the distinct-id count and the error word to the host
-    const size_t need_ints = (size_t)N + 1 + 2;
+    const size_t need_ints = (size_t)N + 1 + 3;
     if (h->host_pinned_ints < need_ints) {
         if (h->host_pinned) (void)hipHostFree(h->host_pinned);
         h->host_pinned = nullptr;
@@ -610,6 +637,8 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     HIP_TRY(hipMemcpyAsync(hoff, p.row_offset, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hoff + N + 1, p.id_slot + V, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hoff + N + 2, p.err, 4, hipMemcpyDeviceToHost, st));
+    hoff[N + 3] = 0;
+    if (pair_plan) HIP_TRY(hipMemcpyAsync(hoff + N + 3, p.pair_slot + PK, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (hoff[N + 2] != 0)
         return fail(ZETT_E_INDEX, "surface-form row %d holds an id outside [0, %d) (original_vocab_size %d + %d fallback rows)",
@@ -618,6 +647,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     const int D = hoff[N + 1];
     h->stats.packed_tokens = Ttot;
     h->stats.distinct_ids = D;
+    h->stats.distinct_positions = Ttot;
 
     // ---- workspace ------------------------------------------------------------------
     const WorkspaceSizes ws = workspace_sizes(c, sizeof(T), seq, Ttot, D, h->max_chunk_tokens);
@@ -692,13 +722,31 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         float* hs_stats = STb;
         const float* hs_gamma = R.Wf("model.embeddings.LayerNorm.weight");
         const float* hs_beta = R.Wf("model.embeddings.LayerNorm.bias");
-        if (H <= 2048)
-            hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 64>), dim3((m + 3) / 4), dim3(256), 0, st, (const float*)nullptr, H, m, H,
-                               hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, Zt, hs_stats, hs_sum, emb, tok0, LnReadout{});
-        else
-            hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 256>), dim3(m), dim3(256), 0, st, (const float*)nullptr, H, m, H,
-                               hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, Zt, hs_stats, hs_sum, emb, tok0, LnReadout{});
-        R.check("embed_layernorm");
+        auto embed_ln = [&](const LnEmbed& e, int n, int t0, T* lo, float* stats, float* sum) {
+            if (H <= 2048)
+                hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 64>), dim3((n + 3) / 4), dim3(256), 0, st, (const float*)nullptr, H, n, H,
+                                   hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, lo, stats, sum, e, t0, LnReadout{});
+            else
+                hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 256>), dim3(n), dim3(256), 0, st, (const float*)nullptr, H, n, H,
+                                   hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, lo, stats, sum, e, t0, LnReadout{});
+            R.check("embed_layernorm");
+        };
+        // Lever 4: the embeddings' output depends on (source id, position) only, so layer 0's Q/K/V are computed once per
+        // DISTINCT pair (P rows instead of m) and the attention kernel reads a packed position's q / k / v through
+        // tok_pair.  The per-position launch then only starts the residual stream (sum + statistics), the pair launch only
+        // writes the GEMM operand.  Same values, same bits.  Taken when the call is one chunk and at least 15 % of the
+        // positions repeat a pair.
+        const int P = pair_plan ? hoff[N + 3] : 0;
+        const bool pairs = pair_plan && rows == N && P > 0 && (int64_t)P * 100 <= (int64_t)m * 85;
+        if (pairs) {
+            LnEmbed pe = emb;
+            pe.tok_slot = p.pair_tslot; pe.tok_pos = p.pair_pos; pe.tok_row = nullptr;
+            embed_ln(pe, P, 0, Zt, nullptr, nullptr);
+            embed_ln(emb, m, tok0, nullptr, hs_stats, hs_sum);
+            h->stats.distinct_positions = P;
+        } else {
+            embed_ln(emb, m, tok0, Zt, hs_stats, hs_sum);
+        }
 
         int zrows = m;            // rows of the current hidden state: m, or `rows` (position 0 only) in a position-0-only last layer
         auto other = [&](float* b) { return b == Zf ? PRE : Zf; };
@@ -710,12 +758,14 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             const T* wqkv = (const T*)h->qkv_w[l];
             const int64_t waves = (int64_t)rows * groups;
             if (!cls_only) {
+                const bool by_pair = pairs && l == 0;       // Zt holds the P pair rows; BIG gets their Q/K/V
                 GemmEpilogue<T> eq = R.epi();
                 eq.bias = h->qkv_b[l]; eq.out_lo = BIG; eq.ld_lo = 3 * H;
-                R.gemm(Zt, H, wqkv, H, m, 3 * H, H, eq);
+                R.gemm(Zt, H, wqkv, H, by_pair ? P : m, 3 * H, H, eq);
                 hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                                    (const T*)BIG, (size_t)3 * H, (const T*)BIG + H, (const T*)BIG + 2 * H, (size_t)3 * H,
-                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 0, CTX);
+                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 0,
+                                   by_pair ? (const int32_t*)p.tok_pair : (const int32_t*)nullptr, CTX);
                 R.check("attention");
             } else {
                 // Only hidden[:,0] is consumed after this layer (modeling_hypernet.py:234): keys and values for every
@@ -731,7 +781,8 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 R.gemm(Zt, H, wqkv, H, rows, H, H, eq);
                 hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                                    (const T*)Q, (size_t)H, (const T*)KV, (const T*)KV + H, (size_t)2 * H,
-                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 1, CTX);
+                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 1,
+                                   (const int32_t*)nullptr, CTX);
                 R.check("attention(position 0)");
                 zrows = rows;
             }
