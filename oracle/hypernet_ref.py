@@ -222,12 +222,14 @@ def _heads(W, cfg, cls):
 
 
 def forward_levers(W, cfg, target_surface_forms, source_embeddings, lang_index=None):
-    """The same function as forward(), computed with the three exact levers the HIP path uses
+    """The same function as forward(), computed with the four exact levers the HIP path uses
     (DESIGN.md §2): (L1) positions that are pad, are not position 0 and are not the language token
     never influence the CLS state of a row with at least one visible key, so they are dropped;
     (L2) the input projection depends on the source id only, so it is evaluated once per DISTINCT
     id; (L3) only position 0 of the last layer is read, so its attention output, FFN and
-    LayerNorms are evaluated for position 0 only.  Rows whose keys are all masked keep every
+    LayerNorms are evaluated for position 0 only; (L4) the embeddings' output — hence layer 0's
+    query / key / value — depends on the (source id, position) pair only, so with two or more layers they are
+    evaluated once per DISTINCT pair.  Rows whose keys are all masked keep every
     position (uniform attention over all of them, the eager / Flax behaviour).
 
     Test infrastructure like the rest of this file: it is (a) a CPU proof that the levers are exact
@@ -268,6 +270,21 @@ def forward_levers(W, cfg, target_surface_forms, source_embeddings, lang_index=N
     if has_lang:
         lang_vec = W["lang_embeddings.weight"][int(lang_index)].astype(F32)   # the cancel trick nets out to lang + nothing
 
+    # L4: layer 0's q / k / v once per distinct (table slot, position) pair (+ one row for the language token)
+    qkv0 = pair_of = None
+    if layers >= 2:
+        pos_all = np.broadcast_to(np.arange(seq)[None, :], ids.shape)
+        pkey = slot[keep] * seq + pos_all[keep]
+        upair, pinv = np.unique(pkey, return_inverse=True)
+        pair_of = np.full(ids.shape, -1, dtype=np.int64)
+        pair_of[keep] = pinv
+        xp = table[upair // seq] + tt + pos_emb[upair % seq]
+        if has_lang:
+            xp = np.concatenate([xp, lang_vec[None, :]], axis=0)          # last pair row = the language token
+        zp = layer_norm(xp, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], ROBERTA_LN_EPS)
+        a0 = "model.encoder.layer.0.attention.self."
+        qkv0 = tuple(linear(zp, W[a0 + nm + ".weight"], W[a0 + nm + ".bias"]) for nm in ("query", "key", "value"))
+
     out_cls = np.zeros((n, hdim), dtype=F32)
     kept_len = keep.sum(axis=1)
     for k in np.unique(kept_len):                            # L1: dense batches of rows with k kept positions
@@ -288,9 +305,15 @@ def forward_levers(W, cfg, target_surface_forms, source_embeddings, lang_index=N
             lpfx = f"model.encoder.layer.{layer}."
             a = lpfx + "attention.self."
             zq = z[:, :1] if last else z                      # L3: only the CLS query in the last layer
-            q = linear(zq, W[a + "query.weight"], W[a + "query.bias"]).reshape(m, zq.shape[1], heads, d).transpose(0, 2, 1, 3)
-            kx = linear(z, W[a + "key.weight"], W[a + "key.bias"]).reshape(m, kk, heads, d).transpose(0, 2, 1, 3)
-            v = linear(z, W[a + "value.weight"], W[a + "value.bias"]).reshape(m, kk, heads, d).transpose(0, 2, 1, 3)
+            if layer == 0 and qkv0 is not None:               # L4: gathered from the per-pair projections
+                pidx = pair_of[rows[:, None], pos]
+                if has_lang:
+                    pidx = np.concatenate([pidx, np.full((m, 1), len(qkv0[0]) - 1, dtype=np.int64)], axis=1)
+                q, kx, v = (t[pidx].reshape(m, kk, heads, d).transpose(0, 2, 1, 3) for t in qkv0)
+            else:
+                q = linear(zq, W[a + "query.weight"], W[a + "query.bias"]).reshape(m, zq.shape[1], heads, d).transpose(0, 2, 1, 3)
+                kx = linear(z, W[a + "key.weight"], W[a + "key.bias"]).reshape(m, kk, heads, d).transpose(0, 2, 1, 3)
+                v = linear(z, W[a + "value.weight"], W[a + "value.bias"]).reshape(m, kk, heads, d).transpose(0, 2, 1, 3)
             sc = (q @ kx.transpose(0, 1, 3, 2)).astype(F32) * scaling + bias
             sc = sc - sc.max(axis=-1, keepdims=True)
             ex = np.exp(sc).astype(F32)
