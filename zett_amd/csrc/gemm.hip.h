@@ -242,6 +242,7 @@ __device__ __forceinline__ void epi_values(float (&vs)[NV], const float (&bias)[
 //   v = acc + bias[col]; v = act(v); v += r[row, col]; v = scale[col]*v + shift[col]
 //   r = residual[row, col], or, with res_stats, the LayerNorm of that row recomputed on the fly:
 //       r = ln_affine(residual[row, col], res_stats[2*row], res_stats[2*row + 1], res_gamma[col], res_beta[col])
+//   (with res_index, `row` on the right-hand sides is res_index[row])
 //   col <  split_col -> out_f32[row*ld_f32 + col], out_lo[row*ld_lo + col]
 //   col >= split_col -> out_f32_b[row*ld_f32 + (col - split_col)]
 template <typename T>
@@ -253,6 +254,8 @@ struct GemmEpilogue {
     const float* res_stats;     // [M][2] (mean, rstd) of the residual rows, or null: the residual is used as stored
     const float* res_gamma;     // [N]
     const float* res_beta;      // [N]
+    const int32_t* res_index;   // [M] row of `residual` / `res_stats` that output row m adds, or null: row m itself (layer 0
+                                //     of the encoder: the residual stream starts per (source id, position) pair)
     const float* scale;
     const float* shift;
     float* out_f32;
@@ -429,8 +432,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (row >= g.M) continue;
-                float res = e.residual ? e.residual[(size_t)row * e.ld_res + col] : 0.f;
-                if (e.residual && e.res_stats) res = ln_affine(res, e.res_stats[2 * (size_t)row], e.res_stats[2 * (size_t)row + 1], e.res_gamma[col], e.res_beta[col]);
+                const size_t rrow = e.res_index ? (size_t)e.res_index[row] : (size_t)row;
+                float res = e.residual ? e.residual[rrow * e.ld_res + col] : 0.f;
+                if (e.residual && e.res_stats) res = ln_affine(res, e.res_stats[2 * rrow], e.res_stats[2 * rrow + 1], e.res_gamma[col], e.res_beta[col]);
                 const bool hr = e.residual != nullptr, hs = e.scale != nullptr;
                 const float v = e.act == ACT_GELU_TANH ? epi_value<ACT_GELU_TANH>(acc[i][j][r], bias, hr, res, hs, sc, sh)
                               : e.act == ACT_GELU_ERF ? epi_value<ACT_GELU_ERF>(acc[i][j][r], bias, hr, res, hs, sc, sh)

@@ -348,7 +348,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     int srow = m0 + wm * 128 + p * 64 + lane_e; srow = srow < g.M ? srow : g.M - 1;
+                    if (e.res_index) srow = e.res_index[srow];
                     pst[p] = *(const float2*)(e.res_stats + 2 * (size_t)srow);
+                }
+            }
+        }
+        // indexed residual rows (GemmEpilogue::res_index): lane l holds the index of row l of each pass, fetched per
+        // instruction with v_readlane like the statistics
+        int rix[2] = {0, 0};
+        const bool res_ix = RES && e.res_index != nullptr;
+        if constexpr (RES) {
+            if (res_ix) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    int srow = m0 + wm * 128 + p * 64 + lane_e; srow = srow < g.M ? srow : g.M - 1;
+                    rix[p] = e.res_index[srow];
                 }
             }
         }
@@ -360,7 +374,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int t = 0; t < NIT; ++t) {
                     const int grow = grow0 + p * 64 + t * RPI;
-                    res[p][t] = (grow < g.M && col_ok) ? *(const float4*)(e.residual + (size_t)grow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    size_t rrow = (size_t)grow;
+                    if (res_ix) {               // rows t*RPI (rsub = 0) and t*RPI + 1 (rsub = 1) of the pass
+                        const int i0 = __builtin_amdgcn_readlane(rix[p], t * RPI), i1 = __builtin_amdgcn_readlane(rix[p], t * RPI + 1);
+                        rrow = (size_t)(rsub ? i1 : i0);
+                    }
+                    res[p][t] = (grow < g.M && col_ok) ? *(const float4*)(e.residual + rrow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         };

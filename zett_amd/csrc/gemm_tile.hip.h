@@ -83,7 +83,8 @@ struct EpiDrain {
         for (int t = 0; t < NIT; ++t) {
             const int grow = row0 + t * RPI + lane / LPR;
             const bool ok = grow < g.M && col_ok;
-            const float* src = g.epi.residual + (size_t)grow * g.epi.ld_res + gcol;
+            const size_t rrow = (g.epi.res_index && grow < g.M) ? (size_t)g.epi.res_index[grow] : (size_t)grow;
+            const float* src = g.epi.residual + rrow * g.epi.ld_res + gcol;
             oa[t] = ok ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
             ob[t] = ok ? *(const float4*)(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -101,6 +102,7 @@ struct EpiDrain {
         static_assert(ROWS <= 64, "one statistics row per lane");
         int grow = row0 + (lane < ROWS ? lane : ROWS - 1);
         grow = grow < g.M ? grow : g.M - 1;
+        if (g.epi.res_index) grow = g.epi.res_index[grow];
         st = *(const float2*)(g.epi.res_stats + 2 * (size_t)grow);
     }
     static __device__ __forceinline__ void load_ln_cols(const GemmEpilogue<T>& e, int gcol, bool col_ok, float4 (&gm)[2], float4 (&bt)[2]) {

@@ -202,6 +202,15 @@ __global__ void plan_pairs_kernel(int64_t n_rows, PlanArrays p) {
     p.pair_pos[ps] = p.tok_pos[t];
 }
 
+// pair slot per BUFFER row of a chunk (position 0 first, chunk_row below): what the residual epilogue of layer 0 indexes with
+__device__ __forceinline__ int chunk_row(int t_rel, int row_rel, bool first, int rows);
+__global__ void pair_rows_kernel(int m, int tok0, int64_t row0, int rows, PlanArrays p, int32_t* __restrict__ brow_pair) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const int n = p.tok_row[tok0 + t];
+    brow_pair[chunk_row(t, (int)(n - row0), p.row_offset[n] == tok0 + t, rows)] = p.tok_pair[tok0 + t];
+}
+
 __global__ void plan_idlist_kernel(int n_ids, PlanArrays p) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id < n_ids && p.id_flag[id]) p.id_list[p.id_slot[id]] = id;

@@ -731,18 +731,21 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                                    hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, lo, stats, sum, e, t0, LnReadout{});
             R.check("embed_layernorm");
         };
-        // Lever 4: the embeddings' output depends on (source id, position) only, so layer 0's Q/K/V are computed once per
-        // DISTINCT pair (P rows instead of m) and the attention kernel reads a packed position's q / k / v through
-        // tok_pair.  The per-position launch then only starts the residual stream (sum + statistics), the pair launch only
-        // writes the GEMM operand.  Same values, same bits.  Taken when the call is one chunk and at least 15 % of the
-        // positions repeat a pair.
+        // Lever 4: the embeddings' output depends on (source id, position) only, so the embeddings' LayerNorm and layer 0's
+        // Q/K/V are computed once per DISTINCT pair (P rows instead of m).  The attention kernel reads a packed position's
+        // q / k / v through tok_pair, and layer 0's attention-output epilogue adds the residual row of the position's pair
+        // (GemmEpilogue::res_index = pair slot per buffer row): until that GEMM has run, the hidden state (operand, sum,
+        // statistics) exists per pair only.  Same values, same bits.  Taken when the call is one chunk and at least 15 % of
+        // the positions repeat a pair.
         const int P = pair_plan ? hoff[N + 3] : 0;
         const bool pairs = pair_plan && rows == N && P > 0 && (int64_t)P * 100 <= (int64_t)m * 85;
+        int32_t* brow_pair = p.tok_pkey;       // (the keys are dead once plan_pairs_kernel has run)
         if (pairs) {
             LnEmbed pe = emb;
             pe.tok_slot = p.pair_tslot; pe.tok_pos = p.pair_pos; pe.tok_row = nullptr;
-            embed_ln(pe, P, 0, Zt, nullptr, nullptr);
-            embed_ln(emb, m, tok0, nullptr, hs_stats, hs_sum);
+            embed_ln(pe, P, 0, Zt, hs_stats, hs_sum);
+            hipLaunchKernelGGL(pair_rows_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, tok0, r0, rows, p, brow_pair);
+            R.check("pair_rows");
             h->stats.distinct_positions = P;
         } else {
             embed_ln(emb, m, tok0, Zt, hs_stats, hs_sum);
@@ -792,6 +795,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             GemmEpilogue<T> eo = R.epi();
             eo.bias = R.Wf(lp + "attention.output.dense.bias"); eo.residual = hs_sum; eo.ld_res = H;
             eo.res_stats = hs_stats; eo.res_gamma = hs_gamma; eo.res_beta = hs_beta;
+            if (pairs && l == 0) eo.res_index = brow_pair;       // hs_sum / hs_stats are still per pair here
             eo.out_f32 = s1; eo.ld_f32 = H;
             R.gemm(CTX, H, R.Wlo(lp + "attention.output.dense.weight"), H, zrows, H, H, eo);
             const float* g1 = R.Wf(lp + "attention.output.LayerNorm.weight");
