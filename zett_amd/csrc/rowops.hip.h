@@ -503,7 +503,11 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
     auto brow = [&](int t) -> size_t { return (size_t)chunk_row(t, rl, t == t0, rows); };
     // row of q / k / v of packed position t: its buffer row, or — layer 0 with the pair lever — the row of its
     // (source id, position) pair, whose Q/K/V were computed once
-    auto qrow = [&](int t) -> size_t { return tok_pair ? (size_t)tok_pair[tok0 + t] : brow(t); };
+    // (the row's <= 64 pair slots are fetched once, one per lane, and handed out by shuffle: an index load in front of
+    //  every key would put a second memory round trip into the loop)
+    int pslot = 0;
+    if (tok_pair) { const int t = t0 + lane; pslot = t < t1 ? tok_pair[tok0 + t] : 0; }
+    auto qrow = [&](int t) -> size_t { return tok_pair ? (size_t)__shfl(pslot, t - t0, 64) : brow(t); };
     for (int qi = 0; qi < nq; ++qi) {
         float q[8];
         load8<T>(qbase + (cls_only ? (size_t)rl : qrow(t0 + qi)) * ldq + ccol, q);
