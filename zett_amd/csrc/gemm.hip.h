@@ -50,6 +50,10 @@ template <typename T> __device__ __forceinline__ T to_lo(float v);
 template <> __device__ __forceinline__ float to_lo<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t to_lo<bf16_t>(float v) { return f32_to_bf16(v); }
 template <> __device__ __forceinline__ f16_t to_lo<f16_t>(float v) { return (f16_t)v; }
+template <typename T> __device__ __forceinline__ float lo_to_f32(T v);
+template <> __device__ __forceinline__ float lo_to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float lo_to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <> __device__ __forceinline__ float lo_to_f32<f16_t>(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ uint32_t pack2_lo(float a, float b);      // two 16-bit operands in a dword
 template <> __device__ __forceinline__ uint32_t pack2_lo<bf16_t>(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -256,6 +260,11 @@ struct GemmEpilogue {
     const float* res_beta;      // [N]
     const int32_t* res_index;   // [M] row of `residual` / `res_stats` that output row m adds, or null: row m itself (layer 0
                                 //     of the encoder: the residual stream starts per (source id, position) pair)
+    // LayerNorm folded into the GEMMs on either side of it (gemm4d only; DESIGN.md §4 "LayerNorm fold"):
+    float2* stats_part;         // producer: [N/128][ld_part] (sum, sum of squares) of the fp32 output row over each 128-column
+    int ld_part;                //           slice; the launch also writes out_lo = the 16-bit copy of the same values
+    const float* fold_stats;    // consumer: [M][2] (mean, rstd) of the A rows: the accumulator becomes rstd * (acc - mean * fold_c[n])
+    const float* fold_c;        //           [N] row sums of the gamma-folded weight
     const float* scale;
     const float* shift;
     float* out_f32;

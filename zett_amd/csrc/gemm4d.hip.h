@@ -65,6 +65,11 @@ template <> __device__ __forceinline__ void mfma16_agpr<f16_t>(f32x4& c, const u
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
+// value of lane (l ^ K) within each group of 32 lanes (ds_swizzle bit mode: no LDS access, K < 32)
+template <int K> __device__ __forceinline__ float g4d_xor_lane(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (K << 10) | 0x1f));
+}
+
 #ifdef G4D_TRACE
 // per-tile timeline (tools/experiments/trace4d.hip): [block]{start, K loop begins, K loop ends, end, hw id} in 10 ns ticks
 __device__ unsigned long long g4d_trace[32768 * 8];
@@ -79,7 +84,10 @@ __device__ int g4d_stagger_ticks, g4d_stagger_mode;
 //   F32        only the fp32 output (out_f32), bias + ACT + residual  (attention output, FFN down, dense2, heads)
 //   F32_SCALE  as F32 with the Rescaler (scale, shift)                (output heads)
 //   BOTH       fp32 AND 16-bit output of the same values, bias only   (input_projection.0: residual + operand of the ProjectorBlock)
-enum { G4D_EPI_GENERIC = 0, G4D_EPI_LO = 1, G4D_EPI_F32 = 2, G4D_EPI_F32_SCALE = 3, G4D_EPI_BOTH = 4 };
+//   F32_LN     as F32 with a residual, plus the 16-bit copy of the fp32 rows (out_lo) and per-row partial statistics over
+//              the wave's 128 columns (stats_part): the producer half of the LayerNorm fold
+//   LO_FOLD    as LO on an un-normalised operand: acc <- rstd_row * (acc - mean_row * fold_c[col]) in front of the bias
+enum { G4D_EPI_GENERIC = 0, G4D_EPI_LO = 1, G4D_EPI_F32 = 2, G4D_EPI_F32_SCALE = 3, G4D_EPI_BOTH = 4, G4D_EPI_F32_LN = 5, G4D_EPI_LO_FOLD = 6 };
 constexpr int G4D_EPI_STRIDE = 132;                                   // floats per staged row: 128 columns + 4 of padding
 constexpr int G4D_EPI_REGION = 64 * G4D_EPI_STRIDE * 4;               // bytes per wave
 constexpr int G4D_LDS_BYTES = 4 * G4D_EPI_REGION;                     // 132 KiB (the K loop uses the first 128)
@@ -306,7 +314,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     } else {
         // ---- streamlined epilogues (see the header).  No barrier here: the last K step carries it.
-        constexpr bool LO = EPI == G4D_EPI_LO, SCALE = EPI == G4D_EPI_F32_SCALE;
+        constexpr bool LO = EPI == G4D_EPI_LO || EPI == G4D_EPI_LO_FOLD, SCALE = EPI == G4D_EPI_F32_SCALE;
+        constexpr bool LNP = EPI == G4D_EPI_F32_LN, FOLD = EPI == G4D_EPI_LO_FOLD;
+        static_assert(!LNP || (RES && ACT == ACT_NONE), "the LayerNorm producer is the residual epilogue");
         constexpr int CPL = LO ? 8 : 4;            // columns per lane
         constexpr int LPR = 128 / CPL;             // lanes per row
         constexpr int RPI = 64 / LPR;              // rows per wave instruction
@@ -366,6 +376,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
         }
+        // LayerNorm fold, consumer side: the row sums of the folded weight for the lane's columns, and (mean, rstd) of row l
+        // of each pass in lane l (fetched per instruction with v_readlane)
+        float fc[FOLD ? CPL : 1];
+        float2 fst[2] = {make_float2(0.f, 1.f), make_float2(0.f, 1.f)};
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) fc[c] = 0.f;
+            if (col_ok) {
+#pragma unroll
+                for (int c4 = 0; c4 < CPL; c4 += 4) {
+                    const float4 a = *(const float4*)(e.fold_c + gcol + c4);
+                    fc[c4] = a.x; fc[c4 + 1] = a.y; fc[c4 + 2] = a.z; fc[c4 + 3] = a.w;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                int srow = m0 + wm * 128 + p * 64 + lane_e; srow = srow < g.M ? srow : g.M - 1;
+                fst[p] = *(const float2*)(e.fold_stats + 2 * (size_t)srow);
+            }
+        }
         // residual rows of both passes: requested before any store leaves (pass 1's right after pass 0 is staged, by
         // which time the accumulators of pass 0 have left their registers)
         float4 res[2][RES ? NIT : 1];
@@ -400,6 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // GROUP instructions at a time: their LDS reads, then their arithmetic stage by stage, then their stores
             constexpr int GROUP = (LO || RES) ? 4 : 8;      // 32 values per lane and group (16 beside the 256 residual registers)
             constexpr int NV = GROUP * CPL;
+            float acc_s = 0.f, acc_q = 0.f;        // LNP: (sum, sum of squares) of the row this lane ends up holding
 #pragma unroll
             for (int t0 = 0; t0 < NIT; t0 += GROUP) {
                 float v[NV], bb[NV], rr[NV], ss[NV], hh[NV];
@@ -428,7 +459,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         }
                     }
                 }
+                if constexpr (FOLD) {
+                    // acc <- rstd_row * (acc - mean_row * c_col): the LayerNorm of the A row, applied to the product
+#pragma unroll
+                    for (int u = 0; u < GROUP; ++u) {
+                        const int rb = (t0 + u) * RPI;      // rows rb .. rb + 3 of the pass (rsub selects)
+                        float mk[RPI], rk[RPI];
+#pragma unroll
+                        for (int k = 0; k < RPI; ++k) {
+                            mk[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fst[p].x), rb + k));
+                            rk[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fst[p].y), rb + k));
+                        }
+                        float mean = mk[0], rstd = rk[0];
+#pragma unroll
+                        for (int k = 1; k < RPI; ++k) { mean = rsub == k ? mk[k] : mean; rstd = rsub == k ? rk[k] : rstd; }
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c) v[u * CPL + c] = __builtin_fmaf(-mean, fc[c], v[u * CPL + c]) * rstd;
+                    }
+                }
                 epi_values<ACT, RES, SCALE, NV>(v, bb, rr, ss, hh);
+                if constexpr (LNP) {
+                    // per-row (sum, sum of squares) over the wave's 128 columns: a reduce-scatter over the 32 lanes of a row
+                    // group — after the xor-16 and xor-8 exchanges a lane carries ONE of the group's four row pairs, after
+                    // three butterfly steps the row's totals; lane (idx & 7) == group keeps them
+                    static_assert(GROUP == 4 && CPL == 4 && RPI == 2, "reduce-scatter layout");
+                    float S[4], Q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float a = v[4 * u], b = v[4 * u + 1], c = v[4 * u + 2], d = v[4 * u + 3];
+                        S[u] = (a + b) + (c + d);
+                        Q[u] = __builtin_fmaf(a, a, __builtin_fmaf(b, b, __builtin_fmaf(c, c, d * d)));
+                    }
+                    const bool b4 = (idx & 16) != 0, b3 = (idx & 8) != 0;
+                    float ks0 = b4 ? S[2] : S[0], ks1 = b4 ? S[3] : S[1], kq0 = b4 ? Q[2] : Q[0], kq1 = b4 ? Q[3] : Q[1];
+                    ks0 += g4d_xor_lane<16>(b4 ? S[0] : S[2]); ks1 += g4d_xor_lane<16>(b4 ? S[1] : S[3]);
+                    kq0 += g4d_xor_lane<16>(b4 ? Q[0] : Q[2]); kq1 += g4d_xor_lane<16>(b4 ? Q[1] : Q[3]);
+                    float ks = b3 ? ks1 : ks0, kq = b3 ? kq1 : kq0;
+                    ks += g4d_xor_lane<8>(b3 ? ks0 : ks1); kq += g4d_xor_lane<8>(b3 ? kq0 : kq1);
+                    ks += g4d_xor_lane<4>(ks); kq += g4d_xor_lane<4>(kq);
+                    ks += g4d_xor_lane<2>(ks); kq += g4d_xor_lane<2>(kq);
+                    ks += g4d_xor_lane<1>(ks); kq += g4d_xor_lane<1>(kq);
+                    const bool mine = (idx & 7) == (t0 >> 2);
+                    acc_s = mine ? ks : acc_s; acc_q = mine ? kq : acc_q;
+                }
 #pragma unroll
                 for (int u = 0; u < GROUP; ++u) {
                     const int grow = grow0 + p * 64 + (t0 + u) * RPI;
@@ -442,10 +515,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const f32x4 x = {v[u * 4], v[u * 4 + 1], v[u * 4 + 2], v[u * 4 + 3]};
                         if (RES) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(d), "v"(x) : "memory");
                         else *(f32x4*)d = x;
-                        if constexpr (EPI == G4D_EPI_BOTH)      // the same four values as the next GEMM's operand: 8 bytes per lane, 256 per row
+                        if constexpr (EPI == G4D_EPI_BOTH || LNP)      // the same four values as the next GEMM's operand: 8 bytes per lane, 256 per row
                             store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, make_float4(x[0], x[1], x[2], x[3]));
                     }
                 }
+            }
+            if constexpr (LNP) {
+                // the lane holds row ((4 * (idx & 7) + 2 * b4 + b3) * 2 + rsub) of the pass: 64 lanes, 64 rows, one 512-byte store
+                const int rp = ((4 * (idx & 7) + 2 * ((idx >> 4) & 1) + ((idx >> 3) & 1)) << 1) + rsub;
+                const int grow = m0 + wm * 128 + p * 64 + rp;
+                if (grow < g.M && n0 + wn * 128 < g.N)
+                    e.stats_part[(size_t)((n0 + wn * 128) >> 7) * e.ld_part + grow] = make_float2(acc_s, acc_q);
             }
         };
         auto drain_pass = [&](int p) {
@@ -500,6 +580,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <typename T>
 inline int gemm4d_epi_mode(const GemmArgs<T>& g) {
     const GemmEpilogue<T>& e = g.epi;
+    if (e.stats_part)      // LayerNorm producer: only this instantiation writes the partial statistics
+        return (e.out_f32 && e.out_lo && e.residual && e.act == ACT_NONE && !e.scale && !e.shift && !e.out_f32_b && e.split_col >= g.N &&
+                g.N % 128 == 0 && e.ld_f32 % 4 == 0 && e.ld_lo % 4 == 0 && e.ld_res % 4 == 0) ? G4D_EPI_F32_LN : -1;
+    if (e.fold_stats)      // LayerNorm consumer
+        return (e.fold_c && e.out_lo && !e.out_f32 && !e.residual && !e.scale && !e.shift && !e.out_f32_b && e.split_col >= g.N &&
+                g.N % 8 == 0 && e.ld_lo % 8 == 0) ? G4D_EPI_LO_FOLD : -1;
     if (e.out_f32_b || e.split_col < g.N) return G4D_EPI_GENERIC;
     if (e.res_stats && (e.act != ACT_NONE || !e.residual)) return G4D_EPI_GENERIC;
     if (e.out_lo && !e.out_f32 && !e.residual && !e.scale && !e.shift && g.N % 8 == 0 && e.ld_lo % 8 == 0) return G4D_EPI_LO;
@@ -535,6 +621,7 @@ inline hipError_t launch_gemm4d_act(const GemmArgs<T>& g, hipStream_t stream, in
     const bool res = g.epi.residual != nullptr;
     switch (mode) {
         case G4D_EPI_LO: return launch_gemm4d_inst<T, ACT, false, G4D_EPI_LO>(g, stream);
+        case G4D_EPI_LO_FOLD: return launch_gemm4d_inst<T, ACT, false, G4D_EPI_LO_FOLD>(g, stream);
         case G4D_EPI_F32:
             if constexpr (ACT == ACT_NONE) return res ? launch_gemm4d_inst<T, ACT, true, G4D_EPI_F32>(g, stream) : launch_gemm4d_inst<T, ACT, false, G4D_EPI_F32>(g, stream);
             else if constexpr (ACT == ACT_GELU_TANH) { if (res) return launch_gemm4d_inst<T, ACT, true, G4D_EPI_F32>(g, stream); }
@@ -545,7 +632,9 @@ inline hipError_t launch_gemm4d_act(const GemmArgs<T>& g, hipStream_t stream, in
 
 template <typename T>
 inline hipError_t launch_gemm4d(const GemmArgs<T>& g, hipStream_t stream, bool force_generic = false) {
-    const int mode = force_generic ? G4D_EPI_GENERIC : gemm4d_epi_mode(g);
+    const int mode = (force_generic && !g.epi.stats_part && !g.epi.fold_stats) ? G4D_EPI_GENERIC : gemm4d_epi_mode(g);
+    if (mode < 0) return hipErrorInvalidValue;       // a LayerNorm-fold launch whose outputs no instantiation carries
+    if (mode == G4D_EPI_F32_LN) return launch_gemm4d_inst<T, ACT_NONE, true, G4D_EPI_F32_LN>(g, stream);
     if (mode == G4D_EPI_F32_SCALE) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE>(g, stream);
     if (mode == G4D_EPI_BOTH) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_BOTH>(g, stream);
     switch (g.epi.act) {

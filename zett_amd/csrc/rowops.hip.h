@@ -544,6 +544,43 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// LayerNorm fold: the LayerNorm between two GEMMs without a kernel that reads the fp32 rows again.
+//   ln_stats_kernel   (mean, rstd) per row from the per-128-column partials the producer GEMM's epilogue wrote
+//   fold_weight_kernel  one-off, at zett_finalize: W'[n,k] = lo(W[n,k] * gamma[k]),  c[n] = sum_k W'[n,k],
+//                       b'[n] = b[n] + sum_k W[n,k] * beta[k]     so that   LN(x) W^T + b = rstd (x W'^T - mean c) + b'
+// ---------------------------------------------------------------------------
+__global__ void ln_stats_kernel(const float2* __restrict__ part, int parts, int ld_part, int rows, int H, float eps,
+                                float* __restrict__ stats) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float s = 0.f, q = 0.f;
+    for (int p = 0; p < parts; ++p) { const float2 v = part[(size_t)p * ld_part + r]; s += v.x; q += v.y; }
+    const float mean = s / (float)H;
+    const float var = fmaxf(q / (float)H - mean * mean, 0.f);
+    *(float2*)(stats + 2 * (size_t)r) = make_float2(mean, 1.0f / sqrtf(var + eps));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fold_weight_kernel(const float* __restrict__ w, int K, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ bias,
+                                                          T* __restrict__ w_fold, float* __restrict__ c_out, float* __restrict__ b_out) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    const float* row = w + (size_t)n * K;
+    float cs = 0.f, bs = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float x = row[k];
+        const T lo = to_lo<T>(x * gamma[k]);
+        w_fold[(size_t)n * K + k] = lo;
+        cs += lo_to_f32<T>(lo);
+        bs = fmaf(x, beta[k], bs);
+    }
+    const float ct = block_sum_256(cs, red);
+    const float bt = block_sum_256(bs, red);
+    if (threadIdx.x == 0) { c_out[n] = ct; b_out[n] = bias[n] + bt; }
+}
+
 // dtype conversion used when weights are uploaded
 template <typename T>
 __global__ void convert_f32_to_lo_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {

@@ -61,6 +61,12 @@ struct zett_hypernet {
     // fused / derived operands built by zett_finalize
     std::vector<void*> qkv_w;         // per layer [3H, H]
     std::vector<float*> qkv_b;        // per layer [3H]
+    // LayerNorm fold (16-bit modes): gamma-folded operands of the GEMMs that follow an encoder LayerNorm — the fused QKV of
+    // layers >= 1 (folded with the previous layer's output LayerNorm) and every intermediate.dense (with the layer's
+    // attention-output LayerNorm) — with their row sums and beta-folded biases
+    struct Folded { void* w = nullptr; float* c = nullptr; float* b = nullptr; };
+    std::vector<Folded> fold_qkv, fold_up;
+    int ln_fold = 1;
     float* head_scale = nullptr;      // [head_out_width] scaler.w (| out_scaler.w for single_head)
     float* head_shift = nullptr;
     std::vector<void*> owned;         // everything to hipFree at destroy
@@ -74,7 +80,7 @@ struct zett_hypernet {
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
                                       // 7 = 256x256 four-wave direct-to-LDS, 8 = as 7 with the generic epilogue drain
     // workspace
-    DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct, lnstats;
+    DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct, lnstats, lnparts;
     int32_t* host_pinned = nullptr;
     size_t host_pinned_ints = 0;
     std::vector<hipEvent_t> ev;
@@ -340,6 +346,39 @@ int zett_finalize(zett_hypernet* h) {
         h->qkv_w.push_back(wq);
         h->qkv_b.push_back(bq);
     }
+    // LayerNorm fold operands (rowops.hip.h fold_weight_kernel); needs the fp32 originals, which are freed below
+    if (h->precision != ZETT_PREC_F32 && c.hidden % 128 == 0) {
+        auto fold = [&](const float* w32, size_t N, size_t K, const float* gamma, const float* beta, const float* bias,
+                        zett_hypernet::Folded& f) -> int {
+            HIP_TRY(hipMalloc(&f.w, N * K * es));
+            HIP_TRY(hipMalloc((void**)&f.c, N * 4));
+            HIP_TRY(hipMalloc((void**)&f.b, N * 4));
+            h->owned.push_back(f.w); h->owned.push_back(f.c); h->owned.push_back(f.b);
+            if (h->precision == ZETT_PREC_F16)
+                hipLaunchKernelGGL(fold_weight_kernel<f16_t>, dim3((unsigned)N), dim3(256), 0, 0, w32, (int)K, gamma, beta, bias, (f16_t*)f.w, f.c, f.b);
+            else
+                hipLaunchKernelGGL(fold_weight_kernel<bf16_t>, dim3((unsigned)N), dim3(256), 0, 0, w32, (int)K, gamma, beta, bias, (bf16_t*)f.w, f.c, f.b);
+            return 0;
+        };
+        h->fold_qkv.resize(c.layers); h->fold_up.resize(c.layers);
+        float* tmp = nullptr;                       // fp32 [3H, H] fused QKV of one layer
+        HIP_TRY(hipMalloc((void**)&tmp, 3 * H * H * 4));
+        for (int l = 0; l < c.layers; ++l) {
+            const std::string lp = "model.encoder.layer." + std::to_string(l) + ".";
+            if (int rc = fold(h->w[lp + "intermediate.dense.weight"].f32, c.intermediate, H, h->w[lp + "attention.output.LayerNorm.weight"].f32,
+                              h->w[lp + "attention.output.LayerNorm.bias"].f32, h->w[lp + "intermediate.dense.bias"].f32, h->fold_up[l])) return rc;
+            if (l == 0) continue;
+            const std::string pp = "model.encoder.layer." + std::to_string(l - 1) + ".output.LayerNorm.";
+            int k = 0;
+            for (const char* q : {"query", "key", "value"}) {
+                HIP_TRY(hipMemcpy(tmp + (size_t)k * H * H, h->w[lp + "attention.self." + q + ".weight"].f32, H * H * 4, hipMemcpyDeviceToDevice));
+                ++k;
+            }
+            if (int rc = fold(tmp, 3 * H, H, h->w[pp + "weight"].f32, h->w[pp + "bias"].f32, h->qkv_b[l], h->fold_qkv[l])) return rc;
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(tmp);
+    }
     // output Rescaler vectors laid out over the first head's columns
     if (c.rescale) {
         const size_t w0 = c.single_head ? c.n_in_embd : c.n_embd;
@@ -376,6 +415,8 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
         h->cls_only_last = value != 0;
     } else if (k == "pair_dedupe") {
         h->pair_dedupe = value != 0;
+    } else if (k == "ln_fold") {
+        h->ln_fold = value != 0;
     } else if (k == "gemm_tile_order") {
         if (value < 0 || value > 1) return fail(ZETT_E_INVALID, "gemm_tile_order must be 0 or 1");
         h->gemm_tile_order = (int)value;
@@ -400,7 +441,8 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
     const int64_t max_tok = n_rows * (int64_t)(seq + (c.embed_lang ? 1 : 0));
     // worst case of the plan: no pad position, every position a different source id
     const WorkspaceSizes w = workspace_sizes(c, elt_size(h->precision), seq, max_tok, std::min<int64_t>(V, max_tok), h->max_chunk_tokens);
-    *out_bytes = (int64_t)(w.total() + plan_i32_bytes(c, n_rows, seq) + (size_t)n_rows + (size_t)max_tok);
+    const size_t parts = c.hidden % 128 == 0 ? (size_t)(c.hidden / 128) * (size_t)w.chunk_tokens * 8 : 0;      // LayerNorm-fold partials
+    *out_bytes = (int64_t)(w.total() + parts + plan_i32_bytes(c, n_rows, seq) + (size_t)n_rows + (size_t)max_tok);
     return 0;
 }
 
@@ -510,6 +552,7 @@ struct Runner {
                              (e.split_col >= N || e.split_col % 8 == 0);
         if (variant != 1 && !wide_ok) variant = 1;
         if (e.residual && (e.scale || e.shift)) variant = 1;      // the large tiles compile their residual epilogues without the Rescaler
+        if (e.stats_part || e.fold_stats) variant = 7;       // LayerNorm-fold launches exist in gemm4d only (any M)
         if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
         hipError_t err;
         switch (variant) {
@@ -541,6 +584,14 @@ struct Runner {
         else { if (H <= 2048) ZETT_LN_LAUNCH(64, false); else ZETT_LN_LAUNCH(256, false); }
 #undef ZETT_LN_LAUNCH
         check("layernorm");
+    }
+
+    // LayerNorm fold: (mean, rstd) per row from the partials the producer GEMM wrote
+    void ln_stats(const float2* parts, int ld_part, int rows, float eps, float* stats) {
+        if (rc || rows <= 0) return;
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, parts, h->cfg.hidden / 128, ld_part, rows,
+                           h->cfg.hidden, eps, stats);
+        check("ln_stats");
     }
 
     // ProjectorBlock (modeling_hypernet.py:22-40) on rows already projected to H:
@@ -663,6 +714,14 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     if (int rc = h->cf.reserve(ws.f32_rows)) return rc;
     if (int rc = h->ct.reserve(ws.lo_rows)) return rc;
     if (int rc = h->lnstats.reserve(ws.stats)) return rc;
+    // LayerNorm fold: in the 16-bit modes the LayerNorms inside the encoder are not launches — the residual GEMM
+    // in front writes the 16-bit copy of its fp32 rows and per-row partial statistics, the GEMM behind runs on gamma-folded
+    // weights and normalises in its epilogue.  gemm4d only: off when a tile variant is forced.
+    const bool fold = h->ln_fold && !std::is_same<T, float>::value && h->gemm_variant == 0 && H % 128 == 0 && H >= 512 &&
+                      (int)h->fold_up.size() == c.layers;
+    const size_t ws_parts = fold ? (size_t)(H / 128) * (size_t)MC * sizeof(float2) : 0;
+    if (int rc = h->lnparts.reserve(ws_parts)) return rc;
+    float2* PARTS = h->lnparts.as<float2>();
     float* TBL = h->table.as<float>();
     T* X0 = h->x0.as<T>();
     float* Zf = h->yf.as<float>();
@@ -752,18 +811,24 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         }
 
         int zrows = m;            // rows of the current hidden state: m, or `rows` (position 0 only) in a position-0-only last layer
+        bool raw = false;         // Zt = 16-bit copy of the un-normalised sum (LayerNorm fold) instead of the LayerNorm output
         auto other = [&](float* b) { return b == Zf ? PRE : Zf; };
         auto other_stats = [&](float* b) { return b == STa ? STb : STa; };
         for (int l = 0; l < c.layers && !R.rc; ++l) {
             const std::string lp = "model.encoder.layer." + std::to_string(l) + ".";
             const bool last = l == c.layers - 1;
             const bool cls_only = h->cls_only_last && last;
-            const T* wqkv = (const T*)h->qkv_w[l];
+            // raw: Zt holds the 16-bit copy of the pre-LayerNorm sum (LayerNorm fold: the previous layer's FFN-down wrote it
+            // with the statistics in hs_stats) instead of the normalised operand — then this layer's QKV runs on the folded weight
+            const T* wqkv = raw ? (const T*)h->fold_qkv[l].w : (const T*)h->qkv_w[l];
+            const float* bqkv = raw ? h->fold_qkv[l].b : h->qkv_b[l];
+            const float* cqkv = raw ? h->fold_qkv[l].c : nullptr;
             const int64_t waves = (int64_t)rows * groups;
             if (!cls_only) {
                 const bool by_pair = pairs && l == 0;       // Zt holds the P pair rows; BIG gets their Q/K/V
                 GemmEpilogue<T> eq = R.epi();
-                eq.bias = h->qkv_b[l]; eq.out_lo = BIG; eq.ld_lo = 3 * H;
+                eq.bias = bqkv; eq.out_lo = BIG; eq.ld_lo = 3 * H;
+                if (raw) { eq.fold_stats = hs_stats; eq.fold_c = cqkv; }
                 R.gemm(Zt, H, wqkv, H, by_pair ? P : m, 3 * H, H, eq);
                 hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                                    (const T*)BIG, (size_t)3 * H, (const T*)BIG + H, (const T*)BIG + 2 * H, (size_t)3 * H,
@@ -777,10 +842,12 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 T* KV = BIG;                              // [m, 2H]
                 T* Q = BIG + (size_t)m * 2 * H;           // [rows, H]  (rows <= m, BIG holds >= m x 3H)
                 GemmEpilogue<T> ekv = R.epi();
-                ekv.bias = h->qkv_b[l] + H; ekv.out_lo = KV; ekv.ld_lo = 2 * H;
+                ekv.bias = bqkv + H; ekv.out_lo = KV; ekv.ld_lo = 2 * H;
+                if (raw) { ekv.fold_stats = hs_stats; ekv.fold_c = cqkv + H; }
                 R.gemm(Zt, H, wqkv + (size_t)H * H, H, m, 2 * H, H, ekv);
                 GemmEpilogue<T> eq = R.epi();
-                eq.bias = h->qkv_b[l]; eq.out_lo = Q; eq.ld_lo = H;
+                eq.bias = bqkv; eq.out_lo = Q; eq.ld_lo = H;
+                if (raw) { eq.fold_stats = hs_stats; eq.fold_c = cqkv; }
                 R.gemm(Zt, H, wqkv, H, rows, H, H, eq);
                 hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                                    (const T*)Q, (size_t)H, (const T*)KV, (const T*)KV + H, (size_t)2 * H,
@@ -797,13 +864,21 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             eo.res_stats = hs_stats; eo.res_gamma = hs_gamma; eo.res_beta = hs_beta;
             if (pairs && l == 0) eo.res_index = brow_pair;       // hs_sum / hs_stats are still per pair here
             eo.out_f32 = s1; eo.ld_f32 = H;
+            if (fold) { eo.out_lo = Zt; eo.ld_lo = H; eo.stats_part = PARTS; eo.ld_part = (int)MC; }
             R.gemm(CTX, H, R.Wlo(lp + "attention.output.dense.weight"), H, zrows, H, H, eo);
             const float* g1 = R.Wf(lp + "attention.output.LayerNorm.weight");
             const float* b1 = R.Wf(lp + "attention.output.LayerNorm.bias");
-            R.layernorm(s1, zrows, g1, b1, c.ln_eps_encoder, nullptr, Zt, st1);
             GemmEpilogue<T> ei = R.epi();
-            ei.bias = R.Wf(lp + "intermediate.dense.bias"); ei.act = ACT_GELU_ERF; ei.out_lo = BIG; ei.ld_lo = I;
-            R.gemm(Zt, H, R.Wlo(lp + "intermediate.dense.weight"), H, zrows, I, H, ei);
+            ei.act = ACT_GELU_ERF; ei.out_lo = BIG; ei.ld_lo = I;
+            if (fold) {          // the attention-output LayerNorm is folded into intermediate.dense
+                R.ln_stats(PARTS, (int)MC, zrows, c.ln_eps_encoder, st1);
+                ei.bias = h->fold_up[l].b; ei.fold_stats = st1; ei.fold_c = h->fold_up[l].c;
+                R.gemm(Zt, H, (const T*)h->fold_up[l].w, H, zrows, I, H, ei);
+            } else {
+                R.layernorm(s1, zrows, g1, b1, c.ln_eps_encoder, nullptr, Zt, st1);
+                ei.bias = R.Wf(lp + "intermediate.dense.bias");
+                R.gemm(Zt, H, R.Wlo(lp + "intermediate.dense.weight"), H, zrows, I, H, ei);
+            }
             // FFN output: sum = dense(gelu) + LN(s1)
             float* s2 = other(s1);
             float* st2 = other_stats(st1);
@@ -811,12 +886,16 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             ef.bias = R.Wf(lp + "output.dense.bias"); ef.residual = s1; ef.ld_res = H;
             ef.res_stats = st1; ef.res_gamma = g1; ef.res_beta = b1;
             ef.out_f32 = s2; ef.ld_f32 = H;
+            if (fold && !last) { ef.out_lo = Zt; ef.ld_lo = H; ef.stats_part = PARTS; ef.ld_part = (int)MC; }
             R.gemm(BIG, I, R.Wlo(lp + "output.dense.weight"), I, zrows, H, I, ef);
             hs_gamma = R.Wf(lp + "output.LayerNorm.weight");
             hs_beta = R.Wf(lp + "output.LayerNorm.bias");
             hs_sum = s2; hs_stats = st2;
             // (the last layer's output LayerNorm is the readout below: position 0 only, whatever the layer computed)
-            if (!last) R.layernorm(s2, zrows, hs_gamma, hs_beta, c.ln_eps_encoder, nullptr, Zt, st2);
+            if (!last) {
+                if (fold) { R.ln_stats(PARTS, (int)MC, zrows, c.ln_eps_encoder, st2); raw = true; }
+                else R.layernorm(s2, zrows, hs_gamma, hs_beta, c.ln_eps_encoder, nullptr, Zt, st2);
+            }
         }
         if (R.rc) break;
 
