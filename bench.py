@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force one GEMM tile variant (zett_set_option gemm_variant); 0 = per-launch choice")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the side measurement of the same steps in the other 16-bit arithmetic (N = 1; reported as alt_precision, never as value)")
     ap.add_argument("--no-pair-dedupe", action="store_true", help="A/B only: layer 0's Q/K/V per packed position instead of per distinct (source id, position) pair (zett_set_option pair_dedupe 0; same bits)")
+    ap.add_argument("--no-ln-fold", action="store_true", help="A/B only: the encoder's LayerNorms as launches instead of folded into the GEMMs around them (zett_set_option ln_fold 0)")
     ap.add_argument("--no-retokenize", action="store_true", help="A/B only: start every step from the id matrix instead of the surface forms")
     ap.add_argument("--chunks", type=int, default=2, help="N > 1: row blocks per step (zett_amd/sharding.py: the all-gather of a block overlaps the next block's forward)")
     ap.add_argument("--serial-allgather", action="store_true", help="N > 1: one block per step, i.e. forward, then all-gather (A/B)")
@@ -188,6 +189,8 @@ def main():
         engine.set_option("max_chunk_tokens", args.max_chunk_tokens)
     if args.no_pair_dedupe:
         engine.set_option("pair_dedupe", 0)
+    if args.no_ln_fold:
+        engine.set_option("ln_fold", 0)
     # the same weights in the OTHER 16-bit arithmetic, for the side measurement after the timed region (N = 1 only)
     alt_precision = {"f16": "bf16", "bf16": "f16"}.get(args.precision) if (world == 1 and not args.no_alt_precision) else None
     alt_engine = None
@@ -197,6 +200,8 @@ def main():
         alt_engine.set_option("time_gemm", 1)
         if args.no_pair_dedupe:
             alt_engine.set_option("pair_dedupe", 0)
+        if args.no_ln_fold:
+            alt_engine.set_option("ln_fold", 0)
     if rank != 0 or args.no_cpu_baseline or world > 1:
         weights_keep = None
     else:

@@ -398,7 +398,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         // residual rows of both passes: requested before any store leaves (pass 1's right after pass 0 is staged, by
         // which time the accumulators of pass 0 have left their registers)
-        float4 res[2][RES ? NIT : 1];
+        // (LNP: ONE buffer — pass 1's rows are requested after pass 0 has drained; the row statistics and the second
+        //  output need the registers that both passes' rows would take, and a spill costs more than that wait)
+        constexpr int RB = LNP ? 1 : 2;
+        float4 res[RB][RES ? NIT : 1];
         auto load_res = [&](int p) {
             if constexpr (RES) {
 #pragma unroll
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const int i0 = __builtin_amdgcn_readlane(rix[p], t * RPI), i1 = __builtin_amdgcn_readlane(rix[p], t * RPI + 1);
                         rrow = (size_t)(rsub ? i1 : i0);
                     }
-                    res[p][t] = (grow < g.M && col_ok) ? *(const float4*)(e.residual + rrow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    res[p % RB][t] = (grow < g.M && col_ok) ? *(const float4*)(e.residual + rrow * e.ld_res + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         };
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) { bb[u * CPL + c] = bias[c]; ss[u * CPL + c] = sc[c]; hh[u * CPL + c] = sh[c]; rr[u * CPL + c] = 0.f; }
                     if constexpr (RES) {
-                        const float4 x = res[p][t0 + u];
+                        const float4 x = res[p % RB][t0 + u];
                         rr[u * CPL] = x.x; rr[u * CPL + 1] = x.y; rr[u * CPL + 2] = x.z; rr[u * CPL + 3] = x.w;
                         if (ACT == ACT_NONE && res_ln) {
                             const int r0 = (t0 + u) * RPI;          // rows r0 (rsub = 0) and r0 + 1 (rsub = 1) of the pass
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
         stage(0);
         __builtin_amdgcn_sched_barrier(0);         // (pass 1's residual registers only exist once pass 0's accumulators are staged)
-        load_res(1);
+        if constexpr (!LNP) load_res(1);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef G4D_TRACE
         __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
@@ -552,6 +555,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef G4D_TRACE
         trp[0][3] = trp[1][0] = wall_clock64();
 #endif
+        if constexpr (LNP) { __builtin_amdgcn_sched_barrier(0); load_res(1); __builtin_amdgcn_sched_barrier(0); }
         stage(1);
 #ifdef G4D_TRACE
         __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
