@@ -424,6 +424,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         region[(i4 * 16 + kq * 4 + r) * G4D_EPI_STRIDE + j * 16 + l15] = acc[4 * p + i4][j][r];
+            if constexpr (FOLD)      // row l's statistics into the four floats of padding behind its 128 staged columns
+                *(float2*)(region + lane_e * G4D_EPI_STRIDE + 128) = fst[p];
         };
         // FULL: all 64 rows and all 128 columns of the pass lie inside the matrix (wave-uniform): no predicate anywhere.
         // fp32 rows behind a residual go out non-temporal: they are streamed once to the LayerNorm kernel and stay out
@@ -463,21 +465,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
                 if constexpr (FOLD) {
-                    // acc <- rstd_row * (acc - mean_row * c_col): the LayerNorm of the A row, applied to the product
+                    // acc <- rstd_row * (acc - mean_row * c_col): the LayerNorm of the A row, applied to the product; the row's
+                    // (mean, rstd) sit in the padding of its staged row (stage_stats below): one 8-byte LDS read per instruction
 #pragma unroll
                     for (int u = 0; u < GROUP; ++u) {
-                        const int rb = (t0 + u) * RPI;      // rows rb .. rb + 3 of the pass (rsub selects)
-                        float mk[RPI], rk[RPI];
+                        const float2 st = *(const float2*)(region + ((t0 + u) * RPI + rsub) * G4D_EPI_STRIDE + 128);
 #pragma unroll
-                        for (int k = 0; k < RPI; ++k) {
-                            mk[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fst[p].x), rb + k));
-                            rk[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fst[p].y), rb + k));
-                        }
-                        float mean = mk[0], rstd = rk[0];
-#pragma unroll
-                        for (int k = 1; k < RPI; ++k) { mean = rsub == k ? mk[k] : mean; rstd = rsub == k ? rk[k] : rstd; }
-#pragma unroll
-                        for (int c = 0; c < CPL; ++c) v[u * CPL + c] = __builtin_fmaf(-mean, fc[c], v[u * CPL + c]) * rstd;
+                        for (int c = 0; c < CPL; ++c) v[u * CPL + c] = __builtin_fmaf(-st.x, fc[c], v[u * CPL + c]) * st.y;
                     }
                 }
                 epi_values<ACT, RES, SCALE, NV>(v, bb, rr, ss, hh);
