@@ -465,13 +465,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
                 if constexpr (FOLD) {
-                    // acc <- rstd_row * (acc - mean_row * c_col): the LayerNorm of the A row, applied to the product; the row's
-                    // (mean, rstd) sit in the padding of its staged row (stage_stats below): one 8-byte LDS read per instruction
+                    // acc <- rstd_row * (acc - mean_row * c_col) + bias_col, the LayerNorm of the A row applied to the product, as
+                    // two packed FMAs per pair of values: x = t * c + bias (t = -mean * rstd), acc * rstd + x.  The row's
+                    // (mean, rstd) sit in the padding of its staged row (stage): one 8-byte LDS read per instruction.
 #pragma unroll
                     for (int u = 0; u < GROUP; ++u) {
                         const float2 st = *(const float2*)(region + ((t0 + u) * RPI + rsub) * G4D_EPI_STRIDE + 128);
+                        const float t = -st.x * st.y;
+                        const f32x2 t2 = {t, t}, r2 = {st.y, st.y};
 #pragma unroll
-                        for (int c = 0; c < CPL; ++c) v[u * CPL + c] = __builtin_fmaf(-st.x, fc[c], v[u * CPL + c]) * st.y;
+                        for (int c = 0; c < CPL; c += 2) {
+                            const f32x2 x = __builtin_elementwise_fma(t2, f32x2{fc[c], fc[c + 1]}, f32x2{bias[c], bias[c + 1]});
+                            const f32x2 y = __builtin_elementwise_fma(f32x2{v[u * CPL + c], v[u * CPL + c + 1]}, r2, x);
+                            v[u * CPL + c] = y.x; v[u * CPL + c + 1] = y.y;
+                            bb[u * CPL + c] = 0.f; bb[u * CPL + c + 1] = 0.f;
+                        }
                     }
                 }
                 epi_values<ACT, RES, SCALE, NV>(v, bb, rr, ss, hh);
