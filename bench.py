@@ -324,6 +324,8 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak if peak else None, "traffic": traffic,
                      "kernel": "zett::gemm4d_tn_kernel (256x256 four-wave direct-to-LDS MFMA GEMM on 16x16x32 MFMAs: every 16-bit launch with K >= 512; its epilogues carry bias / GELU / residual and, with the LayerNorm fold, the encoder's LayerNorms), zett::gemm8r_tn_kernel (256x256 register-staged: shorter K and fp32 mode), 384x256 / 128x128 tiles where wave quantisation / small shapes call for them: all GEMM launches, FLOP-weighted", "launches_per_step": launches / max(args.steps, 1),
+                     "note": ("the GEMM launches also carry the encoder's LayerNorms (LayerNorm fold, DESIGN.md section 4): same box with --no-ln-fold, "
+                              "frac +0.01 and ms_per_step +0.9" if (args.precision != "f32" and not args.no_ln_fold) else "no LayerNorm fold in this run"),
                      "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
                      "executed_tflop_per_step": gemm_fl / max(args.steps, 1) / 1e12},
         "as_written_tflops": rows * f_ref * args.steps / dt / 1e12,
