@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ZETT_ABI_VERSION 2      /* 2: zett_stats gained distinct_positions */
+#define ZETT_ABI_VERSION 3      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range */
 
 enum zett_status {
     ZETT_OK = 0,
@@ -35,7 +35,17 @@ enum zett_status {
     ZETT_E_STATE = -3,        /* weights missing, handle not finalized, ...       */
     ZETT_E_INDEX = -4,        /* surface-form id outside [0, V0 + n_extra)        */
     ZETT_E_NOT_IMPLEMENTED = -5,
-    ZETT_E_KEY = -6           /* character outside the byte table (KeyError)      */
+    ZETT_E_KEY = -6,          /* character outside the byte table (KeyError)      */
+    ZETT_E_RANGE = -7         /* a value left the range of the 16-bit operand type, or an output is not finite
+                                 (zett_finalize: a weight; zett_check_range: the last forward)              */
+};
+
+/* Bits of the range word (zett_check_range). */
+enum zett_range_bits {
+    ZETT_RANGE_SOURCE = 1,      /* in_scaler(source_embeddings[id]) of a referenced id does not fit the operand type */
+    ZETT_RANGE_ACTIVATION = 2,  /* a 16-bit GEMM output (Q/K/V, FFN intermediate, the operand copy of the residual sum) */
+    ZETT_RANGE_OUTPUT = 4,      /* a predicted embedding is inf / NaN                                                */
+    ZETT_RANGE_WEIGHT = 8       /* a GEMM weight (or a LayerNorm-folded weight) does not fit: reported by zett_finalize */
 };
 
 enum zett_dtype { ZETT_F32 = 0, ZETT_F16 = 1, ZETT_BF16 = 2 };
@@ -129,6 +139,22 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
                  float* out_in, float* out_out, float* out_bias, void* stream);
 
 int zett_get_stats(const zett_hypernet* h, zett_stats* out);
+
+/* Range guard of the 16-bit arithmetic modes.  ZETT_PREC_F16 operands overflow to inf above 65504; LayerNorm'd
+ * activations and embedding-scale weights stay far inside, but with the LayerNorm fold the operand copy of the RAW
+ * residual sum is rounded to half, and a checkpoint with massive activations can leave the range.  Nothing is silent:
+ *   - zett_finalize returns ZETT_E_RANGE when a weight (or gamma-folded weight) does not fit the operand type;
+ *   - every kernel that writes a 16-bit operand, and the epilogues that write the predicted embeddings, OR a bit of
+ *     `zett_range_bits` into a device word that zett_forward clears when it starts.  An inf anywhere upstream reaches
+ *     the outputs of its row (inf / NaN propagate through every residual add), so ZETT_RANGE_OUTPUT is the catch-all
+ *     and the other bits say where it started;
+ *   - zett_check_range waits for `stream`, reads the word of the most recent zett_forward on the handle and returns
+ *     ZETT_E_RANGE if it is non-zero (0 otherwise); *flags (may be NULL) receives the word.  zett_forward itself
+ *     stays asynchronous.  What to do on a hit is the caller's policy: the Python layer (zett_amd/hypernet.py)
+ *     re-runs the call with bf16 operands (fp32's exponent range, same MFMA rate) and warns; a hit in BF16 / F32
+ *     mode means the outputs are non-finite in the reference's own arithmetic too (non-finite inputs or weights).
+ * The reference has no counterpart: its bf16 / fp32 arithmetic cannot leave the range short of inf in fp32. */
+int zett_check_range(zett_hypernet* h, void* stream, int32_t* flags);
 
 /* Upper bound of the device bytes zett_forward reserves (and keeps until zett_destroy)
  * for a [n_rows, seq] batch at the current options: the plan's worst case, no pad

@@ -45,8 +45,34 @@ def set_matmul_backend(name: str) -> None:
     _MATMUL_BACKEND = name
 
 
+_OPERAND_ROUNDING = None
+
+
+def set_operand_rounding(kind) -> None:
+    """None (default: the fp32 reference math) or "bf16" / "f16": round BOTH operands of every Linear to that type before
+    an fp32-accumulated product — a CPU emulation of what 16-bit MFMA operands must cost, whatever the kernel.
+    "bf16" is (an upper bound of the accuracy of) the reference CLI's own default arithmetic (scripts/transfer.py:41,
+    145-151: bfloat16 parameters and compute).  Used by tests that bound the HIP path's 16-bit modes by the error the
+    arithmetic itself implies instead of by a bare number."""
+    global _OPERAND_ROUNDING
+    assert kind in (None, "bf16", "f16")
+    _OPERAND_ROUNDING = kind
+
+
+def _round_operand(a):
+    if _OPERAND_ROUNDING is None:
+        return a
+    a = np.ascontiguousarray(a, dtype=F32)
+    if _OPERAND_ROUNDING == "f16":
+        return a.astype(np.float16).astype(F32)
+    u = a.view(np.uint32).astype(np.uint64)                  # bf16, round to nearest even
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(F32)
+
+
 def linear(x, w, b):
     """torch.nn.Linear: x @ w.T + b (fp32)."""
+    x, w = _round_operand(x), _round_operand(w)
     if _MATMUL_BACKEND == "torch":
         import torch
         x2 = np.ascontiguousarray(x, dtype=F32).reshape(-1, x.shape[-1])

@@ -17,8 +17,9 @@ outlier channels.  With Student-t (3 degrees of freedom) Linear weights, outlier
 heavy-tailed source table, f16 arithmetic (the default) stays inside its tolerance with the same margin as on
 normal weights; bf16 arithmetic lands at rel-L2 1.04e-2 at the 4096-wide shape — on the wrong side of the 1e-2
 line it clears by 3 % on normal weights (the operand rounding error of a dot product is relative, so it barely
-moves with the tails: it was on the edge before).  That measurement is why bf16 is not the default; the test pins
-bf16 to <= 1.2e-2 there so that the number stays visible.
+moves with the tails: it was on the edge before).  That measurement is why bf16 is not the default.  bf16 mode is
+bounded there by what bf16 operands cost in the oracle itself (operand-rounding emulation, + 10 %): the error is the
+arithmetic's, the arithmetic is the reference CLI's default, and the kernel adds none of its own.
 """
 import numpy as np
 import pytest
@@ -79,10 +80,14 @@ def test_full_size_parity(name):
     sample = np.unique(np.concatenate([[2, 3, rows - 1], rng.choice(np.arange(2, rows), SAMPLE_ROWS - 3, replace=False)]))
     hypernet_ref.set_matmul_backend("torch")
     want = hypernet_ref.forward({k: v.float().cpu().numpy() for k, v in weights.items()}, cfg, ids[sample], src_np, None if lang < 0 else lang)
-    for precision in ("f16", "bf16"):
+    # f32 — the mode whose tolerance north_star names — at full size on the headline workload and on the narrow one
+    # (its launches run gemm8r's fp32 instantiation at M = 77 k / 169 k rows; 0.5 s per forward)
+    precisions = ("f16", "bf16", "f32") if name in ("mistral_gpt2_32k", "xlmr_gpt2") else ("f16", "bf16")
+    for precision in precisions:
         eng = _engine(cfg, weights, precision)
         full = _run(eng, ids, src, lang)
         assert all(t is None or bool(torch.isfinite(t).all()) for t in full)
+        assert eng.range_flags() == 0                        # range guard: nothing left the operand range
         st = eng.stats()
         assert st["rows"] == rows and 0 < st["packed_tokens"] <= rows * 8 and 0 < st["distinct_ids"]
         if name == "llama3_256k":
@@ -135,13 +140,26 @@ def test_heavy_tailed_checkpoint_stays_inside_tolerance(name, rows):
     want = hypernet_ref.forward({k: v.float().cpu().numpy() for k, v in weights.items()}, cfg, ids[sample], src.cpu().numpy(), None)
     kurt = float(((src - src.mean()) ** 4).mean() / src.var() ** 2)
     assert kurt > 6.0, kurt                                  # the table really is heavy-tailed (normal: 3)
+    # What bf16 operands cost on THIS checkpoint whatever the kernel: the oracle with both operands of every Linear rounded
+    # to bf16 (fp32 accumulate).  That is (an upper bound on the accuracy of) the reference CLI's own default arithmetic
+    # (scripts/transfer.py:41: bfloat16 parameters and compute), so bf16 mode is held to SURVEY 8d's 1e-2 OR to that
+    # emulation + 10 %, whichever is larger: the HIP path may not add error of its own, and no bare relaxed number remains.
+    hypernet_ref.set_operand_rounding("bf16")
+    try:
+        emulated = hypernet_ref.forward({k: v.float().cpu().numpy() for k, v in weights.items()}, cfg, ids[sample], src.cpu().numpy(), None)
+    finally:
+        hypernet_ref.set_operand_rounding(None)
     for precision in ("f16", "bf16"):
         eng = _engine(cfg, weights, precision)
         full = _run(eng, ids, src, -1)
+        assert eng.range_flags() == 0                        # heavy tails, but nothing near the half range
         if precision != "bf16":
             _check_sample(full, want, sample, precision, f"{name} heavy-tailed")
         else:
             idx = torch.from_numpy(sample).cuda()
-            for got, ref, what in zip(full, want, ("pred_in", "pred_out", "bias")):
-                util.assert_bf16_close(got[idx].cpu().numpy(), ref, f"{name} heavy-tailed bf16 {what}", rel_max=1.2e-2 if ref.ndim > 1 else 1.8e-2)
+            for got, ref, emu, what in zip(full, want, emulated, ("pred_in", "pred_out", "bias")):
+                rel_emu = float(np.linalg.norm(emu - ref) / np.linalg.norm(ref))
+                lim = util.BF16_REL_L2 if ref.ndim > 1 else util.BF16_REL_L2_VECTOR
+                util.assert_bf16_close(got[idx].cpu().numpy(), ref, f"{name} heavy-tailed bf16 {what} (emulated bf16 operands: {rel_emu:.2e})",
+                                       rel_max=max(lim, 1.1 * rel_emu))
         eng.close()

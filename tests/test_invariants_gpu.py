@@ -134,6 +134,37 @@ def test_repeated_launches_identical_bits_small_grids():
         eng.set_option("gemm_tile_order", 2)
 
 
+def test_long_rows_pair_lever_bit_identical_and_vs_oracle():
+    """Rows with more than 64 packed positions (hn_surface_maxlen >= 64 is legal: position_embeddings has 514 rows).
+    The attention kernel hands a row's first 64 (source id, position) pair slots out by wave shuffle; slots past the
+    64th must be read directly (r2 advisor finding: the shuffle index wrapped modulo 64).  Pair lever on == off bit
+    for bit, both == the as-written oracle in f32, with an all-pad (uniform) 80-position row in the batch."""
+    from oracle import hypernet_ref
+    cfg, *_ = synth.workload("tiny")
+    cfg = dict(cfg, hn_surface_maxlen=80)
+    hist = tuple([1e-3] * 60 + [1.0] * 20)                       # lengths 61..80 (+ the language token: 62..81 positions)
+    ids = synth.make_surface_forms(cfg, 400, seed=9, hist=hist, seq=80, n_special=2)
+    assert (ids != cfg["pad_token_id"]).sum(1).max() > 64
+    w = synth.make_weights(cfg, seed=9)
+    src_np = synth.make_source_embeddings(cfg, 9)
+    src = torch.from_numpy(src_np).cuda()
+    from zett_amd.hypernet import HipEngine
+    for precision in ("f32", "f16"):
+        eng = HipEngine(HypernetDims.from_config(cfg), 1e-5, torch.device("cuda:0"), precision)
+        eng.load_weights({k: torch.from_numpy(v).cuda() for k, v in w.items()})
+        on = _run(eng, ids, src, 2)
+        st = eng.stats()
+        assert st["distinct_positions"] < st["packed_tokens"], st           # the lever is taken
+        eng.set_option("pair_dedupe", 0)
+        off = _run(eng, ids, src, 2)
+        assert _eq(on, off), precision
+        if precision == "f32":
+            want = hypernet_ref.forward(w, cfg, ids[:48], src_np, lang_index=2)
+            for g, r, what in zip(on, want, ("pred_in", "pred_out", "bias")):
+                util.assert_f32_close(g[:48].cpu().numpy(), r, f"long rows {what}")
+        eng.close()
+
+
 def test_pad_content_independence():
     """Changing the pad token's source embedding must change nothing for rows with a visible key."""
     cfg, *_ = synth.workload("tiny")

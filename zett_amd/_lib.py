@@ -12,7 +12,8 @@ import threading
 from .build import LIB_PATH
 
 ZETT_OK = 0
-E_INVALID, E_HIP, E_STATE, E_INDEX, E_NOT_IMPLEMENTED, E_KEY = -1, -2, -3, -4, -5, -6
+E_INVALID, E_HIP, E_STATE, E_INDEX, E_NOT_IMPLEMENTED, E_KEY, E_RANGE = -1, -2, -3, -4, -5, -6, -7
+RANGE_SOURCE, RANGE_ACTIVATION, RANGE_OUTPUT, RANGE_WEIGHT = 1, 2, 4, 8      # zett_range_bits
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
 RETOK_BPE, RETOK_UNIGRAM = 0, 1
@@ -20,7 +21,7 @@ RETOK_BPE, RETOK_UNIGRAM = 0, 1
 ABI_SYMBOLS = (
     "zett_last_error", "zett_abi_version", "zett_create", "zett_destroy", "zett_load_weight",
     "zett_finalize", "zett_forward", "zett_get_stats", "zett_workspace_bytes", "zett_set_option",
-    "zett_retok_create", "zett_retok_destroy", "zett_retokenize",
+    "zett_retok_create", "zett_retok_destroy", "zett_retokenize", "zett_check_range",
 )
 
 
@@ -32,7 +33,7 @@ class ZettConfig(C.Structure):
         ("ln_eps_encoder", C.c_float), ("ln_eps_projector", C.c_float)]
 
 
-ABI_VERSION = 2      # ZETT_ABI_VERSION of include/zett_hip.h
+ABI_VERSION = 3      # ZETT_ABI_VERSION of include/zett_hip.h
 
 
 class ZettStats(C.Structure):
@@ -87,6 +88,7 @@ def load():
         lib.zett_get_stats.argtypes = [C.c_void_p, C.POINTER(ZettStats)]
         lib.zett_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         lib.zett_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        lib.zett_check_range.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         lib.zett_retok_create.argtypes = [C.POINTER(ZettRetokModel), C.c_int, C.POINTER(C.c_void_p)]
         lib.zett_retok_destroy.argtypes = [C.c_void_p]
         lib.zett_retokenize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
@@ -100,6 +102,10 @@ def load():
                                "rebuild it (`python -m zett_amd.build`)")
         _lib = lib
     return _lib
+
+
+class RangeError(OverflowError):
+    """ZETT_E_RANGE: a value left the range of the 16-bit operand type, or an output is not finite."""
 
 
 def check(rc: int, what: str = "") -> None:
@@ -117,4 +123,6 @@ def check(rc: int, what: str = "") -> None:
         raise KeyError(msg)
     if rc == E_INVALID:
         raise ValueError(msg)
+    if rc == E_RANGE:
+        raise RangeError(msg)
     raise RuntimeError(msg)

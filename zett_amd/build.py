@@ -14,9 +14,12 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libzett_hip.so")
-SOURCES = ("zett_hip.hip",)
-HEADERS = tuple(sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))) + ("../../include/zett_hip.h",)      # every header of csrc/
-HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC")
+# One translation unit per kernel family and operand type: hipcc compiles them in parallel, and an edit to one tile kernel
+# rebuilds only its own objects (csrc/gemm_launch.hip.h).
+SOURCES = tuple(sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")))
+HEADERS = tuple(sorted(f for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".inc"))) + ("../../include/zett_hip.h",)      # every header of csrc/
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC")
+OBJ_DIR = os.path.join(CSRC, "build")
 
 
 def source_hash() -> str:
@@ -48,13 +51,48 @@ def is_stale() -> bool:
     return False
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def _includes(path: str, seen=None) -> set:
+    """Headers of csrc/ a source reaches through #include "..." (transitively)."""
+    import re
+    seen = set() if seen is None else seen
+    with open(path) as f:
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', f.read(), re.M):
+            full = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+            if os.path.exists(full) and full not in seen:
+                seen.add(full)
+                _includes(full, seen)
+    return seen
+
+
+def _object_stale(src: str, obj: str) -> bool:
+    if not os.path.exists(obj):
+        return True
+    built = os.path.getmtime(obj)
+    return any(os.path.getmtime(p) > built for p in [src, *_includes(src)])
+
+
+def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc(), *HIPCC_FLAGS, "-o", LIB_PATH + ".tmp", *[os.path.join(CSRC, s) for s in SOURCES]]
-    if verbose:
-        print("[zett_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    todo, objs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ_DIR, s[:-4] + ".o")
+        objs.append(obj)
+        if force or _object_stale(src, obj):
+            todo.append([hipcc, *HIPCC_FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print("[zett_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    jobs = jobs or int(os.environ.get("ZETT_BUILD_JOBS", "0")) or min(len(todo) or 1, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
+        list(pool.map(run, todo))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp", *objs])
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

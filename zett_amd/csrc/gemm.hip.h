@@ -273,7 +273,24 @@ struct GemmEpilogue {
     int ld_lo;
     int split_col;
     float* out_f32_b;
+    // Range guard (include/zett_hip.h zett_check_range): where a launch ORs its findings, or null.  16-bit outputs of an f16
+    // launch are checked against the half range (ZETT_RANGE_ACTIVATION); with range_final the fp32 outputs are the
+    // predicted embeddings and are checked for inf / NaN (ZETT_RANGE_OUTPUT).
+    int32_t* range_flag;
+    int range_final;
 };
+
+// Largest finite value of the operand type: what a value written as a 16-bit operand is checked against.  bf16 and fp32
+// share fp32's exponent range: only the half type can overflow where the fp32 value was finite.
+template <typename T> struct LoRange { static constexpr bool checked = false; static constexpr float limit = 0.f; };
+template <> struct LoRange<f16_t> { static constexpr bool checked = true; static constexpr float limit = 65504.0f; };
+// true where v would not survive: beyond the limit, or NaN (the comparison is false for NaN)
+__device__ __forceinline__ bool out_of_range(float v, float limit) { return !(__builtin_fabsf(v) <= limit); }
+constexpr float ZETT_F32_MAX = 3.402823466e38f;
+constexpr int ZETT_RANGE_BIT_SOURCE = 1, ZETT_RANGE_BIT_ACTIVATION = 2, ZETT_RANGE_BIT_OUTPUT = 4, ZETT_RANGE_BIT_WEIGHT = 8;
+__device__ __forceinline__ void range_report(int32_t* flag, bool bad, int bit) {
+    if (bad && flag) atomicOr(flag, bit);      // (never taken on a healthy checkpoint)
+}
 
 template <typename T>
 struct GemmArgs {
@@ -428,6 +445,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31,
     //      row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const GemmEpilogue<T>& e = g.epi;
+    bool bad_lo = false, bad_out = false;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
@@ -452,13 +470,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
                     if (e.out_f32) e.out_f32[(size_t)row * e.ld_f32 + col] = v;
                     if (e.out_lo) {
                         e.out_lo[(size_t)row * e.ld_lo + col] = to_lo<T>(v);
+                        if (LoRange<T>::checked) bad_lo |= out_of_range(v, LoRange<T>::limit);
                     }
                 } else if (e.out_f32_b) {
                     e.out_f32_b[(size_t)row * e.ld_f32 + (col - e.split_col)] = v;
                 }
+                if (e.range_final) bad_out |= out_of_range(v, ZETT_F32_MAX);
             }
         }
     }
+    range_report(e.range_flag, bad_lo, ZETT_RANGE_BIT_ACTIVATION);
+    range_report(e.range_flag, bad_out, ZETT_RANGE_BIT_OUTPUT);
 }
 
 constexpr int GEMM_LDS_BYTES = 4 * GEMM_TILE_BYTES;   // two buffers x (A tile + W tile) = 64 KiB

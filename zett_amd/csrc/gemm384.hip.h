@@ -127,7 +127,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // four passes (one per 32-row MFMA tile row), drained by EpiDrain (gemm_tile.hip.h).
     __syncthreads();
     float* region = (float*)(smem + wave * 8192);
-    typedef EpiDrain<T, ACT, RES, 32, 64, false> Drain;      // no scale/shift: launch_gemm384 refuses such epilogues
+    typedef EpiDrain<T, ACT, RES, 32, 64, false, true, false> Drain;      // no scale/shift: launch_gemm384 refuses such epilogues
     const int gcol = n0 + wn * 64 + (lane % Drain::LPR) * 8;
     const bool col_ok = gcol < g.N;
     float4 bias8[2], sc8[2], sh8[2];

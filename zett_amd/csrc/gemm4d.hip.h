@@ -324,6 +324,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         static_assert(!(LO && RES), "the 16-bit-only epilogue has no residual");
         float* region = (float*)(smem + wave * G4D_EPI_REGION);
         const GemmEpilogue<T>& e = g.epi;
+        // range guard (GemmEpilogue::range_flag): every value that leaves as a 16-bit operand of an f16 launch is compared
+        // with the half range (one v_cmp per value, accumulated in a scalar mask); the launches that write the predicted
+        // embeddings (range_final, wave-uniform) check their fp32 values for inf / NaN instead
+        constexpr bool W16 = LO || EPI == G4D_EPI_BOTH || LNP;
+        constexpr bool CHK16 = W16 && LoRange<T>::checked;
+        const bool chk_final = !W16 && e.range_final != 0;
+        bool bad = false;
         const int idx = lane_e % LPR, rsub = lane_e / LPR;
         const int gcol = n0 + wn * 128 + idx * CPL;
         const bool col_ok = gcol < g.N;
@@ -483,6 +490,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
                 epi_values<ACT, RES, SCALE, NV>(v, bb, rr, ss, hh);
+                if constexpr (CHK16) {
+#pragma unroll
+                    for (int x = 0; x < NV; ++x) bad |= out_of_range(v[x], LoRange<T>::limit);
+                } else if (chk_final) {
+#pragma unroll
+                    for (int x = 0; x < NV; ++x) bad |= out_of_range(v[x], ZETT_F32_MAX);
+                }
                 if constexpr (LNP) {
                     // per-row (sum, sum of squares) over the wave's 128 columns: a reduce-scatter over the 32 lanes of a row
                     // group — after the xor-16 and xor-8 exchanges a lane carries ONE of the group's four row pairs, after
@@ -567,6 +581,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef G4D_TRACE
         trp[1][3] = wall_clock64();
 #endif
+        range_report(e.range_flag, bad, W16 ? ZETT_RANGE_BIT_ACTIVATION : ZETT_RANGE_BIT_OUTPUT);
     }
 #ifdef G4D_TRACE
     __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);

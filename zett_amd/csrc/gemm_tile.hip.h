@@ -71,7 +71,9 @@ template <> __device__ __forceinline__ void store_out8<f16_t>(f16_t* dst, float4
 // first version of this epilogue paid (11 us per tile).
 // SCALE = false: the caller guarantees epi.scale == nullptr (saves the 16 scale/shift registers).
 // NTF32 = false: never use the non-temporal store path (callers whose register budget is exhausted).
-template <typename T, int ACT, bool RES, int ROWS, int COLS, bool SCALE = true, bool NTF32 = true>
+// GUARD = false: no range guard in this drain (gemm384: 168 registers per wave, the comparisons spill; its launches are
+// covered by the catch-all check of the launches that write the predicted embeddings, which never take that tile).
+template <typename T, int ACT, bool RES, int ROWS, int COLS, bool SCALE = true, bool NTF32 = true, bool GUARD = true>
 struct EpiDrain {
     static constexpr int LPR = COLS / 8;       // lanes per row
     static constexpr int RPI = 64 / LPR;       // rows per wave instruction
@@ -142,6 +144,21 @@ struct EpiDrain {
             const float4 lo = sw ? second : first, hi = sw ? first : second;
             oa[t] = epi_value4<ACT>(lo, bias8[0], RES, RES ? oa[t] : zero, has_scale, sc8[0], sh8[0]);
             ob[t] = epi_value4<ACT>(hi, bias8[1], RES, RES ? ob[t] : zero, has_scale, sc8[1], sh8[1]);
+        }
+        // range guard (GemmEpilogue::range_flag): the values about to be written as 16-bit operands / as predicted embeddings
+        if (GUARD && e.range_flag) {
+            bool bad = false;
+            const float lim = e.range_final ? ZETT_F32_MAX : LoRange<T>::limit;
+            if (e.range_final || (LoRange<T>::checked && e.out_lo)) {
+#pragma unroll
+                for (int t = 0; t < NIT; ++t) {
+                    const int grow = row0 + t * RPI + lane / LPR;
+                    if (grow >= g.M || !col_ok) continue;
+                    bad |= out_of_range(oa[t].x, lim) | out_of_range(oa[t].y, lim) | out_of_range(oa[t].z, lim) | out_of_range(oa[t].w, lim) |
+                           out_of_range(ob[t].x, lim) | out_of_range(ob[t].y, lim) | out_of_range(ob[t].z, lim) | out_of_range(ob[t].w, lim);
+                }
+            }
+            range_report(e.range_flag, bad, e.range_final ? ZETT_RANGE_BIT_OUTPUT : ZETT_RANGE_BIT_ACTIVATION);
         }
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {

@@ -269,14 +269,20 @@ __global__ __launch_bounds__(256) void gather_src_kernel(const int32_t* __restri
                                                          const void* __restrict__ src, int e_in, int v0,
                                                          const float* __restrict__ fallback,
                                                          const float* __restrict__ sc_w, const float* __restrict__ sc_b,
-                                                         T* __restrict__ out) {
+                                                         T* __restrict__ out, int32_t* __restrict__ range_flag) {
     const int s = blockIdx.x;
     if (s >= n_slots) return;
     const int id = id_list[slot0 + s];
     T* dst = out + (size_t)s * e_in;
+    bool bad = false;          // range guard: a value that does not fit the operand type (f16 only), ZETT_RANGE_SOURCE
+    auto chk = [&](float4 v) {
+        if (LoRange<T>::checked)
+            bad |= out_of_range(v.x, LoRange<T>::limit) | out_of_range(v.y, LoRange<T>::limit) | out_of_range(v.z, LoRange<T>::limit) |
+                   out_of_range(v.w, LoRange<T>::limit);
+    };
     if (id >= v0) {
         const float* f = fallback + (size_t)(id - v0) * e_in;
-        for (int c = threadIdx.x * 4; c < e_in; c += 1024) store_lo4<T>(dst + c, *(const float4*)(f + c));
+        for (int c = threadIdx.x * 4; c < e_in; c += 1024) { const float4 v = *(const float4*)(f + c); chk(v); store_lo4<T>(dst + c, v); }
     } else {
         const size_t base = (size_t)id * e_in;
         for (int c = threadIdx.x * 4; c < e_in; c += 1024) {
@@ -285,9 +291,11 @@ __global__ __launch_bounds__(256) void gather_src_kernel(const int32_t* __restri
                 const float4 w = *(const float4*)(sc_w + c), b = *(const float4*)(sc_b + c);
                 v.x = w.x * v.x + b.x; v.y = w.y * v.y + b.y; v.z = w.z * v.z + b.z; v.w = w.w * v.w + b.w;
             }
+            chk(v);
             store_lo4<T>(dst + c, v);
         }
     }
+    range_report(range_flag, bad, ZETT_RANGE_BIT_SOURCE);
 }
 
 // ---------------------------------------------------------------------------
@@ -503,11 +511,16 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
     auto brow = [&](int t) -> size_t { return (size_t)chunk_row(t, rl, t == t0, rows); };
     // row of q / k / v of packed position t: its buffer row, or — layer 0 with the pair lever — the row of its
     // (source id, position) pair, whose Q/K/V were computed once
-    // (the row's <= 64 pair slots are fetched once, one per lane, and handed out by shuffle: an index load in front of
-    //  every key would put a second memory round trip into the loop)
+    // (the row's first 64 pair slots are fetched once, one per lane, and handed out by shuffle: an index load in front of
+    //  every key would put a second memory round trip into the loop; a row with more than 64 packed positions —
+    //  hn_surface_maxlen >= 64 is legal, max_positions is 514 — reads the slots past the 64th directly: t is
+    //  wave-uniform, so the branch is too)
     int pslot = 0;
     if (tok_pair) { const int t = t0 + lane; pslot = t < t1 ? tok_pair[tok0 + t] : 0; }
-    auto qrow = [&](int t) -> size_t { return tok_pair ? (size_t)__shfl(pslot, t - t0, 64) : brow(t); };
+    auto qrow = [&](int t) -> size_t {
+        if (!tok_pair) return brow(t);
+        return t - t0 < 64 ? (size_t)__shfl(pslot, t - t0, 64) : (size_t)tok_pair[tok0 + t];
+    };
     for (int qi = 0; qi < nq; ++qi) {
         float q[8];
         load8<T>(qbase + (cls_only ? (size_t)rl : qrow(t0 + qi)) * ldq + ccol, q);
@@ -564,13 +577,15 @@ __global__ void ln_stats_kernel(const float2* __restrict__ part, int parts, int 
 template <typename T>
 __global__ __launch_bounds__(256) void fold_weight_kernel(const float* __restrict__ w, int K, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ bias,
-                                                          T* __restrict__ w_fold, float* __restrict__ c_out, float* __restrict__ b_out) {
+                                                          T* __restrict__ w_fold, float* __restrict__ c_out, float* __restrict__ b_out,
+                                                          int32_t* __restrict__ range_flag) {
     __shared__ float red[4];
     const int n = blockIdx.x;
     const float* row = w + (size_t)n * K;
     float cs = 0.f, bs = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) {
         const float x = row[k];
+        if (LoRange<T>::checked) range_report(range_flag, out_of_range(x * gamma[k], LoRange<T>::limit), ZETT_RANGE_BIT_WEIGHT);
         const T lo = to_lo<T>(x * gamma[k]);
         w_fold[(size_t)n * K + k] = lo;
         cs += lo_to_f32<T>(lo);
@@ -583,13 +598,21 @@ __global__ __launch_bounds__(256) void fold_weight_kernel(const float* __restric
 
 // dtype conversion used when weights are uploaded
 template <typename T>
-__global__ void convert_f32_to_lo_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
+__global__ void convert_f32_to_lo_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n, int32_t* __restrict__ range_flag) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
-    for (; i + 3 < n; i += stride) store_lo4<T>(out + i, *(const float4*)(in + i));
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (size_t j = n & ~(size_t)3; j < n; ++j) out[j] = to_lo<T>(in[j]);
+    bool bad = false;          // range guard: a weight that does not fit the operand type (f16 only), ZETT_RANGE_WEIGHT
+    for (; i + 3 < n; i += stride) {
+        const float4 v = *(const float4*)(in + i);
+        if (LoRange<T>::checked)
+            bad |= out_of_range(v.x, LoRange<T>::limit) | out_of_range(v.y, LoRange<T>::limit) | out_of_range(v.z, LoRange<T>::limit) |
+                   out_of_range(v.w, LoRange<T>::limit);
+        store_lo4<T>(out + i, v);
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (size_t j = n & ~(size_t)3; j < n; ++j) { out[j] = to_lo<T>(in[j]); if (LoRange<T>::checked) bad |= out_of_range(in[j], LoRange<T>::limit); }
+    }
+    range_report(range_flag, bad, ZETT_RANGE_BIT_WEIGHT);
 }
 template <int SRC_DTYPE>
 __global__ void convert_to_f32_kernel(const void* __restrict__ in, float* __restrict__ out, size_t n) {

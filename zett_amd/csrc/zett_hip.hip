@@ -30,10 +30,7 @@
 #include "../../include/zett_hip.h"
 #include "common.hip.h"
 #include "gemm.hip.h"
-#include "gemm_tile.hip.h"
-#include "gemm384.hip.h"
-#include "gemm8r.hip.h"
-#include "gemm4d.hip.h"
+#include "gemm_launch.hip.h"
 #include "rowops.hip.h"
 #include "retok.hip.h"
 
@@ -81,6 +78,8 @@ struct zett_hypernet {
                                       // 7 = 256x256 four-wave direct-to-LDS, 8 = as 7 with the generic epilogue drain
     // workspace
     DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct, lnstats, lnparts;
+    int32_t* range_word = nullptr;    // device: zett_range_bits of the forward in flight (cleared when a forward starts)
+    int32_t* range_host = nullptr;    // pinned: where zett_check_range / zett_finalize read it
     int32_t* host_pinned = nullptr;
     size_t host_pinned_ints = 0;
     std::vector<hipEvent_t> ev;
@@ -234,13 +233,17 @@ int zett_create(const zett_config* cfg, int device, int precision, zett_hypernet
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(ZETT_E_INVALID, "device %d out of range (%d visible)", device, ndev);
     ZETT_ON_DEVICE(device);
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     auto* h = new zett_hypernet();
     h->cfg = *cfg;
     h->device = device;
     h->precision = precision;
+    if (hipMalloc((void**)&h->range_word, 64) != hipSuccess || hipHostMalloc((void**)&h->range_host, 64, hipHostMallocDefault) != hipSuccess ||
+        hipMemset(h->range_word, 0, 64) != hipSuccess) {
+        if (h->range_word) (void)hipFree(h->range_word);
+        if (h->range_host) (void)hipHostFree(h->range_host);
+        delete h;
+        return fail(ZETT_E_HIP, "allocation of the range word failed");
+    }
     *out = h;
     return 0;
 }
@@ -253,9 +256,11 @@ int zett_destroy(zett_hypernet* h) {
         if (kv.second.lo && kv.second.lo != (void*)kv.second.f32) (void)hipFree(kv.second.lo);
     }
     for (void* p : h->owned) (void)hipFree(p);
-    for (DevBuf* b : {&h->plan_i32, &h->plan_u8, &h->table, &h->x0, &h->yf, &h->yt, &h->big, &h->pre, &h->ctx, &h->cf, &h->ct, &h->lnstats})
+    for (DevBuf* b : {&h->plan_i32, &h->plan_u8, &h->table, &h->x0, &h->yf, &h->yt, &h->big, &h->pre, &h->ctx, &h->cf, &h->ct, &h->lnstats, &h->lnparts})
         b->release();
     if (h->host_pinned) (void)hipHostFree(h->host_pinned);
+    if (h->range_word) (void)hipFree(h->range_word);
+    if (h->range_host) (void)hipHostFree(h->range_host);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
     return 0;
@@ -322,9 +327,9 @@ int zett_finalize(zett_hypernet* h) {
         HIP_TRY(hipMalloc(&t.lo, t.numel * 2));
         const int blocks = (int)std::min<size_t>((t.numel / 4 + 255) / 256 + 1, 65535);
         if (h->precision == ZETT_PREC_F16)
-            hipLaunchKernelGGL(convert_f32_to_lo_kernel<f16_t>, dim3(blocks), dim3(256), 0, 0, t.f32, (f16_t*)t.lo, t.numel);
+            hipLaunchKernelGGL(convert_f32_to_lo_kernel<f16_t>, dim3(blocks), dim3(256), 0, 0, t.f32, (f16_t*)t.lo, t.numel, h->range_word);
         else
-            hipLaunchKernelGGL(convert_f32_to_lo_kernel<bf16_t>, dim3(blocks), dim3(256), 0, 0, t.f32, (bf16_t*)t.lo, t.numel);
+            hipLaunchKernelGGL(convert_f32_to_lo_kernel<bf16_t>, dim3(blocks), dim3(256), 0, 0, t.f32, (bf16_t*)t.lo, t.numel, h->range_word);
     }
     HIP_TRY(hipDeviceSynchronize());
     // fused QKV operand per layer: rows [q | k | v]
@@ -355,9 +360,9 @@ int zett_finalize(zett_hypernet* h) {
             HIP_TRY(hipMalloc((void**)&f.b, N * 4));
             h->owned.push_back(f.w); h->owned.push_back(f.c); h->owned.push_back(f.b);
             if (h->precision == ZETT_PREC_F16)
-                hipLaunchKernelGGL(fold_weight_kernel<f16_t>, dim3((unsigned)N), dim3(256), 0, 0, w32, (int)K, gamma, beta, bias, (f16_t*)f.w, f.c, f.b);
+                hipLaunchKernelGGL(fold_weight_kernel<f16_t>, dim3((unsigned)N), dim3(256), 0, 0, w32, (int)K, gamma, beta, bias, (f16_t*)f.w, f.c, f.b, h->range_word);
             else
-                hipLaunchKernelGGL(fold_weight_kernel<bf16_t>, dim3((unsigned)N), dim3(256), 0, 0, w32, (int)K, gamma, beta, bias, (bf16_t*)f.w, f.c, f.b);
+                hipLaunchKernelGGL(fold_weight_kernel<bf16_t>, dim3((unsigned)N), dim3(256), 0, 0, w32, (int)K, gamma, beta, bias, (bf16_t*)f.w, f.c, f.b, h->range_word);
             return 0;
         };
         h->fold_qkv.resize(c.layers); h->fold_up.resize(c.layers);
@@ -379,6 +384,11 @@ int zett_finalize(zett_hypernet* h) {
         HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(tmp);
     }
+    // range guard: a weight (or gamma-folded weight) that does not fit the operand type is an error here, not an inf later
+    HIP_TRY(hipMemcpy(h->range_host, h->range_word, 4, hipMemcpyDeviceToHost));
+    if (h->range_host[0] & ZETT_RANGE_WEIGHT)
+        return fail(ZETT_E_RANGE, "a GEMM weight (or a LayerNorm-folded weight W*gamma) exceeds the half range (|w| > 65504 or not finite): "
+                                  "this checkpoint needs ZETT_PREC_BF16 or ZETT_PREC_F32");
     // output Rescaler vectors laid out over the first head's columns
     if (c.rescale) {
         const size_t w0 = c.single_head ? c.n_in_embd : c.n_embd;
@@ -452,6 +462,22 @@ int zett_get_stats(const zett_hypernet* h, zett_stats* out) {
     return 0;
 }
 
+int zett_check_range(zett_hypernet* h, void* stream, int32_t* flags) {
+    if (!h) return fail(ZETT_E_INVALID, "null handle");
+    ZETT_ON_DEVICE(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h->range_host, h->range_word, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int32_t w = h->range_host[0];
+    if (flags) *flags = w;
+    if (!w) return 0;
+    return fail(ZETT_E_RANGE, "the last forward left the range of its arithmetic:%s%s%s (precision %s)",
+                (w & ZETT_RANGE_SOURCE) ? " in_scaler(source_embeddings) beyond the half range;" : "",
+                (w & ZETT_RANGE_ACTIVATION) ? " a 16-bit activation (Q/K/V, FFN intermediate or the operand copy of the residual sum) beyond the half range;" : "",
+                (w & ZETT_RANGE_OUTPUT) ? " non-finite predicted embeddings;" : "",
+                h->precision == ZETT_PREC_F16 ? "f16: re-run with ZETT_PREC_BF16" : h->precision == ZETT_PREC_BF16 ? "bf16" : "f32");
+}
+
 int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq,
                  const void* source_embeddings, int src_dtype, int64_t v_src, int32_t lang_index,
                  float* out_in, float* out_out, float* out_bias, void* stream) {
@@ -460,7 +486,12 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
     const zett_config& c = h->cfg;
     if (n_rows < 0 || seq < 1) return fail(ZETT_E_INVALID, "bad surface-form shape [%lld, %d]", (long long)n_rows, seq);
     if (seq + (c.embed_lang ? 1 : 0) > c.max_positions) return fail(ZETT_E_INDEX, "sequence %d exceeds position_embeddings (%d rows)", seq, c.max_positions);
-    if (n_rows == 0) { h->stats = zett_stats{}; return 0; }
+    if (n_rows == 0) {
+        h->stats = zett_stats{};
+        ZETT_ON_DEVICE(h->device);
+        HIP_TRY(hipMemsetAsync(h->range_word, 0, 4, (hipStream_t)stream));
+        return 0;
+    }
     if (!surface_forms || !source_embeddings || !out_in || !out_bias) return fail(ZETT_E_INVALID, "null tensor argument");
     const bool has_out = c.separate_out;
     if (has_out && !out_out) return fail(ZETT_E_INVALID, "out_out is required when separate_out_embeddings is set");
@@ -495,15 +526,12 @@ struct Runner {
     GemmEpilogue<T> epi() {
         GemmEpilogue<T> e{};
         e.split_col = 0x7fffffff;
+        e.range_flag = h->range_word;
         return e;
     }
 
     long a_rows_readable = 0;   // rows every A operand buffer can be read for (workspace slack)
 
-    static hipError_t launch_4d(const GemmArgs<T>& g, hipStream_t s, bool generic_epilogue) {
-        if constexpr (std::is_same<T, float>::value) return hipErrorInvalidValue;
-        else return launch_gemm4d<T>(g, s, generic_epilogue);
-    }
     void gemm(const T* A, int lda, const T* Wp, int ldw, int M, int N, int K, const GemmEpilogue<T>& e) {
         if (rc || M <= 0) return;
         GemmArgs<T> g{A, lda, Wp, ldw, M, N, K, e};
@@ -542,7 +570,7 @@ struct Runner {
                 if (c384 < c256) variant = 3;
             }
         }
-        if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift || e.residual)) variant = 2;
+        if (variant == 3 && (N % 256 != 0 || (long)((M + 383) / 384) * 384 > a_rows_readable || e.scale || e.shift || e.residual || e.range_final)) variant = 2;
         // 16-bit operands, K >= 2048: the four-wave direct-to-LDS tile on 16x16x32 MFMAs (4-8 % ahead of the
         // register-staged eight-wave kernels on the launches of the benchmark step; identical bits).
         if (h->gemm_variant == 0 && variant == 2 && !is_f32 && K >= h->gemm4d_min_k) variant = 7;
@@ -554,14 +582,7 @@ struct Runner {
         if (e.residual && (e.scale || e.shift)) variant = 1;      // the large tiles compile their residual epilogues without the Rescaler
         if (e.stats_part || e.fold_stats) variant = 7;       // LayerNorm-fold launches exist in gemm4d only (any M)
         if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
-        hipError_t err;
-        switch (variant) {
-            case 8: err = launch_4d(g, st, true); break;
-            case 7: err = launch_4d(g, st, false); break;
-            case 3: err = launch_gemm384<T>(g, st); break;
-            case 2: err = launch_gemm8r<T>(g, st); break;
-            default: err = launch_gemm<T>(g, st); break;
-        }
+        const hipError_t err = launch_gemm_variant(variant, g, st);      // gemm_launch.hip.h: the tile kernels live in their own translation units
         if (h->time_gemm) (void)hipEventRecord(e1, st);
         if (err != hipSuccess) { rc = fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(err)); return; }
         h->stats.executed_flops += fl;
@@ -611,9 +632,9 @@ struct Runner {
 
 template <typename T, int SD>
 void launch_gather(hipStream_t st, const int32_t* id_list, int s0, int m, const void* src, const zett_config& c,
-                   const float* fallback, const float* sw, const float* sb, T* out) {
+                   const float* fallback, const float* sw, const float* sb, T* out, int32_t* range_flag) {
     hipLaunchKernelGGL((gather_src_kernel<T, SD>), dim3(m), dim3(256), 0, st, id_list, s0, m, src, c.n_in_embd,
-                       c.original_vocab_size, fallback, sw, sb, out);
+                       c.original_vocab_size, fallback, sw, sb, out, range_flag);
 }
 
 template <typename T>
@@ -664,6 +685,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     p.tok_key = p.row_uniform + N;
     HIP_TRY(hipMemsetAsync(p.id_flag, 0, (size_t)V * 4, st));
     HIP_TRY(hipMemsetAsync(p.err, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(h->range_word, 0, 4, st));          // range guard: the word of THIS forward (zett_check_range)
     if (pair_plan) HIP_TRY(hipMemsetAsync(p.pair_flag, 0, (size_t)PK * 4, st));
     const int rb = (int)((N + 255) / 256);
     hipLaunchKernelGGL(plan_rows_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
@@ -747,9 +769,9 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     for (int s0 = 0; s0 < D && !R.rc; s0 += (int)MC) {
         const int m = (int)std::min<int64_t>(MC, D - s0);
         const float* fb = R.Wf("fallback_embeddings.weight");
-        if (src_dtype == ZETT_F32) launch_gather<T, 0>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0);
-        else if (src_dtype == ZETT_F16) launch_gather<T, 1>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0);
-        else launch_gather<T, 2>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0);
+        if (src_dtype == ZETT_F32) launch_gather<T, 0>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0, h->range_word);
+        else if (src_dtype == ZETT_F16) launch_gather<T, 1>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0, h->range_word);
+        else launch_gather<T, 2>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0, h->range_word);
         R.check("gather_src");
         GemmEpilogue<T> e0 = R.epi();
         e0.bias = R.Wf("input_projection.0.bias"); e0.out_f32 = Zf; e0.ld_f32 = H; e0.out_lo = Zt; e0.ld_lo = H;
@@ -914,7 +936,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             e.bias = R.Wf("output_projection.1.bias");
             e.scale = c.rescale ? h->head_scale : nullptr;
             e.shift = c.rescale ? h->head_shift : nullptr;
-            e.out_f32 = out_in + (size_t)r0 * E; e.ld_f32 = E;
+            e.out_f32 = out_in + (size_t)r0 * E; e.ld_f32 = E; e.range_final = 1;
             const int width = c.single_head ? EIN : E;
             if (c.single_head && c.separate_out) { e.split_col = E; e.out_f32_b = out_out + (size_t)r0 * E; }
             R.gemm(CTX, H, R.Wlo("output_projection.1.weight"), H, rows, width, H, e);
@@ -925,7 +947,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             e.bias = R.Wf("output_projection_out.1.bias");
             e.scale = c.rescale ? R.Wf("out_scaler.w") : nullptr;
             e.shift = c.rescale ? R.Wf("out_scaler.b") : nullptr;
-            e.out_f32 = out_out + (size_t)r0 * E; e.ld_f32 = E;
+            e.out_f32 = out_out + (size_t)r0 * E; e.ld_f32 = E; e.range_final = 1;
             R.gemm(CTX, H, R.Wlo("output_projection_out.1.weight"), H, rows, E, H, e);
         }
         r0 = r1;

@@ -110,6 +110,18 @@ class HipEngine:
         _lib.check(self.lib.zett_workspace_bytes(self.handle, int(n_rows), int(seq), C.byref(out)), "zett_workspace_bytes")
         return out.value
 
+    def range_flags(self) -> int:
+        """Wait for the current stream and return the range word of the most recent forward (zett_check_range):
+        0 = every 16-bit operand stayed inside its type's range and the predicted embeddings are finite; otherwise a
+        combination of _lib.RANGE_SOURCE / RANGE_ACTIVATION / RANGE_OUTPUT."""
+        flags = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.zett_check_range(self.handle, C.c_void_p(stream), C.byref(flags))
+        if rc not in (_lib.ZETT_OK, _lib.E_RANGE):
+            _lib.check(rc, "zett_check_range")
+        return int(flags.value)
+
     def stats(self) -> dict:
         s = _lib.ZettStats()
         _lib.check(self.lib.zett_get_stats(self.handle, C.byref(s)))
@@ -180,6 +192,13 @@ class ZettHypernet(PreTrainedModel):
         # (same MFMA rate: the chip is power-limited and significand bits cost energy; rounding the f16
         # activations to 9 bits recovered 0.5-1.4 % of that by box at 3x the error and was dropped).
         self.precision = os.environ.get("ZETT_PRECISION", getattr(config, "zett_precision", None) or DEFAULT_PRECISION)
+        # Range guard (include/zett_hip.h zett_check_range).  f16 operands overflow above 65504; with the LayerNorm fold the
+        # operand copy of the raw residual sum is rounded to half, and a checkpoint with massive activations can leave the
+        # range.  Policy of this layer, ONE policy for the class and the CLI: compute in f16, ask the device after every
+        # forward (one 4-byte read behind a stream sync), and on a hit repeat the call with bf16 operands (fp32's
+        # exponent range, the arithmetic of the reference CLI) with a warning; the model then stays on bf16.  Set
+        # range_guard = False to take the asynchronous forward and call engine(...).range_flags() yourself.
+        self.range_guard = True
         for name, shape in weight_shapes(self.dims).items():
             _attach(self, name, nn.Parameter(torch.empty(shape, dtype=torch.float32), requires_grad=False))
         self._engines: Dict[Tuple[str, str], HipEngine] = {}
@@ -275,4 +294,29 @@ class ZettHypernet(PreTrainedModel):
             lang = int(lang_index.item()) if torch.is_tensor(lang_index) else int(lang_index)
         else:
             lang = -1
-        return self.engine(device).forward(target_surface_forms, source_embeddings, lang)
+        return self._guarded_forward(device, target_surface_forms, source_embeddings, lang)
+
+    def _guarded_forward(self, device, surface_forms, source_embeddings, lang):
+        import warnings
+        if self.precision in ("f16", "fp16", "float16") and self.range_guard:
+            try:
+                eng = self.engine(device)
+                out = eng.forward(surface_forms, source_embeddings, lang)
+                flags = eng.range_flags()
+            except _lib.RangeError as err:           # zett_finalize: a weight does not fit the half type
+                out, flags = None, _lib.RANGE_WEIGHT
+                warnings.warn(f"zett_amd: {err}; continuing with bf16 operands")
+            if not flags:
+                return out
+            if out is not None:
+                where = [n for b, n in ((_lib.RANGE_SOURCE, "in_scaler(source_embeddings)"), (_lib.RANGE_ACTIVATION, "a 16-bit activation"),
+                                        (_lib.RANGE_OUTPUT, "non-finite outputs")) if flags & b]
+                warnings.warn("zett_amd: the f16 forward left the half range (" + ", ".join(where) + "); repeating the call with bf16 "
+                              "operands (fp32 exponent range, rel-L2 ~1e-2 instead of ~1e-3 of the fp32 reference). The model stays on bf16.")
+            self.precision = "bf16"
+        eng = self.engine(device)
+        out = eng.forward(surface_forms, source_embeddings, lang)
+        if self.range_guard and eng.range_flags() & _lib.RANGE_OUTPUT:
+            warnings.warn(f"zett_amd: non-finite predicted embeddings in {self.precision} arithmetic (non-finite weights or source embeddings?); "
+                          "returned as computed, as the reference would")
+        return out

@@ -194,11 +194,40 @@ def init_distributed(device_index_from_env: bool = True):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # (the collectives of a run are all over within seconds of each other; the long timeout only keeps a watchdog from
+        #  firing while one rank is still paging a 7B-parameter model in)
+        import datetime
+        timeout = datetime.timedelta(hours=2)
         if one_device:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=timeout)
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=timeout)
     return device
+
+
+def dtype_given(argv) -> bool:
+    """True when --dtype was passed on the command line (argv None = sys.argv)."""
+    import sys
+    args = sys.argv[1:] if argv is None else list(argv)
+    return any(a == "--dtype" or a.startswith("--dtype=") for a in args)
+
+
+def precision_for_dtype(dtype: str, explicit: bool) -> str:
+    """Arithmetic of the dense contractions for the CLI's --dtype (scripts/transfer.py:41).
+
+    The reference flag is the dtype its parameters are held and computed in; its default is bfloat16.  Here parameters are
+    fp32 and the flag picks the MFMA operand type.  NOT passing the flag selects the library policy
+    (zett_amd/hypernet.py DEFAULT_PRECISION: f16 operands with the range guard and its bf16 fallback — 8x closer to the
+    fp32 reference than bf16 at the same MFMA rate, and inside SURVEY.md section 8d's tolerance where bf16 sits on its edge);
+    passing --dtype bfloat16 / float16 / float32 explicitly selects exactly that arithmetic; anything else is an error
+    (the reference would fail in getattr(jnp, dtype))."""
+    from .hypernet import DEFAULT_PRECISION
+    if not explicit and dtype == "bfloat16":
+        return DEFAULT_PRECISION
+    table = {"bfloat16": "bf16", "float32": "f32", "float16": "f16"}
+    if dtype not in table:
+        raise ValueError(f"--dtype {dtype!r}: expected one of {sorted(table)}")
+    return table[dtype]
 
 
 def target_priors_of(tokenizer) -> np.ndarray:
@@ -247,7 +276,7 @@ def main(argv=None):
         hypernet = ZettHypernet.from_flax_checkpoint(args.checkpoint_path).to(device)
     else:
         hypernet = AutoModel.from_pretrained(args.checkpoint_path).to(device)
-    hypernet.precision = {"bfloat16": "bf16", "float32": "f32", "float16": "f16"}.get(args.dtype, "bf16")
+    hypernet.precision = precision_for_dtype(args.dtype, dtype_given(argv))
 
     source_tokenizer = AutoTokenizer.from_pretrained(args.target_model)
     hn_tokenizer = type(source_tokenizer).from_pretrained(args.checkpoint_path)
@@ -263,7 +292,10 @@ def main(argv=None):
     emb_out = None if tied else out_layer.weight.data
     source_embeddings = (emb_in if emb_out is None else torch.cat([emb_in, emb_out], dim=1)).to(device)   # :162-191
 
-    if args.copy_inner_parameters_from is not None:
+    if _rank() != 0:
+        # only rank 0 writes the model: the other ranks needed the embedding matrices (now on their GPU) and nothing else
+        downstream = emb_in = emb_out = out_layer = None
+    elif args.copy_inner_parameters_from is not None:
         downstream = model_cls.from_pretrained(args.copy_inner_parameters_from, torch_dtype=torch.float32)
 
     tokenizer = convert_to_byte_level(tokenizer, make_whitespace_consistent=args.make_whitespace_consistent,
@@ -275,10 +307,15 @@ def main(argv=None):
     target_priors = target_priors_of(tokenizer)                                                          # :210-219
     pred_in, pred_out, pred_bias = predict_vocabulary(hypernet, sfm.long(), source_embeddings, lang_index, args, target_priors)
 
-    if _rank() != 0:          # every rank holds the whole prediction; one of them writes the model
+    # every rank holds the whole prediction; the last collective is over.  The group is torn down HERE, so that no rank
+    # sits in a barrier (and no watchdog runs) while rank 0 spends minutes writing a multi-GB model.
+    if _world_size() > 1:
         import torch.distributed as dist
+        rank = _rank()
         dist.barrier()
-        return
+        dist.destroy_process_group()
+        if rank != 0:
+            return
     special_src = list(source_tokenizer.all_special_ids)                                                  # :274-300
     special_dst = [tokenizer.get_vocab()[t] for t in source_tokenizer.all_special_tokens]
     os.makedirs(args.output, exist_ok=True)
@@ -298,9 +335,6 @@ def main(argv=None):
         save_file({"bias": pred_bias.cpu()}, os.path.join(args.output, "bias.safetensors"))
     downstream.config.vocab_size = len(tokenizer)
     downstream.save_pretrained(args.output, max_shard_size="20GB")
-    if _world_size() > 1:
-        import torch.distributed as dist
-        dist.barrier()
 
 
 if __name__ == "__main__":
