@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "gemm.hip.h"
+// -DGEMM_BENCH_LEAN: only the product kernels (128x128, gemm8r, gemm384, gemm4d, gemm2w) — compiles in a minute instead of seven
+#ifndef GEMM_BENCH_LEAN
 #include "gemm256.hip.h"
 #include "gemm256p.hip.h"
 #include "gemm256r.hip.h"
@@ -24,11 +26,14 @@
 #include "gemm4w.hip.h"
 #include "gemm256l.hip.h"
 #include "gemm4r.hip.h"
-#include "gemm8r.hip.h"
 #include "gemm8x.hip.h"
 #include "gemm4dx.hip.h"
 #include "gemm8p.hip.h"
+#endif
+#include "gemm8r.hip.h"
 #include "gemm384.hip.h"
+#include "gemm4d.hip.h"
+#include "gemm2w.hip.h"
 
 using namespace zett;
 
@@ -86,6 +91,15 @@ int main(int argc, char** argv) {
         shapes = {{8192, 8192, 8192}, {65536, 12288, 4096}, {65536, 4096, 4096}, {65536, 8192, 4096},
                   {65536, 4096, 8192}, {29187, 4096, 8192}, {32768, 4096, 4096}, {5111, 4096, 4096}};
     CK(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+#ifdef GEMM_BENCH_LEAN
+    std::vector<Variant> variants = {{"g128", launch_gemm<bf16_t>}};
+    variants.push_back({"g384", launch_gemm384<bf16_t>});
+    variants.push_back({"g8r", launch_gemm8r<bf16_t>});
+    variants.push_back({"p4d", [](const GemmArgs<bf16_t>& g, hipStream_t st) { return launch_gemm4d<bf16_t>(g, st, false); }});      // the product kernel, streamlined epilogues
+    variants.push_back({"p4dg", [](const GemmArgs<bf16_t>& g, hipStream_t st) { return launch_gemm4d<bf16_t>(g, st, true); }});      // the product kernel, generic drain
+    variants.push_back({"g2w", [](const GemmArgs<bf16_t>& g, hipStream_t st) { return launch_gemm2w<bf16_t>(g, st, false); }});      // 128x256, two workgroups per CU
+    variants.push_back({"g2wg", [](const GemmArgs<bf16_t>& g, hipStream_t st) { return launch_gemm2w<bf16_t>(g, st, true); }});      // ... with the generic drain
+#else
     std::vector<Variant> variants = {{"g128", launch_gemm<bf16_t>}, {"g256", launch_gemm256<bf16_t, 0>}};
     variants.push_back({"g256_spread", launch_gemm256<bf16_t, 1>});
     variants.push_back({"spread_skew", launch_gemm256<bf16_t, 17>});
@@ -110,6 +124,8 @@ int main(int argc, char** argv) {
     variants.push_back({"g8x", launch_gemm8x<bf16_t>});
     variants.push_back({"p4d", [](const GemmArgs<bf16_t>& g, hipStream_t st) { return launch_gemm4d<bf16_t>(g, st, false); }});      // the product kernel, streamlined epilogues
     variants.push_back({"p4dg", [](const GemmArgs<bf16_t>& g, hipStream_t st) { return launch_gemm4d<bf16_t>(g, st, true); }});      // the product kernel, generic drain
+    variants.push_back({"g2w", [](const GemmArgs<bf16_t>& g, hipStream_t st) { return launch_gemm2w<bf16_t>(g, st, false); }});      // 128x256, two workgroups per CU
+    variants.push_back({"g2wg", [](const GemmArgs<bf16_t>& g, hipStream_t st) { return launch_gemm2w<bf16_t>(g, st, true); }});      // ... with the generic drain
     variants.push_back({"g4d", launch_gemm4dx<bf16_t>});
     variants.push_back({"g4dt4", launch_gemm4dx<bf16_t, 4>});
     variants.push_back({"g4ds1", launch_gemm4dx<bf16_t, 101>});
@@ -152,6 +168,7 @@ int main(int argc, char** argv) {
         CK(hipFuncSetAttribute((const void*)gemm256p_tn_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
         variants.push_back({"Adma_Wvgpr", launch_gemm256p<bf16_t, 9>});
     }
+#endif
     if (const char* only = getenv("ONLY")) {      // comma-separated names; the reference variant 0 always stays
         std::vector<Variant> kept = {variants[0]};
         std::string o = std::string(",") + only + ",";
