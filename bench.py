@@ -238,6 +238,22 @@ def main():
     lang_arg = -1 if lang is None else lang
 
     acc = {"gemm_ms": 0.0, "gemm_flops_timed": 0.0, "gemm_launches": 0}
+    classes = {}          # launch class -> [launches, ms, flops, algorithmic bytes] over the timed steps (zett_get_gemm_log)
+
+    def launch_class(r):
+        e = r["epilogue"]
+        act = {0: "", 1: " + tanh-GELU", 2: " + erf-GELU"}[(e >> 8) & 3]
+        if e & 16:
+            return "LayerNorm-fold producer (fp32 residual in, fp32 + 16-bit out, row statistics)"
+        if e & 32:
+            return "LayerNorm-fold consumer, 16-bit out" + act
+        if e & 8:
+            return "output head (Rescaler, fp32 out)"
+        if e & 4:
+            return "fp32 residual, fp32 out" + act
+        if (e & 3) == 3:
+            return "fp32 + 16-bit out" + act
+        return ("16-bit out" if e & 1 else "fp32 out") + act
 
     def step():
         gather = RowGather(blocks) if world > 1 else None
@@ -248,6 +264,10 @@ def main():
             st_k = engine.stats()
             for key in acc:
                 acc[key] += st_k[key]
+            if world == 1:
+                for r in engine.gemm_log():
+                    c = classes.setdefault(launch_class(r), [0, 0.0, 0.0, 0.0])
+                    c[0] += 1; c[1] += r["ms"]; c[2] += r["flops"]; c[3] += r["bytes"]
             if gather is not None:
                 gather.add(b, outs)            # async all-gather of this block; the next block's forward runs meanwhile
         return outs if gather is None else gather.finish(rows)
@@ -265,9 +285,11 @@ def main():
     t0 = time.perf_counter()
     for key in acc:
         acc[key] = 0
+    classes.clear()
     for _ in range(args.steps):
         out = step()
     gemm_ms, gemm_fl, launches = acc["gemm_ms"], acc["gemm_flops_timed"], acc["gemm_launches"]
+    timed_classes = {k: list(v) for k, v in classes.items()}
     torch.cuda.synchronize()   # (every step ends with its own all-gathers complete on the compute stream)
     if world > 1:
         dist.barrier()
@@ -295,14 +317,21 @@ def main():
     # this same command.  It is only quoted for the workload and precision it was taken on AND while the HIP sources
     # still hash to what was profiled (zett_amd.build.source_hash): a stale file yields null, not an old number.
     traffic = None
+    traffic_source = None
     try:
         from zett_amd.build import source_hash
         pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
         if (args.workload == "mistral_gpt2_32k" and args.precision == pmc.get("precision") and world == 1 and not args.rows
                 and pmc.get("source_hash") == source_hash()):
             traffic = pmc["hbm_bytes_per_launch"]
+            traffic_source = {"profile_set": pmc.get("tag"), "commit": pmc.get("commit"), "source_hash": pmc.get("source_hash"), "method": pmc.get("method")}
+        else:
+            traffic_source = {"stale": True, "reason": "profiles/pmc_traffic.json was taken on other HIP sources, another workload or another precision",
+                              "profile_set": pmc.get("tag"), "source_hash_profiled": pmc.get("source_hash"), "source_hash_now": source_hash()}
     except Exception:
         traffic = None
+    alg_bytes = sum(v[3] for v in timed_classes.values())
+    alg_launches = sum(v[0] for v in timed_classes.values())
 
     f_ref = as_written_flops_per_row(dims, int(ids_all.shape[1]))
 
@@ -327,10 +356,38 @@ def main():
                      "note": ("the GEMM launches also carry the encoder's LayerNorms (LayerNorm fold, DESIGN.md section 4): same box with --no-ln-fold, "
                               "frac +0.01 and ms_per_step +0.9" if (args.precision != "f32" and not args.no_ln_fold) else "no LayerNorm fold in this run"),
                      "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
-                     "executed_tflop_per_step": gemm_fl / max(args.steps, 1) / 1e12},
+                     "executed_tflop_per_step": gemm_fl / max(args.steps, 1) / 1e12,
+                     "traffic_source": traffic_source,
+                     # A and W read once, every output written once, residual rows read once, summed over the launches of the
+                     # timed steps / their number: what `traffic` (a PMC measurement, when present) is to be compared with
+                     "algorithmic_bytes_per_launch": alg_bytes / alg_launches if alg_launches else None,
+                     "traffic_over_algorithmic": (traffic / (alg_bytes / alg_launches)) if (traffic and alg_launches) else None,
+                     # the same FLOP / HIP-event-time ratio per launch class (zett_get_gemm_log), so that the fraction can be
+                     # read class by class: K loops are alike, the epilogues differ
+                     "by_class": [{"class": k, "launches_per_step": v[0] / max(args.steps, 1), "ms_per_step": v[1] / max(args.steps, 1),
+                                   "achieved": (v[2] / (v[1] * 1e-3) / 1e12) if v[1] > 0 else None,
+                                   "frac": (v[2] / (v[1] * 1e-3) / 1e12 / peak) if v[1] > 0 else None,
+                                   "algorithmic_gb_per_launch": v[3] / v[0] / 1e9 if v[0] else None}
+                                  for k, v in sorted(timed_classes.items(), key=lambda kv: -kv[1][1])]},
         "as_written_tflops": rows * f_ref * args.steps / dt / 1e12,
         "as_written_gflop_per_row": f_ref / 1e9,
     }
+    if world == 1:
+        # What a caller gets: the same steps with the per-launch HIP events (and the stream sync that reads them at the end of
+        # every forward) switched off.  Measured after the timed region; `value` / `ms_per_step` stay the instrumented,
+        # conservative figures the roofline is priced on.
+        engine.set_option("time_gemm", 0)
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dt_plain = time.perf_counter() - t1
+        engine.set_option("time_gemm", 1)
+        result["ms_per_step_uninstrumented"] = dt_plain / args.steps * 1e3
+        result["value_uninstrumented"] = rows * args.steps / dt_plain
+        result["range_flags"] = engine.range_flags()          # range guard of the 16-bit arithmetic: 0 = nothing left the operand range
     if alt_engine is not None:
         # Side measurement, outside the timed region and never `value`: the SAME steps in the other 16-bit arithmetic
         # (f16 is the default because bf16 sits on the edge of the parity tolerance; it costs ~4 %: both

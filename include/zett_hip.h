@@ -140,6 +140,22 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
 
 int zett_get_stats(const zett_hypernet* h, zett_stats* out);
 
+/* Per-launch record of the GEMMs of the most recent zett_forward ("time_gemm" on: durations from HIP events recorded on
+ * the launch stream around every launch).  What bench.py prices its roofline on, launch class by launch class. */
+typedef struct zett_gemm_record {
+    int32_t m, n, k;
+    int32_t variant;              /* tile kernel that ran: the "gemm_variant" numbering                          */
+    int32_t epilogue;             /* bit 0 16-bit output, 1 fp32 output, 2 residual, 3 Rescaler, 4 LayerNorm-fold producer
+                                     (16-bit copy + partial statistics), 5 LayerNorm-fold consumer; bits 8-9 activation
+                                     (0 none, 1 tanh-GELU, 2 erf-GELU)                                            */
+    float ms;                     /* launch duration (0 when "time_gemm" is off)                                  */
+    double flops;                 /* 2*m*n*k                                                                      */
+    double bytes;                 /* algorithmic HBM bytes of the launch: A and W read once, every output written
+                                     once, the residual rows read once                                            */
+} zett_gemm_record;
+/* Copies up to `capacity` records into `out` (may be NULL with capacity 0) and stores the number of launches in *count. */
+int zett_get_gemm_log(const zett_hypernet* h, zett_gemm_record* out, int64_t capacity, int64_t* count);
+
 /* Range guard of the 16-bit arithmetic modes.  ZETT_PREC_F16 operands overflow to inf above 65504; LayerNorm'd
  * activations and embedding-scale weights stay far inside, but with the LayerNorm fold the operand copy of the RAW
  * residual sum is rounded to half, and a checkpoint with massive activations can leave the range.  Nothing is silent:

@@ -48,6 +48,7 @@ def test_struct_layouts_match_header():
     from zett_amd import _lib
     assert ctypes.sizeof(_lib.ZettConfig) == 16 * 4 + 2 * 4
     assert ctypes.sizeof(_lib.ZettStats) == 9 * 8
+    assert ctypes.sizeof(_lib.ZettGemmRecord) == 5 * 4 + 4 + 2 * 8
     # zett_retok_model: int,int,4 ptr,double,int,ptr,3 int,ptr,int,int,3 ptr  (natural alignment)
     assert _lib.ZettRetokModel.piece_scores.offset == 32
     assert _lib.ZettRetokModel.unigram_min_score.offset == 40

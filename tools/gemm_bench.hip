@@ -183,12 +183,15 @@ int main(int argc, char** argv) {
     for (auto& s : shapes) {
         const int M = s[0], N = s[1], K = s[2];
         bf16_t *A, *W, *C0, *C1;
-        float *bias, *res, *cf;
+        float *bias, *res, *cf, *stats;
+        float2* parts;
         const int ldpad = getenv("LDPAD") ? atoi(getenv("LDPAD")) : 0;      // extra elements per operand row (channel spread)
         const int ldk = K + ldpad;
         CK(hipMalloc(&A, ((size_t)M + 512) * ldk * 2)); CK(hipMalloc(&W, (size_t)N * ldk * 2));
         CK(hipMalloc(&C0, (size_t)M * N * 2)); CK(hipMalloc(&C1, (size_t)M * N * 2));
         CK(hipMalloc(&bias, (size_t)N * 4)); CK(hipMalloc(&res, (size_t)M * N * 4)); CK(hipMalloc(&cf, (size_t)M * N * 4));
+        CK(hipMalloc(&stats, (size_t)M * 8)); CK(hipMalloc(&parts, (size_t)M * (N / 128 + 1) * 8));
+        fill_f32<<<64, 256>>>(stats, (size_t)M * 2, 5, 1.0f);
         if (getenv("ZERO")) {               // all-zero operands: the rate of the schedule without the power limit
             CK(hipMemset(A, 0, (size_t)M * ldk * 2)); CK(hipMemset(W, 0, (size_t)N * ldk * 2));
         } else if (getenv("NORMAL")) {
@@ -211,6 +214,11 @@ int main(int argc, char** argv) {
             else if (epi_mode == 5) { g.epi.bias = bias; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N; }   // the library's residual launches: fp32 out only
             else if (epi_mode == 6) { g.epi.bias = bias; g.epi.act = ACT_GELU_TANH; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N; }   // ProjectorBlock dense2
             else if (epi_mode == 7) { g.epi.bias = bias; g.epi.scale = res; g.epi.shift = bias; g.epi.out_f32 = cf; g.epi.ld_f32 = N; }   // output head with Rescaler
+            else if (epi_mode == 8) {   // LayerNorm-fold producer (attention-output / FFN-down of an encoder layer): LN'd fp32 residual, fp32 + 16-bit out, partial statistics
+                g.epi.bias = bias; g.epi.residual = res; g.epi.ld_res = N; g.epi.res_stats = stats; g.epi.res_gamma = bias; g.epi.res_beta = bias;
+                g.epi.out_f32 = cf; g.epi.ld_f32 = N; g.epi.out_lo = out; g.epi.ld_lo = N; g.epi.stats_part = parts; g.epi.ld_part = M; }
+            else if (epi_mode == 9) {   // LayerNorm-fold consumer with erf-GELU (FFN up)
+                g.epi.bias = bias; g.epi.act = ACT_GELU_ERF; g.epi.out_lo = out; g.epi.ld_lo = N; g.epi.fold_stats = stats; g.epi.fold_c = bias; }
             else if (epi_mode == 4) { g.epi.bias = bias; g.epi.scale = res; g.epi.shift = bias; g.epi.out_f32 = cf; g.epi.ld_f32 = N; g.epi.out_lo = out; g.epi.ld_lo = N; }
             else { g.epi.bias = bias; g.epi.residual = res; g.epi.ld_res = N; g.epi.out_f32 = cf; g.epi.ld_f32 = N; g.epi.out_lo = out; g.epi.ld_lo = N; }
             return g;
@@ -254,7 +262,7 @@ int main(int argc, char** argv) {
         }
         printf("\n");
         fflush(stdout);
-        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C0)); CK(hipFree(C1)); CK(hipFree(bias)); CK(hipFree(res)); CK(hipFree(cf)); CK(hipFree(dmax));
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C0)); CK(hipFree(C1)); CK(hipFree(bias)); CK(hipFree(res)); CK(hipFree(cf)); CK(hipFree(dmax)); CK(hipFree(stats)); CK(hipFree(parts));
     }
     return 0;
 }

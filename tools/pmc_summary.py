@@ -66,6 +66,12 @@ def main(dirs):
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from zett_amd.build import source_hash
         out["source_hash"] = source_hash()
+        out["tag"] = os.environ.get("ZETT_PMC_TAG")                  # profile set (profiles/<tag>_*) the passes belong to
+        try:
+            import subprocess
+            out["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip() or None
+        except Exception:
+            out["commit"] = None
         json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
     f = lambda x, fmt: "" if x is None else fmt % x
     for _, k, n, dur, rd, wr, bw, util, clk in sorted(rows):

@@ -36,5 +36,5 @@ PY
   echo "Summarised by \`tools/pmc_summary.py\` (FETCH_SIZE doubled per the gfx950 correction; GRBM_GUI_ACTIVE is summed over the 8 XCDs)."; echo
   python tools/pmc_summary.py $src/pmc_FETCH_SIZE $src/pmc_WRITE_SIZE $src/pmc_SQ_VALU_MFMA_BUSY_CYCLES
 } > profiles/${tag}_pmc.md
-python tools/pmc_summary.py $src/pmc_FETCH_SIZE $src/pmc_WRITE_SIZE $src/pmc_SQ_VALU_MFMA_BUSY_CYCLES --json profiles/pmc_traffic.json > /dev/null
+ZETT_PMC_TAG=$tag python tools/pmc_summary.py $src/pmc_FETCH_SIZE $src/pmc_WRITE_SIZE $src/pmc_SQ_VALU_MFMA_BUSY_CYCLES --json profiles/pmc_traffic.json > /dev/null
 echo "wrote profiles/${tag}_*"

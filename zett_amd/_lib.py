@@ -21,7 +21,7 @@ RETOK_BPE, RETOK_UNIGRAM = 0, 1
 ABI_SYMBOLS = (
     "zett_last_error", "zett_abi_version", "zett_create", "zett_destroy", "zett_load_weight",
     "zett_finalize", "zett_forward", "zett_get_stats", "zett_workspace_bytes", "zett_set_option",
-    "zett_retok_create", "zett_retok_destroy", "zett_retokenize", "zett_check_range",
+    "zett_retok_create", "zett_retok_destroy", "zett_retokenize", "zett_check_range", "zett_get_gemm_log",
 )
 
 
@@ -40,6 +40,11 @@ class ZettStats(C.Structure):
     _fields_ = [("rows", C.c_int64), ("packed_tokens", C.c_int64), ("distinct_ids", C.c_int64),
                 ("chunks", C.c_int64), ("executed_flops", C.c_double), ("gemm_ms", C.c_double),
                 ("gemm_launches", C.c_int64), ("gemm_flops_timed", C.c_double), ("distinct_positions", C.c_int64)]
+
+
+class ZettGemmRecord(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("variant", C.c_int32), ("epilogue", C.c_int32),
+                ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
 class ZettRetokModel(C.Structure):
@@ -89,6 +94,7 @@ def load():
         lib.zett_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         lib.zett_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.zett_check_range.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+        lib.zett_get_gemm_log.argtypes = [C.c_void_p, C.POINTER(ZettGemmRecord), C.c_int64, C.POINTER(C.c_int64)]
         lib.zett_retok_create.argtypes = [C.POINTER(ZettRetokModel), C.c_int, C.POINTER(C.c_void_p)]
         lib.zett_retok_destroy.argtypes = [C.c_void_p]
         lib.zett_retokenize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

@@ -86,6 +86,7 @@ struct zett_hypernet {
     size_t ev_used = 0;
     std::vector<double> ev_flops;
     std::vector<std::array<int, 4>> ev_shape;   // M, N, K, variant of each timed launch
+    std::vector<zett_gemm_record> gemm_log;     // every GEMM launch of the last forward (zett_get_gemm_log)
     zett_stats stats{};
 };
 
@@ -462,6 +463,13 @@ int zett_get_stats(const zett_hypernet* h, zett_stats* out) {
     return 0;
 }
 
+int zett_get_gemm_log(const zett_hypernet* h, zett_gemm_record* out, int64_t capacity, int64_t* count) {
+    if (!h || !count || capacity < 0 || (capacity > 0 && !out)) return fail(ZETT_E_INVALID, "null argument");
+    *count = (int64_t)h->gemm_log.size();
+    for (int64_t i = 0; i < capacity && i < *count; ++i) out[i] = h->gemm_log[(size_t)i];
+    return 0;
+}
+
 int zett_check_range(zett_hypernet* h, void* stream, int32_t* flags) {
     if (!h) return fail(ZETT_E_INVALID, "null handle");
     ZETT_ON_DEVICE(h->device);
@@ -582,6 +590,17 @@ struct Runner {
         if (e.residual && (e.scale || e.shift)) variant = 1;      // the large tiles compile their residual epilogues without the Rescaler
         if (e.stats_part || e.fold_stats) variant = 7;       // LayerNorm-fold launches exist in gemm4d only (any M)
         if (h->time_gemm && !h->ev_shape.empty()) h->ev_shape.back()[3] = variant;
+        {
+            zett_gemm_record r{};
+            r.m = M; r.n = N; r.k = K; r.variant = variant;
+            r.epilogue = (e.out_lo ? 1 : 0) | ((e.out_f32 || e.out_f32_b) ? 2 : 0) | (e.residual ? 4 : 0) | ((e.scale || e.shift) ? 8 : 0) |
+                         (e.stats_part ? 16 : 0) | (e.fold_stats ? 32 : 0) | (e.act << 8);
+            r.flops = fl;
+            const double mn = (double)M * (double)N;
+            r.bytes = ((double)M + (double)N) * (double)K * sizeof(T) + (e.out_lo ? mn * sizeof(T) : 0.0) + ((e.out_f32 || e.out_f32_b) ? mn * 4.0 : 0.0) +
+                      (e.residual ? mn * 4.0 : 0.0) + (e.stats_part ? (double)M * (N / 128) * 8.0 : 0.0) + ((e.fold_stats || e.res_stats) ? (double)M * 8.0 : 0.0);
+            h->gemm_log.push_back(r);
+        }
         const hipError_t err = launch_gemm_variant(variant, g, st);      // gemm_launch.hip.h: the tile kernels live in their own translation units
         if (h->time_gemm) (void)hipEventRecord(e1, st);
         if (err != hipSuccess) { rc = fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(err)); return; }
@@ -651,6 +670,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     h->ev_used = 0;
     h->ev_flops.clear();
     h->ev_shape.clear();
+    h->gemm_log.clear();
 
     // ---- plan ---------------------------------------------------------------------
     // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] tok_row[T] err[1] scan scratch
@@ -963,6 +983,10 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         }
         h->stats.gemm_ms = ms;
         h->stats.gemm_flops_timed = fl;
+        for (size_t i = 0; i + 1 < h->ev_used && i / 2 < h->gemm_log.size(); i += 2) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]) == hipSuccess) h->gemm_log[i / 2].ms = t;
+        }
         if (getenv("ZETT_GEMM_LOG")) {
             for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
                 float t = 0.f;

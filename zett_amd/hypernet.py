@@ -122,6 +122,15 @@ class HipEngine:
             _lib.check(rc, "zett_check_range")
         return int(flags.value)
 
+    def gemm_log(self) -> list:
+        """Per-launch records of the GEMMs of the most recent forward (zett_get_gemm_log): dicts with m, n, k, variant,
+        epilogue (bit mask, include/zett_hip.h), ms (0 unless the "time_gemm" option is on), flops, bytes."""
+        n = C.c_int64(0)
+        _lib.check(self.lib.zett_get_gemm_log(self.handle, None, 0, C.byref(n)), "zett_get_gemm_log")
+        buf = (_lib.ZettGemmRecord * max(1, n.value))()
+        _lib.check(self.lib.zett_get_gemm_log(self.handle, buf, n.value, C.byref(n)), "zett_get_gemm_log")
+        return [{f: getattr(buf[i], f) for f, _ in _lib.ZettGemmRecord._fields_} for i in range(n.value)]
+
     def stats(self) -> dict:
         s = _lib.ZettStats()
         _lib.check(self.lib.zett_get_stats(self.handle, C.byref(s)))
