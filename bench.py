@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--no-retokenize", action="store_true", help="A/B only: start every step from the id matrix instead of the surface forms")
     ap.add_argument("--chunks", type=int, default=2, help="N > 1: row blocks per step (zett_amd/sharding.py: the all-gather of a block overlaps the next block's forward)")
     ap.add_argument("--serial-allgather", action="store_true", help="N > 1: one block per step, i.e. forward, then all-gather (A/B)")
+    ap.add_argument("--gather-mode", default="allgather", choices=["allgather", "fanout"],
+                    help="N > 1: transport of the row exchange (zett_amd/sharding.py RowGather): RCCL all-gather, or direct fan-out (every rank sends its shard to all peers at once, one xGMI link each)")
+    ap.add_argument("--no-early-gather", action="store_true", help="N > 1, A/B: start the exchange of pred_in / bias behind the whole forward instead of behind their own completion point")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -238,6 +241,7 @@ def main():
     lang_arg = -1 if lang is None else lang
 
     acc = {"gemm_ms": 0.0, "gemm_flops_timed": 0.0, "gemm_launches": 0}
+    exposed = []          # N > 1: per step, how long the compute stream waited for the row exchange after its last forward
     classes = {}          # launch class -> [launches, ms, flops, algorithmic bytes] over the timed steps (zett_get_gemm_log)
 
     def launch_class(r):
@@ -256,7 +260,8 @@ def main():
         return ("16-bit out" if e & 1 else "fp32 out") + act
 
     def step():
-        gather = RowGather(blocks) if world > 1 else None
+        gather = RowGather(blocks, mode=args.gather_mode) if world > 1 else None
+        ready = None if args.no_early_gather else engine.stream_wait_output
         outs = None
         for k, b in enumerate(blocks):
             sfm = ids_blocks[k] if retok is None else retok.run(*texts[k], seq_len)[0]
@@ -269,8 +274,12 @@ def main():
                     c = classes.setdefault(launch_class(r), [0, 0.0, 0.0, 0.0])
                     c[0] += 1; c[1] += r["ms"]; c[2] += r["flops"]; c[3] += r["bytes"]
             if gather is not None:
-                gather.add(b, outs)            # async all-gather of this block; the next block's forward runs meanwhile
-        return outs if gather is None else gather.finish(rows)
+                gather.add(b, outs, ready)     # async exchange of this block (pred_in / bias from their own completion point); the next block's forward runs meanwhile
+        if gather is None:
+            return outs
+        full = gather.finish(rows, timed=True)
+        exposed.append(gather.exposed_ms)
+        return full
 
     gemm_ms = gemm_fl = 0.0
     launches = 0
@@ -286,6 +295,7 @@ def main():
     for key in acc:
         acc[key] = 0
     classes.clear()
+    exposed.clear()
     for _ in range(args.steps):
         out = step()
     gemm_ms, gemm_fl, launches = acc["gemm_ms"], acc["gemm_flops_timed"], acc["gemm_launches"]
@@ -369,6 +379,11 @@ def main():
                                    "frac": (v[2] / (v[1] * 1e-3) / 1e12 / peak) if v[1] > 0 else None,
                                    "algorithmic_gb_per_launch": v[3] / v[0] / 1e9 if v[0] else None}
                                   for k, v in sorted(timed_classes.items(), key=lambda kv: -kv[1][1])]},
+        # N > 1: the part of a step the compute stream spent waiting for the row exchange (HIP events around the waits in
+        # RowGather.finish, this rank); the rest of the exchange ran under forwards
+        "exchange_exposed_ms_per_step": (sum(x for x in exposed if x is not None) / max(len(exposed), 1)) if world > 1 else None,
+        "exchange": None if world == 1 else {"mode": args.gather_mode, "early_start_of_pred_in_and_bias": not args.no_early_gather,
+                                             "bytes_received_per_rank_per_step": int(rows * (world - 1) / world * (dims.n_embd * (2 if dims.separate_out else 1) + 1) * 4)},
         "as_written_tflops": rows * f_ref * args.steps / dt / 1e12,
         "as_written_gflop_per_row": f_ref / 1e9,
     }

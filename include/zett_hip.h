@@ -169,8 +169,20 @@ int zett_get_gemm_log(const zett_hypernet* h, zett_gemm_record* out, int64_t cap
  *     stays asynchronous.  What to do on a hit is the caller's policy: the Python layer (zett_amd/hypernet.py)
  *     re-runs the call with bf16 operands (fp32's exponent range, same MFMA rate) and warns; a hit in BF16 / F32
  *     mode means the outputs are non-finite in the reference's own arithmetic too (non-finite inputs or weights).
+ *     With zett_set_option("range_accumulate", 1) zett_forward no longer clears the word and zett_check_range clears it
+ *     after reading: several asynchronous forwards, one question at the end (zett_amd/sharding.py, the CLI under torchrun).
  * The reference has no counterpart: its bf16 / fp32 arithmetic cannot leave the range short of inf in fp32. */
 int zett_check_range(zett_hypernet* h, void* stream, int32_t* flags);
+
+/* Completion of individual outputs inside a forward, for callers that start moving an output while the rest of the
+ * forward still runs (the vocabulary-sharded path starts the all-gather of pred_in under the second head's GEMMs:
+ * zett_amd/sharding.py).  zett_forward records an event on its stream when out_bias is complete (after the position-0
+ * readout of the last encoder chunk) and when out_in is complete (after the first head's final GEMM of the last chunk);
+ * out_out is complete when the forward is, i.e. in stream order.  zett_stream_wait_output makes `stream` (another
+ * hipStream_t) wait for that point of the MOST RECENT zett_forward on the handle; it returns at once on the host.
+ * The reference has no counterpart (its outputs appear together when XLA's executable returns). */
+enum zett_output { ZETT_OUT_IN = 0, ZETT_OUT_BIAS = 1 };
+int zett_stream_wait_output(zett_hypernet* h, int which, void* stream);
 
 /* Upper bound of the device bytes zett_forward reserves (and keeps until zett_destroy)
  * for a [n_rows, seq] batch at the current options: the plan's worst case, no pad

@@ -264,6 +264,25 @@ for chunks in (1, 2, 3):
 from zett_amd.sharding import plan_blocks
 blocks = plan_blocks(40003, world, rank, 3)
 ok = ok and len(blocks) == 3 and all(b.rows == world * b.per for b in blocks[:-1]) and sum(b.rows for b in blocks) == 40003
+# the direct fan-out transport (every rank sends its shard to all peers at once) puts the same bytes in the same places,
+# with and without a second output and with rows that do not divide by the world size
+def fake2(rows):
+    x = rows.float(); e = torch.arange(1, 5, dtype=torch.float32)
+    return x.sum(1, keepdim=True) * e, (x.sum(1, keepdim=True) - 3) * e, x[:, 0].clone()
+for chunks in (1, 3):
+    for fn in (fake, fake2):
+        f_fan = predict_sharded(fn, big, chunks=chunks, mode="fanout"); f_one = fn(big)
+        ok = ok and all((a is None and b is None) or torch.equal(a, b) for a, b in zip(f_fan, f_one))
+f_fan = predict_sharded(fake2, torch.from_numpy(ids), mode="fanout"); f_one = fake2(torch.from_numpy(ids))
+ok = ok and all(torch.equal(a, b) for a, b in zip(f_fan, f_one))
+# the early-start hook is only taken for device tensors: on CPU tensors it must be ignored, not called
+called = []
+f_hook = predict_sharded(fake2, big, chunks=2, ready=lambda name, stream: called.append(name))
+ok = ok and not called and all(torch.equal(a, b) for a, b in zip(f_hook, fake2(big)))
+try:
+    predict_sharded(fake, big, mode="ring"); ok = False
+except ValueError:
+    pass
 shapes = [tuple(t.shape) for t in full]
 if rank == 0:
     json.dump({{"ok": ok, "shapes": shapes}}, open({out!r}, "w"))

@@ -165,6 +165,42 @@ def test_long_rows_pair_lever_bit_identical_and_vs_oracle():
         eng.close()
 
 
+def test_output_completion_events():
+    """zett_stream_wait_output: pred_in is final after the first head's last GEMM and bias after the position-0 readout —
+    a side stream that waits for those points (and for nothing else) reads the final values while the second head still
+    runs.  What the vocabulary-sharded path starts its exchange behind (zett_amd/sharding.py RowGather)."""
+    cfg, _, src_dtype, hist = synth.workload("tinyllama_neox")
+    eng = _engine(cfg, 6, "f16")
+    side = torch.cuda.Stream()
+    with pytest.raises(RuntimeError):
+        eng.stream_wait_output("in", side)                     # no forward has run on the handle yet
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 6, dtype=src_dtype)).cuda()
+    ids = torch.from_numpy(synth.make_surface_forms(cfg, 9000, seed=6, hist=hist, n_special=1)).cuda()
+    ref = _run(eng, ids, src)
+    for it in range(3):
+        out = eng.forward(ids, src, -1)                        # asynchronous: nothing has been waited for
+        eng.stream_wait_output("bias", side)
+        eng.stream_wait_output("in", side)
+        with torch.cuda.stream(side):
+            early_in, early_bias = out[0].clone(), out[2].clone()
+        side.synchronize()
+        assert torch.equal(early_in, ref[0]) and torch.equal(early_bias, ref[2]), it
+        torch.cuda.synchronize()
+        assert _eq(out, ref)
+    # chunked forward: the points are those of the LAST chunk
+    eng.set_option("max_chunk_tokens", 4096)
+    out = eng.forward(ids, src, -1)
+    eng.stream_wait_output("in", side)
+    with torch.cuda.stream(side):
+        early_in = out[0].clone()
+    side.synchronize()
+    assert eng.stats()["chunks"] >= 3 and torch.equal(early_in, ref[0])
+    # an empty call completes at once
+    eng.forward(ids[:0], src, -1)
+    eng.stream_wait_output("in", side)
+    side.synchronize()
+
+
 def test_pad_content_independence():
     """Changing the pad token's source embedding must change nothing for rows with a visible key."""
     cfg, *_ = synth.workload("tiny")

@@ -4,8 +4,9 @@ tests/test_host_logic.py and, with two ranks sharing one device, by tests/test_b
 
   * bench.py --gpus 2 under torch.distributed.run, nccl: one JSON line, the gathered rows equal a local forward bit
     for bit (bench.py checks that itself and exits non-zero otherwise);
-  * predict_sharded on two GPUs: the all-gathered matrices equal a single-GPU forward of the whole vocabulary bit for bit,
-    for one and for several row blocks per rank.
+  * predict_sharded on two GPUs: the gathered matrices equal a single-GPU forward of the whole vocabulary bit for bit,
+    for one and for several row blocks per rank, over both transports (RCCL all-gather, direct fan-out) and with the
+    exchange of pred_in / bias started behind their own completion point (zett_stream_wait_output) or behind the forward.
 """
 import json
 import os
@@ -31,7 +32,9 @@ def _torchrun(script_args, port, timeout=900):
 
 
 @needs_two_gpus
-@pytest.mark.parametrize("extra", [[], ["--serial-allgather"], ["--chunks", "3"]], ids=["two-blocks", "serial", "three-blocks"])
+@pytest.mark.parametrize("extra", [[], ["--serial-allgather"], ["--chunks", "3"], ["--gather-mode", "fanout"], ["--serial-allgather", "--gather-mode", "fanout"],
+                                   ["--serial-allgather", "--no-early-gather"]],
+                         ids=["two-blocks", "serial", "three-blocks", "fanout", "serial-fanout", "serial-late"])
 def test_bench_two_gpus_nccl(extra):
     out = _torchrun([os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "tinyllama_neox",
                      "--rows", "30001", "--no-cpu-baseline"] + extra, 29541)
@@ -40,6 +43,7 @@ def test_bench_two_gpus_nccl(extra):
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rows"] == 30001 and d["value"] > 0 and "TEST HOOK" not in d["data"]
+    assert d["exchange"]["mode"] == ("fanout" if "fanout" in extra else "allgather") and d["exchange_exposed_ms_per_step"] is not None
 
 
 _WORKER = r"""
@@ -64,9 +68,11 @@ predict = lambda rows: eng.forward(rows, src, -1)
 single = predict(ids)
 ok = True
 for chunks in (1, 2, 4):
-    full = predict_sharded(predict, ids, chunks=chunks)
-    torch.cuda.synchronize()
-    ok = ok and all((a is None and b is None) or torch.equal(a, b) for a, b in zip(full, single))
+    for mode in ("allgather", "fanout"):
+        for ready in (None, eng.stream_wait_output):      # exchange behind the whole forward / pred_in and bias behind their own completion point
+            full = predict_sharded(predict, ids, chunks=chunks, mode=mode, ready=ready)
+            torch.cuda.synchronize()
+            ok = ok and all((a is None and b is None) or torch.equal(a, b) for a, b in zip(full, single))
 flag = torch.tensor([1 if ok else 0], device=dev)
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 if rank == 0:

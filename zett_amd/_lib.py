@@ -17,11 +17,13 @@ RANGE_SOURCE, RANGE_ACTIVATION, RANGE_OUTPUT, RANGE_WEIGHT = 1, 2, 4, 8      # z
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
 RETOK_BPE, RETOK_UNIGRAM = 0, 1
+OUT_IN, OUT_BIAS = 0, 1              # zett_output
 
 ABI_SYMBOLS = (
     "zett_last_error", "zett_abi_version", "zett_create", "zett_destroy", "zett_load_weight",
     "zett_finalize", "zett_forward", "zett_get_stats", "zett_workspace_bytes", "zett_set_option",
     "zett_retok_create", "zett_retok_destroy", "zett_retokenize", "zett_check_range", "zett_get_gemm_log",
+    "zett_stream_wait_output",
 )
 
 
@@ -94,6 +96,7 @@ def load():
         lib.zett_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         lib.zett_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.zett_check_range.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+        lib.zett_stream_wait_output.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.zett_get_gemm_log.argtypes = [C.c_void_p, C.POINTER(ZettGemmRecord), C.c_int64, C.POINTER(C.c_int64)]
         lib.zett_retok_create.argtypes = [C.POINTER(ZettRetokModel), C.c_int, C.POINTER(C.c_void_p)]
         lib.zett_retok_destroy.argtypes = [C.c_void_p]

@@ -78,6 +78,10 @@ struct zett_hypernet {
                                       // 7 = 256x256 four-wave direct-to-LDS, 8 = as 7 with the generic epilogue drain
     // workspace
     DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct, lnstats, lnparts;
+    hipEvent_t out_ready[2] = {nullptr, nullptr};      // zett_stream_wait_output: out_in / out_bias of the last forward complete
+    bool out_recorded = false;
+    int range_accumulate = 0;         // 1: zett_forward does not clear the range word, zett_check_range clears it after reading (a caller
+                                      // that runs several asynchronous forwards and asks once at the end: zett_amd/sharding.py)
     int32_t* range_word = nullptr;    // device: zett_range_bits of the forward in flight (cleared when a forward starts)
     int32_t* range_host = nullptr;    // pinned: where zett_check_range / zett_finalize read it
     int32_t* host_pinned = nullptr;
@@ -262,6 +266,7 @@ int zett_destroy(zett_hypernet* h) {
     if (h->host_pinned) (void)hipHostFree(h->host_pinned);
     if (h->range_word) (void)hipFree(h->range_word);
     if (h->range_host) (void)hipHostFree(h->range_host);
+    for (hipEvent_t e : h->out_ready) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
     return 0;
@@ -434,6 +439,8 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "gemm4d_min_k") {
         if (value < 64) return fail(ZETT_E_INVALID, "gemm4d_min_k must be >= 64");
         h->gemm4d_min_k = (int)value;
+    } else if (k == "range_accumulate") {
+        h->range_accumulate = value != 0;
     } else if (k == "gemm_variant") {
         if (value != 0 && value != 1 && value != 2 && value != 3 && value != 7 && value != 8)
             return fail(ZETT_E_INVALID, "gemm_variant must be 0 (auto), 1 (128x128), 2 (256x256 register-staged), 3 (384x256), 7 (256x256 four-wave direct-to-LDS) or 8 (7 with the generic epilogue drain)");
@@ -463,6 +470,15 @@ int zett_get_stats(const zett_hypernet* h, zett_stats* out) {
     return 0;
 }
 
+int zett_stream_wait_output(zett_hypernet* h, int which, void* stream) {
+    if (!h) return fail(ZETT_E_INVALID, "null handle");
+    if (which != ZETT_OUT_IN && which != ZETT_OUT_BIAS) return fail(ZETT_E_INVALID, "which must be ZETT_OUT_IN or ZETT_OUT_BIAS");
+    if (!h->out_recorded) return fail(ZETT_E_STATE, "no forward has run on this handle");
+    ZETT_ON_DEVICE(h->device);
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->out_ready[which], 0));
+    return 0;
+}
+
 int zett_get_gemm_log(const zett_hypernet* h, zett_gemm_record* out, int64_t capacity, int64_t* count) {
     if (!h || !count || capacity < 0 || (capacity > 0 && !out)) return fail(ZETT_E_INVALID, "null argument");
     *count = (int64_t)h->gemm_log.size();
@@ -477,6 +493,7 @@ int zett_check_range(zett_hypernet* h, void* stream, int32_t* flags) {
     HIP_TRY(hipMemcpyAsync(h->range_host, h->range_word, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const int32_t w = h->range_host[0];
+    if (h->range_accumulate && w) HIP_TRY(hipMemsetAsync(h->range_word, 0, 4, st));
     if (flags) *flags = w;
     if (!w) return 0;
     return fail(ZETT_E_RANGE, "the last forward left the range of its arithmetic:%s%s%s (precision %s)",
@@ -497,7 +514,12 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
     if (n_rows == 0) {
         h->stats = zett_stats{};
         ZETT_ON_DEVICE(h->device);
-        HIP_TRY(hipMemsetAsync(h->range_word, 0, 4, (hipStream_t)stream));
+        if (!h->range_accumulate) HIP_TRY(hipMemsetAsync(h->range_word, 0, 4, (hipStream_t)stream));
+        for (hipEvent_t& e : h->out_ready) {
+            if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(e, (hipStream_t)stream));
+        }
+        h->out_recorded = true;
         return 0;
     }
     if (!surface_forms || !source_embeddings || !out_in || !out_bias) return fail(ZETT_E_INVALID, "null tensor argument");
@@ -705,7 +727,9 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     p.tok_key = p.row_uniform + N;
     HIP_TRY(hipMemsetAsync(p.id_flag, 0, (size_t)V * 4, st));
     HIP_TRY(hipMemsetAsync(p.err, 0, 4, st));
-    HIP_TRY(hipMemsetAsync(h->range_word, 0, 4, st));          // range guard: the word of THIS forward (zett_check_range)
+    if (!h->range_accumulate) HIP_TRY(hipMemsetAsync(h->range_word, 0, 4, st));          // range guard: the word of THIS forward (zett_check_range)
+    for (hipEvent_t& e : h->out_ready)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (pair_plan) HIP_TRY(hipMemsetAsync(p.pair_flag, 0, (size_t)PK * 4, st));
     const int rb = (int)((N + 255) / 256);
     hipLaunchKernelGGL(plan_rows_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
@@ -948,6 +972,8 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                     LnReadout{c.predict_bias ? R.Wf("bias_projection.weight") : (const float*)nullptr,
                               c.predict_bias ? R.Wf("bias_projection.bias") : (const float*)nullptr, out_bias + r0});
         R.check("readout");
+        const bool last_chunk = r1 == N;
+        if (last_chunk && !R.rc) HIP_TRY(hipEventRecord(h->out_ready[ZETT_OUT_BIAS], st));      // out_bias complete (zett_stream_wait_output)
 
         // output heads (modeling_hypernet.py:236-258)
         {
@@ -960,6 +986,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             const int width = c.single_head ? EIN : E;
             if (c.single_head && c.separate_out) { e.split_col = E; e.out_f32_b = out_out + (size_t)r0 * E; }
             R.gemm(CTX, H, R.Wlo("output_projection.1.weight"), H, rows, width, H, e);
+            if (last_chunk && !R.rc) HIP_TRY(hipEventRecord(h->out_ready[ZETT_OUT_IN], st));     // out_in complete: the second head runs behind it
         }
         if (c.separate_out && !c.single_head) {
             R.projector("output_projection_out.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX);
@@ -973,6 +1000,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         r0 = r1;
     }
     if (R.rc) return R.rc;
+    h->out_recorded = true;
 
     if (h->time_gemm) {
         HIP_TRY(hipStreamSynchronize(st));

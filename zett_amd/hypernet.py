@@ -122,6 +122,13 @@ class HipEngine:
             _lib.check(rc, "zett_check_range")
         return int(flags.value)
 
+    def stream_wait_output(self, which: str, stream: "torch.cuda.Stream") -> None:
+        """Make `stream` wait until output `which` ("in" = pred_in, "bias") of the most recent forward is complete
+        (zett_stream_wait_output): pred_in is final after the first head's last GEMM, while the second head still
+        computes — the vocabulary-sharded path starts its all-gather there (zett_amd/sharding.py)."""
+        code = {"in": _lib.OUT_IN, "bias": _lib.OUT_BIAS}[which]
+        _lib.check(self.lib.zett_stream_wait_output(self.handle, code, C.c_void_p(stream.cuda_stream)), "zett_stream_wait_output")
+
     def gemm_log(self) -> list:
         """Per-launch records of the GEMMs of the most recent forward (zett_get_gemm_log): dicts with m, n, k, variant,
         epilogue (bit mask, include/zett_hip.h), ms (0 unless the "time_gemm" option is on), flops, bytes."""

@@ -12,7 +12,10 @@ vocabulary is ~10 ms of compute per rank against ~0.94 GB received per rank.  A 
 no "next step" to hide the exchange under.  Instead the vocabulary is cut into `chunks` row blocks (multiples of the
 world size), each block is sharded over the ranks, and the all-gather of block k runs on RCCL's stream while the
 forward of block k + 1 computes; block k is gathered straight into its place of the final matrix (rank shards of one
-block are adjacent rows), so no re-assembly copy follows.  Only the last block's exchange is exposed.
+block are adjacent rows), so no re-assembly copy follows.  Only the last block's exchange is exposed — and of that, only
+pred_out's: pred_in and bias leave as soon as the first output head has written them, under the second head's GEMMs
+(RowGather, "early start").  Two interchangeable transports: RCCL's all-gather, and a direct fan-out in which every rank
+sends its shard to its seven peers at once, one xGMI link each (RowGather, mode "fanout").
 """
 from __future__ import annotations
 
@@ -68,40 +71,103 @@ def padded_rows(blocks: Sequence[Block], world: int) -> int:
     return sum(b.per * world for b in blocks)
 
 
-class RowGather:
-    """Asynchronous all-gather of row blocks into full matrices.  `add(block, tensors)` pads this rank's shard of the
-    block to its nominal height and starts one all_gather_into_tensor per tensor into rows [block.start, block.start +
-    world * block.per) of the corresponding full buffer; `finish(n_rows)` waits for everything and returns the full
-    tensors cut to n_rows.  Blocks must be added in order; every block but the last has rows == world * per, so the
-    shards of a block are adjacent rows of the final matrix and nothing has to be re-assembled."""
+GATHER_MODES = ("allgather", "fanout")
 
-    def __init__(self, blocks: Sequence[Block], group=None):
+
+class RowGather:
+    """Asynchronous reassembly of row blocks into full matrices on every rank.
+
+    `add(block, tensors, ready=None)` pads this rank's shard of the block to its nominal height and starts, per tensor, the
+    exchange that puts the block's rows [block.start, block.start + world * block.per) of the full buffer on every rank;
+    `finish(n_rows)` waits for everything and returns the full tensors cut to n_rows.  Blocks must be added in order; every
+    block but the last has rows == world * per, so the shards of a block are adjacent rows of the final matrix and nothing
+    has to be re-assembled.
+
+    mode "allgather": one `all_gather_into_tensor` per tensor (RCCL picks the algorithm; on xGMI a ring is bound by ONE of
+        the seven links: 7 steps x shard / 153 GB/s).
+    mode "fanout": every rank sends its shard straight into its rows of every peer's buffer (batched isend / irecv: RCCL
+        runs the seven transfers of a rank concurrently, one per xGMI link: shard / 153 GB/s, a seventh of the ring's time);
+        the rank's own rows are a local copy.  Same bytes in the same places: the two modes are interchangeable, the tests
+        demand identical results.
+
+    Early start.  `tensors` = (pred_in, pred_out | None, bias) of ONE forward.  pred_in and bias are final long before the
+    forward ends (the second output head still runs three GEMMs).  With `ready(name, stream)` — a callable that makes
+    `stream` wait until output `name` ("in" / "bias") of that forward is complete (HipEngine.stream_wait_output) — their
+    exchange is issued on a side stream behind that point instead of behind the whole forward; pred_out follows in stream
+    order.  This is what hides half of the exchange when a rank has ONE block (8 GPUs on the headline vocabulary)."""
+
+    def __init__(self, blocks: Sequence[Block], group=None, mode: str = "allgather"):
+        if mode not in GATHER_MODES:
+            raise ValueError(f"gather mode must be one of {GATHER_MODES}")
         self.blocks = list(blocks)
         self.group = group
+        self.mode = mode
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         self.total = padded_rows(self.blocks, self.world)
         self.full: Optional[List[Optional[torch.Tensor]]] = None
         self._works = []
         self._keep = []
+        self._side: Optional[torch.cuda.Stream] = None
+        self.exposed_ms: Optional[float] = None        # set by finish(timed=True): how long the compute stream waited for the exchange
 
-    def add(self, block: Block, tensors: Sequence[Optional[torch.Tensor]]) -> None:
+    def _exchange(self, block: Block, t: torch.Tensor, full: torch.Tensor) -> None:
+        t = t[: block.hi - block.lo]
+        if t.shape[0] != block.per:                  # short shard (end of the vocabulary, or a surplus rank): pad
+            pad = torch.zeros((block.per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            t = torch.cat([t, pad], dim=0)
+        t = t.contiguous()
+        dst = full[block.start: block.start + self.world * block.per]
+        if self.mode == "allgather":
+            self._works.append(dist.all_gather_into_tensor(dst, t, group=self.group, async_op=True))
+        else:
+            ranks = list(range(self.world))
+            to_global = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
+            ops = []
+            for peer in ranks:
+                if peer == self.rank:
+                    continue
+                ops.append(dist.P2POp(dist.isend, t, to_global(peer), self.group))
+                ops.append(dist.P2POp(dist.irecv, dst[peer * block.per: (peer + 1) * block.per], to_global(peer), self.group))
+            dst[self.rank * block.per: (self.rank + 1) * block.per].copy_(t)
+            if ops:
+                self._works.extend(dist.batch_isend_irecv(ops))
+        self._keep.append(t)
+
+    def add(self, block: Block, tensors: Sequence[Optional[torch.Tensor]], ready: Optional[Callable] = None) -> None:
         if self.full is None:
             self.full = [None if t is None else torch.empty((self.total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in tensors]
-        for t, full in zip(tensors, self.full):
-            if t is None:
+        early = ()
+        first = next(t for t in tensors if t is not None)
+        if ready is not None and first.is_cuda and len(tensors) == 3 and tensors[1] is not None:
+            # pred_in and bias leave behind their own completion point, on a side stream; pred_out in stream order
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=first.device)
+            ready("bias", self._side)
+            ready("in", self._side)
+            with torch.cuda.stream(self._side):
+                for i in (0, 2):
+                    self._exchange(block, tensors[i], self.full[i])
+                    tensors[i].record_stream(self._side)
+            early = (0, 2)
+        for i, (t, full) in enumerate(zip(tensors, self.full)):
+            if t is None or i in early:
                 continue
-            t = t[: block.hi - block.lo]
-            if t.shape[0] != block.per:                  # short shard (end of the vocabulary, or a surplus rank): pad
-                pad = torch.zeros((block.per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-                t = torch.cat([t, pad], dim=0)
-            t = t.contiguous()
-            dst = full[block.start: block.start + self.world * block.per]
-            self._works.append(dist.all_gather_into_tensor(dst, t, group=self.group, async_op=True))
-            self._keep.append(t)
+            self._exchange(block, t, full)
 
-    def finish(self, n_rows: int):
+    def finish(self, n_rows: int, timed: bool = False):
+        ev0 = ev1 = None
+        if timed and self.full is not None and any(f is not None and f.is_cuda for f in self.full):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for w in self._works:
             w.wait()           # the compute stream waits for the collective; the host does not block (nccl)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        if ev1 is not None:
+            ev1.record()
+            ev1.synchronize()
+            self.exposed_ms = float(ev0.elapsed_time(ev1))
         self._works.clear()
         self._keep.clear()
         assert self.full is not None
@@ -120,13 +186,15 @@ def all_gather_rows(local: torch.Tensor, n_rows: int, per: int, group=None) -> t
     return full[:n_rows]
 
 
-def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group=None, chunks: int = 2):
+def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group=None, chunks: int = 2,
+                    ready: Optional[Callable] = None, mode: str = "allgather"):
     """Run `predict(rows) -> (pred_in, pred_out | None, bias)` on this rank's rows and return the full result on every
-    rank.  The vocabulary is processed in `chunks` row blocks whose all-gathers overlap the next block's forward (module
-    docstring); chunks = 1 is the plain shard-then-gather.
+    rank.  The vocabulary is processed in `chunks` row blocks whose exchange overlaps the next block's forward (module
+    docstring); chunks = 1 is the plain shard-then-gather.  `ready` (RowGather: early start of pred_in / bias) and `mode`
+    ("allgather" | "fanout") are handed to the RowGather.
 
-    `predict` is typically ``lambda rows: hypernet(rows, source_embeddings=..., lang_index=...)``.
-    Without an initialised process group this is just ``predict(target_surface_forms)``.
+    `predict` is typically ``lambda rows: engine.forward(rows, source_embeddings, lang)`` with
+    ``ready=engine.stream_wait_output``.  Without an initialised process group this is just ``predict(target_surface_forms)``.
     """
     if not (dist.is_available() and dist.is_initialized()):
         return predict(target_surface_forms)
@@ -135,7 +203,7 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
     blocks = plan_blocks(n, world, rank, chunks)
     if not blocks:
         return predict(target_surface_forms)
-    gather = RowGather(blocks, group)
+    gather = RowGather(blocks, group, mode)
     for b in blocks:
         rows = target_surface_forms[b.lo:b.hi]
         if b.hi - b.lo == 0:                           # more ranks than rows in the block: compute one dummy row, contribute none
@@ -143,5 +211,5 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
         outs = predict(rows)
         if b.hi - b.lo == 0:
             outs = tuple(None if t is None else t[:0] for t in outs)
-        gather.add(b, outs)
+        gather.add(b, outs, ready)
     return gather.finish(n)

@@ -146,13 +146,56 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
     # shards every batch over its local devices (scripts/transfer.py:90-91, zett/utils.py:26).  All ranks then hold the
     # whole result; they must walk the SAME batches, so the batch order comes from one seed, broadcast from rank 0.
     predict = predict_local
-    if _world_size() > 1:
+    sharded = _world_size() > 1 and hasattr(hypernet, "engine")
+    if _world_size() > 1 and not sharded:              # (a stand-in model without an engine: plain sharding)
         from zett_amd.sharding import predict_sharded
 
         def predict(rows):
             return predict_sharded(predict_local, rows)
 
         rng = _shared_rng(rng, target_surface_form_matrix.device)
+    elif sharded:
+        # One process per GPU: the forwards stay ASYNCHRONOUS (the class's per-call range check would synchronise the host
+        # after every shard and take the early exchange of pred_in with it): the range word accumulates over the whole
+        # vocabulary and all ranks ask once at the end — together, so that a fallback to bf16 is every rank's or none's.
+        from zett_amd.sharding import predict_sharded
+        device = source_embeddings.device
+        if hypernet.dims.embed_lang and lang_index is None:
+            raise ValueError("this hypernetwork embeds a language id: lang_index is required")
+        lang = int(lang_index) if hypernet.dims.embed_lang else -1
+        rng = _shared_rng(rng, target_surface_form_matrix.device)
+        state = {"rng_state": rng.bit_generator.state}
+
+        def run_with(precision):
+            eng = hypernet.engine(device, precision)
+            eng.set_option("range_accumulate", 1)
+            eng.range_flags()                           # (clears whatever an earlier call left)
+
+            def predict_rows(rows):
+                return predict_sharded(lambda r: eng.forward(r.to(device), source_embeddings, lang), rows, ready=eng.stream_wait_output)
+
+            if not args.do_batching:
+                out = predict_rows(target_surface_form_matrix)
+            else:
+                gen = np.random.default_rng()
+                gen.bit_generator.state = state["rng_state"]        # the same batch order on a repeat
+                out = batched_inference(predict_rows, target_surface_form_matrix, hypernet.config.n_embd, args.batch_size,
+                                        args.sample_batches, target_priors, args.min_k, args.n_samples, gen)
+            flags = torch.tensor([eng.range_flags()], dtype=torch.int32, device=device)
+            import torch.distributed as dist
+            dist.all_reduce(flags, op=dist.ReduceOp.BOR if hasattr(dist.ReduceOp, "BOR") else dist.ReduceOp.MAX)
+            eng.set_option("range_accumulate", 0)
+            return out, int(flags.item())
+
+        import warnings
+        out, flags = run_with(hypernet.precision)
+        if flags and hypernet.precision in ("f16", "fp16", "float16") and getattr(hypernet, "range_guard", True):
+            warnings.warn("zett_amd: the f16 forward left the half range on some rank; repeating the prediction with bf16 operands on every rank")
+            hypernet.precision = "bf16"
+            out, flags = run_with("bf16")
+        if flags:
+            warnings.warn(f"zett_amd: non-finite predicted embeddings in {hypernet.precision} arithmetic; returned as computed")
+        return out
 
     if not args.do_batching:   # scripts/transfer.py:243-262 pads to a multiple of 128 for XLA; no need here
         return predict(target_surface_form_matrix)
