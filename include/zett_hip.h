@@ -253,6 +253,51 @@ int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* of
                     int64_t n_tokens, int32_t maxlen, int32_t pad_id, int32_t* out,
                     int64_t* n_truncated, int64_t* bad_token, void* stream);
 
+/* ---- training use of the forward ---------------------------------------------------------
+ * Replaces: the hypernetwork forward inside the loss of the reference's train_step / eval_step (train.py:1007-1013,
+ * 1191-1197: state.apply_fn({"params": params["hypernet"]}, target_surface_forms, target_priors, source_embeddings,
+ * lang_index) under jax.value_and_grad) — i.e. the same forward, differentiable with respect to every hypernetwork
+ * parameter.  First slice: fp32 arithmetic in the reference's as-written dense [N, L', H] layout.  The primitives below
+ * are what zett_amd/autograd.py (a torch.autograd.Function: torch holds the tensors and the tape, nothing else) builds
+ * the forward that keeps its activations and the backward from.  All pointers are device pointers, fp32, row-major;
+ * `stream` is a hipStream_t.  Dense contractions — forward, dgrad, wgrad — are ONE entry point on the library's TN
+ * GEMM family (fp32 MFMA): dgrad is the same contraction against the transposed weight, wgrad the same contraction of
+ * the two transposed activations (zett_op_transpose_f32 zero-pads the row count to the 32-wide K step). */
+/* out[m, n] = act(a[m, :] . w[n, :] + bias[n]) + residual[m, n]   (bias, residual nullable; act: 0 none, 1 tanh-GELU, 2 erf-GELU;
+ * k % 32 == 0, lda / ldw % 4 == 0) */
+int zett_op_gemm_f32(const float* a, int32_t lda, const float* w, int32_t ldw, int64_t m, int32_t n, int32_t k, const float* bias, int32_t act,
+                     const float* residual, int32_t ld_res, float* out, int32_t ld_out, void* stream);
+/* out[c, r] = in[r, c] (r < rows), 0 for rows <= r < rows_padded */
+int zett_op_transpose_f32(const float* in, int32_t ld_in, float* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream);
+/* out[c] (+)= sum_r in[r, c] */
+int zett_op_colsum_f32(const float* in, int32_t ld, int64_t rows, int32_t cols, float* out, int32_t accumulate, void* stream);
+/* op 0: a + b; 1: a * b; 2: a * vec[col] + vec2[col] (vec NULL: 1, vec2 NULL: 0); 3: a + s[row] * vec[col]; 4: a * s[row] (a NULL: s[row] * vec[col]) */
+int zett_op_elementwise_f32(int32_t op, const float* a, const float* b, const float* vec, const float* vec2, const float* s, float* out,
+                            int64_t n, int32_t cols, void* stream);
+/* out[r] = a[r, :] . w + b[0] (b nullable) */
+int zett_op_rowdot_f32(const float* a, int32_t ld, const float* w, const float* b, float* out, int64_t rows, int32_t cols, void* stream);
+/* y = LayerNorm(x) (two-pass variance); stats[r] = (mean, rstd) */
+int zett_op_layernorm_fwd_f32(const float* x, int32_t ld, const float* gamma, const float* beta, float eps, float* y, float* stats,
+                              int64_t rows, int32_t h, void* stream);
+/* dx, and dyxhat = dy * xhat (dgamma = its column sum, dbeta = the column sum of dy) */
+int zett_op_layernorm_bwd_f32(const float* dy, const float* x, int32_t ld, const float* stats, const float* gamma, float* dx, float* dyxhat,
+                              int64_t rows, int32_t h, void* stream);
+/* kind 1: F.gelu(approximate="tanh") (modeling_hypernet.py:36-39), 2: erf form (RobertaIntermediate) */
+int zett_op_gelu_fwd_f32(const float* z, float* h, int64_t n, int32_t kind, void* stream);
+int zett_op_gelu_bwd_f32(const float* z, const float* dh, float* dz, int64_t n, int32_t kind, void* stream);
+/* softmax(q k^T / sqrt(d) + finfo.min * !mask) v per row and head over seq <= 32 positions (eager semantics: a row whose
+ * keys are all masked attends uniformly); q, k, v: [n_rows * seq, ld]; probs [n_rows, heads, seq, seq] is kept for the backward */
+int zett_op_attention_fwd_f32(const float* q, const float* k, const float* v, int32_t ld, const uint8_t* mask, int64_t n_rows, int32_t seq,
+                              int32_t heads, int32_t head_dim, float* ctx, int32_t ld_ctx, float* probs, void* stream);
+int zett_op_attention_bwd_f32(const float* dctx, int32_t ld_ctx, const float* q, const float* k, const float* v, int32_t ld, const float* probs,
+                              int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, float* dq, float* dk, float* dv, int32_t ld_d, void* stream);
+/* A2 + A3 (modeling_hypernet.py:170-188) per position, and its backward: dfallback accumulated in place (zero it first),
+ * prod = dx * source row and keep = dx on source rows (0 on fallback rows): their column sums are d in_scaler.w / d in_scaler.b */
+int zett_op_gather_fwd_f32(const int32_t* ids, int64_t n_tokens, const void* src, int32_t src_dtype, int32_t e_in, int32_t v0, const float* fallback,
+                           const float* sw, const float* sb, float* x, void* stream);
+int zett_op_gather_bwd_f32(const int32_t* ids, int64_t n_tokens, const void* src, int32_t src_dtype, int32_t e_in, int32_t v0, const float* dx,
+                           float* dfallback, float* prod, float* keep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,218 @@
+"""Training use of the forward (reference: train.py:1007-1013, 1191-1197): zett_amd/autograd.py on
+the GPU against torch.autograd of a float64 torch restatement of the oracle (tests/torch_port.py, itself checked against
+oracle/hypernet_ref.py here).  Primitives one by one, then the whole hypernetwork: outputs, the gradient of every
+parameter, all flag combinations of the tiny shape, and the drop-in class with requires_grad parameters."""
+import numpy as np
+import pytest
+import torch
+
+from tests import torch_port, util
+from zett_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _ops():
+    from zett_amd.autograd import Ops
+    return Ops(torch.device(DEV))
+
+
+def test_gemm_and_linear_backward_match_torch():
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for m, n, k in ((37, 64, 96), (300, 384, 128), (1000, 256, 256), (5, 128, 32)):
+        x = torch.randn(m, k, device=DEV, generator=g)
+        w = torch.randn(n, k, device=DEV, generator=g) * 0.1
+        b = torch.randn(n, device=DEV, generator=g)
+        r = torch.randn(m, n, device=DEV, generator=g)
+        y = ops.gemm(x, w, b, residual=r)
+        assert _rel(y, x.double() @ w.double().T + b.double() + r.double()) < 2e-6
+        dy = torch.randn(m, n, device=DEV, generator=g)
+        dx, dw, db = ops.linear_bwd(dy, x, w)
+        assert _rel(dx, dy.double() @ w.double()) < 2e-6 and _rel(dw, dy.double().T @ x.double()) < 2e-6 and _rel(db, dy.double().sum(0)) < 2e-6
+    with pytest.raises(ValueError):
+        ops.gemm(torch.randn(4, 20, device=DEV), torch.randn(8, 20, device=DEV))         # contraction width not a multiple of 32
+
+
+def test_layernorm_gelu_rowops_match_torch():
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = (torch.randn(77, 384, device=DEV, generator=g) * 3 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(384, device=DEV, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(384, device=DEV, generator=g)).requires_grad_(True)
+    dy = torch.randn(77, 384, device=DEV, generator=g)
+    y, st = ops.layernorm(x.detach(), gamma.detach(), beta.detach(), 1e-5)
+    ref = torch.nn.functional.layer_norm(x.double(), (384,), gamma.double(), beta.double(), 1e-5)
+    assert _rel(y, ref) < 1e-6
+    ref.backward(dy.double())
+    dx, dg, db = ops.layernorm_bwd(dy, x.detach(), st, gamma.detach())
+    assert _rel(dx, x.grad) < 2e-5 and _rel(dg, gamma.grad) < 1e-5 and _rel(db, beta.grad) < 1e-5
+    for kind, approx in ((1, "tanh"), (2, "none")):
+        z = (torch.randn(5000, device=DEV, generator=g) * 2.5).requires_grad_(True)
+        dh = torch.randn(5000, device=DEV, generator=g)
+        h = ops.gelu(z.detach(), kind)
+        ref = torch.nn.functional.gelu(z.double(), approximate=approx)
+        assert float((h.double() - ref).abs().max()) < 1e-6
+        ref.backward(dh.double())
+        assert float((ops.gelu_bwd(z.detach(), dh, kind).double() - z.grad.double()).abs().max()) < 2e-6
+    a = torch.randn(50, 64, device=DEV, generator=g)
+    assert _rel(ops.colsum(a), a.double().sum(0)) < 1e-6
+    t = ops.transpose(a)
+    assert t.shape == (64, 64) and torch.equal(t[:, :50], a.T) and bool((t[:, 50:] == 0).all())
+    w = torch.randn(64, device=DEV, generator=g)
+    s = torch.randn(50, device=DEV, generator=g)
+    assert _rel(ops.rowdot(a, w, s[:1]), a.double() @ w.double() + s[0].double()) < 1e-6
+    assert _rel(ops.add_outer(a, s, w), a.double() + s.double()[:, None] * w.double()[None, :]) < 1e-6        # (one fused multiply-add on the device)
+    assert torch.equal(ops.scale_rows(a, s), a * s[:, None])
+    assert torch.equal(ops.affine_cols(a, w, None), a * w) and torch.equal(ops.affine_cols(a, None, w), a + w)
+
+
+def test_attention_forward_backward_match_torch():
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(2)
+    n, L, heads, d = 19, 8, 4, 32
+    H = heads * d
+    qkv = torch.randn(n * L, 3 * H, device=DEV, generator=g).requires_grad_(True)
+    mask = (torch.rand(n, L, device=DEV, generator=g) < 0.6)
+    mask[:, 0] = True
+    mask[3] = False                                           # a row whose keys are all masked: uniform attention (eager semantics)
+    dctx = torch.randn(n * L, H, device=DEV, generator=g)
+    ctx, probs = ops.attention(qkv.detach(), mask.to(torch.uint8), n, L, heads, H)
+    q, k, v = [t.view(n, L, heads, d).transpose(1, 2) for t in qkv.double().split(H, dim=1)]
+    bias = torch.where(mask, 0.0, torch.finfo(torch.float32).min).double()[:, None, None, :]
+    p = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5 + bias, -1)
+    ref = (p @ v).transpose(1, 2).reshape(n * L, H)
+    assert _rel(ctx, ref) < 2e-6 and float((probs[3] - 1.0 / L).abs().max()) < 1e-6
+    ref.backward(dctx.double())
+    dqkv = ops.attention_bwd(dctx, qkv.detach(), probs, n, L, heads, H)
+    assert _rel(dqkv, qkv.grad) < 2e-5
+
+
+def test_gather_forward_backward_match_torch():
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    v0, e_in, nfb = 50, 96, 3
+    for dtype in (torch.float32, torch.float16):
+        src = torch.randn(v0 + 5, e_in, device=DEV, generator=g).to(dtype)
+        fb = torch.randn(nfb, e_in, device=DEV, generator=g).requires_grad_(True)
+        sw = (1 + torch.rand(e_in, device=DEV, generator=g)).requires_grad_(True)
+        sb = torch.randn(e_in, device=DEV, generator=g).requires_grad_(True)
+        ids = torch.randint(0, v0 + nfb, (200,), device=DEV, generator=g, dtype=torch.int32)
+        x = ops.gather(ids, src, v0, fb.detach(), sw.detach(), sb.detach())
+        il = ids.long()
+        ref = torch.where((il >= v0)[:, None], fb.double()[torch.clamp(il - v0, min=0)], sw.double() * src.double()[torch.clamp(il, max=v0 - 1)] + sb.double())
+        assert _rel(x, ref) < 1e-6
+        dx = torch.randn(200, e_in, device=DEV, generator=g)
+        ref.backward(dx.double())
+        dfb, dsw, dsb = ops.gather_bwd(ids, src, v0, dx, nfb)
+        assert _rel(dfb, fb.grad) < 1e-5 and _rel(dsw, sw.grad) < 1e-5 and _rel(dsb, sb.grad) < 1e-5
+
+
+def _case(flags, seed, rows=24):
+    cfg, *_ = synth.workload("tiny")
+    cfg = dict(cfg, **flags)
+    w = synth.make_weights(cfg, seed=seed)
+    src = synth.make_source_embeddings(cfg, seed)
+    ids = synth.make_surface_forms(cfg, rows, seed=seed, n_special=1)
+    ids[2, 1] = cfg["original_vocab_size"] + 2                       # a fallback id
+    return cfg, w, src, ids
+
+
+FLAGS = [dict(), dict(hn_embed_lang_id=False), dict(separate_out_embeddings=False), dict(hn_single_head=True),
+         dict(hn_rescale_embeddings=False), dict(hn_predict_bias=False), dict(hn_single_head=True, separate_out_embeddings=False, hn_embed_lang_id=False)]
+
+
+@pytest.mark.parametrize("flags", FLAGS, ids=lambda f: "+".join(f"{k[3:] if k.startswith('hn_') else k}={int(v)}" for k, v in f.items()) or "default")
+def test_whole_hypernetwork_outputs_and_every_gradient(flags):
+    from oracle import hypernet_ref
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg, w, src_np, ids_np = _case(flags, seed=31)
+    lang = 2 if cfg.get("hn_embed_lang_id") else None
+    # the torch restatement is the oracle's math
+    W64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in w.items()}
+    ref = torch_port.forward(W64, cfg, torch.from_numpy(ids_np).long(), torch.from_numpy(src_np), lang)
+    want = hypernet_ref.forward(w, cfg, ids_np, src_np, lang_index=lang)
+    for a, b in zip(ref, want):
+        assert (a is None) == (b is None) and (a is None or float(np.abs(a.detach().numpy() - b).max()) < 5e-6)
+    # the drop-in class with trainable parameters takes the differentiable path
+    model = ZettHypernet(ZettHypernetConfig(**cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model = model.to(DEV)
+    src, ids = torch.from_numpy(src_np).to(DEV), torch.from_numpy(ids_np).to(DEV)
+    model.precision = "f32"
+    with torch.no_grad():
+        inference = model(ids, source_embeddings=src, lang_index=None if lang is None else torch.tensor(lang))
+    model.requires_grad_(True)
+    out = model(ids, source_embeddings=src, lang_index=None if lang is None else torch.tensor(lang))
+    keep = ~util.all_pad_rows(cfg, ids_np)
+    for got, inf, r, what in zip(out, inference, want, ("pred_in", "pred_out", "bias")):
+        if r is None:
+            assert got is None
+            continue
+        assert got.requires_grad
+        util.assert_f32_close(got.detach().cpu().numpy()[keep], r[keep], f"training forward {what}")
+        util.assert_f32_close(got.detach().cpu().numpy()[keep], inf.cpu().numpy()[keep], f"training forward vs inference forward {what}")
+    # one scalar loss over all three outputs, random cotangents
+    gen = torch.Generator().manual_seed(5)
+    cot = [None if r is None else torch.randn(r.shape, generator=gen, dtype=torch.float64) for r in ref]
+    loss_ref = sum((r * c).sum() for r, c in zip(ref, cot) if r is not None)
+    loss_ref.backward()
+    loss = sum((o.double() * c.to(DEV)).sum() for o, c in zip(out, cot) if o is not None)
+    loss.backward()
+    params = dict(model.named_parameters())
+    worst = {}
+    for name, p64 in W64.items():
+        if name not in params:
+            continue                                           # model.embeddings.word_embeddings.weight etc.: never read
+        g_ref = torch.zeros_like(p64) if p64.grad is None else p64.grad
+        g = params[name].grad
+        if g is None and p64.grad is None:
+            continue                                           # model.embeddings.word_embeddings.weight: a parameter of the checkpoint contract that nothing reads
+        assert g is not None, name
+        denom = float(g_ref.norm())
+        err = float((g.double().cpu() - g_ref).norm())
+        if denom < 1e-12:
+            assert err < 1e-6, (name, err)
+        else:
+            worst[name] = err / denom
+    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    assert not bad, bad
+    assert len(worst) >= 40
+
+
+def test_a_training_step_lowers_the_loss():
+    """What train.py does with the path: predict embeddings, take a loss on them, step the hypernetwork's parameters."""
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg, w, src_np, ids_np = _case({}, seed=41, rows=64)
+    model = ZettHypernet(ZettHypernetConfig(**cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model = model.to(DEV).requires_grad_(True)
+    src, ids = torch.from_numpy(src_np).to(DEV), torch.from_numpy(ids_np).to(DEV)
+    target = torch.randn(64, cfg["n_embd"], device=DEV, generator=torch.Generator(device=DEV).manual_seed(0)) * 0.05
+    losses = []
+    for _ in range(5):
+        model.zero_grad()
+        pred_in, pred_out, bias = model(ids, source_embeddings=src, lang_index=torch.tensor(1))
+        loss = ((pred_in - target) ** 2).mean() + ((pred_out - target) ** 2).mean() + (bias ** 2).mean()
+        loss.backward()
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        norm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads))
+        with torch.no_grad():                                   # a normalised gradient step of length 0.02 in parameter space
+            for p in model.parameters():
+                if p.grad is not None:
+                    p -= (0.02 / float(norm)) * p.grad
+        model.refresh_weights()
+        losses.append(float(loss))
+    assert all(b < a for a, b in zip(losses, losses[1:])) and all(np.isfinite(losses)), losses
+    # no gradient wanted: the inference path (pad skipping, hoisting, ...) runs as before
+    with torch.no_grad():
+        out = model(ids, source_embeddings=src, lang_index=torch.tensor(1))
+    assert not out[0].requires_grad

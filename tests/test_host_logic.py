@@ -20,7 +20,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from zett_amd import _lib
     header = open(os.path.join(REPO, "include", "zett_hip.h")).read()
-    declared = set(re.findall(r"\b(zett_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(zett_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
     lib = _lib.load()
     for name in declared:

@@ -24,6 +24,10 @@ ABI_SYMBOLS = (
     "zett_finalize", "zett_forward", "zett_get_stats", "zett_workspace_bytes", "zett_set_option",
     "zett_retok_create", "zett_retok_destroy", "zett_retokenize", "zett_check_range", "zett_get_gemm_log",
     "zett_stream_wait_output",
+    # training primitives (zett_amd/autograd.py)
+    "zett_op_gemm_f32", "zett_op_transpose_f32", "zett_op_colsum_f32", "zett_op_elementwise_f32", "zett_op_rowdot_f32",
+    "zett_op_layernorm_fwd_f32", "zett_op_layernorm_bwd_f32", "zett_op_gelu_fwd_f32", "zett_op_gelu_bwd_f32",
+    "zett_op_attention_fwd_f32", "zett_op_attention_bwd_f32", "zett_op_gather_fwd_f32", "zett_op_gather_bwd_f32",
 )
 
 
@@ -102,6 +106,20 @@ def load():
         lib.zett_retok_destroy.argtypes = [C.c_void_p]
         lib.zett_retokenize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                         C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]
+        P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+        lib.zett_op_gemm_f32.argtypes = [P, I32, P, I32, I64, I32, I32, P, I32, P, I32, P, I32, P]
+        lib.zett_op_transpose_f32.argtypes = [P, I32, P, I32, I64, I32, I64, P]
+        lib.zett_op_colsum_f32.argtypes = [P, I32, I64, I32, P, I32, P]
+        lib.zett_op_elementwise_f32.argtypes = [I32, P, P, P, P, P, P, I64, I32, P]
+        lib.zett_op_rowdot_f32.argtypes = [P, I32, P, P, P, I64, I32, P]
+        lib.zett_op_layernorm_fwd_f32.argtypes = [P, I32, P, P, F, P, P, I64, I32, P]
+        lib.zett_op_layernorm_bwd_f32.argtypes = [P, P, I32, P, P, P, P, I64, I32, P]
+        lib.zett_op_gelu_fwd_f32.argtypes = [P, P, I64, I32, P]
+        lib.zett_op_gelu_bwd_f32.argtypes = [P, P, P, I64, I32, P]
+        lib.zett_op_attention_fwd_f32.argtypes = [P, P, P, I32, P, I64, I32, I32, I32, P, I32, P, P]
+        lib.zett_op_attention_bwd_f32.argtypes = [P, I32, P, P, P, I32, P, I64, I32, I32, I32, P, P, P, I32, P]
+        lib.zett_op_gather_fwd_f32.argtypes = [P, I64, P, I32, I32, I32, P, P, P, P, P]
+        lib.zett_op_gather_bwd_f32.argtypes = [P, I64, P, I32, I32, I32, P, P, P, P, P]
         for name in ABI_SYMBOLS:
             fn = getattr(lib, name)
             if name != "zett_last_error":

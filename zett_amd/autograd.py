@@ -1,0 +1,418 @@
+"""Training-time use of the hypernetwork forward: the same forward, differentiable with respect to every
+hypernetwork parameter.
+
+Reference call sites: train.py:1007-1013 (train_step) and 1191-1197 (eval_step) evaluate
+``state.apply_fn({"params": params["hypernet"]}, target_surface_forms, target_priors, source_embeddings, lang_index)``
+inside the loss, under ``jax.value_and_grad``; the gradient flows from the predicted embeddings / biases into the
+hypernetwork's parameters, the source embeddings and the language model are frozen.
+
+First slice.  fp32 arithmetic, the reference's as-written dense ``[N, L', H]`` layout (every position computed, pads
+masked as keys), one ``torch.autograd.Function`` for the whole hypernetwork: its forward keeps the activations the
+backward needs, its backward is straight-line code.  Both are sequences of HIP launches through the C ABI
+(include/zett_hip.h "training use", zett_amd/csrc/train_ops.hip): every dense contraction — forward, dgrad, wgrad — is
+the library's TN MFMA GEMM (dgrad against the transposed weight, wgrad of the two transposed activations); LayerNorm,
+the two GELUs, masked attention and the source-embedding gather have forward and backward row kernels.  torch holds the
+tensors and the autograd tape, allocates, slices and concatenates (layout plumbing, parameter-sized glue); it computes
+nothing of size O(rows x hidden).  There is no CPU path.
+
+What this slice does not do yet: the 16-bit MFMA modes, and the exact levers of the inference path (pad skipping, the
+per-distinct-id input projection, the position-0-only last layer) — all of them exact for gradients too (a position
+that cannot influence hidden[:, 0] receives a zero gradient), so they are a schedule change, not a change of results.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .dims import PROJECTOR_LN_EPS, HypernetDims, weight_shapes
+
+_SRC_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
+ACT_NONE, GELU_TANH, GELU_ERF = 0, 1, 2
+K_STEP = 32          # contraction widths of the fp32 MFMA GEMM are multiples of this
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class Ops:
+    """The HIP primitives on torch tensors (fp32, one cuda device, current stream)."""
+
+    def __init__(self, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("zett_amd computes on MI355X only: the differentiable forward needs cuda (ROCm) tensors; there is no CPU path")
+        self.lib = _lib.load()
+        self.device = device
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def new(self, *shape) -> torch.Tensor:
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    # ---- dense contraction: y[M,N] = act(x[M,K] . w[N,K]^T + bias) + residual
+    def gemm(self, x, w, bias=None, act=ACT_NONE, residual=None):
+        assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.stride(1) == 1 and w.stride(1) == 1
+        m, k = x.shape
+        n = w.shape[0]
+        out = self.new(m, n)
+        _lib.check(self.lib.zett_op_gemm_f32(_ptr(x), x.stride(0), _ptr(w), w.stride(0), m, n, k, _ptr(bias), act,
+                                             _ptr(residual), 0 if residual is None else residual.stride(0), _ptr(out), n, self._stream()), "zett_op_gemm_f32")
+        return out
+
+    def transpose(self, x, pad_to=K_STEP):
+        assert x.dim() == 2 and x.stride(1) == 1
+        r, c = x.shape
+        rp = -(-r // pad_to) * pad_to
+        out = self.new(c, rp)
+        _lib.check(self.lib.zett_op_transpose_f32(_ptr(x), x.stride(0), _ptr(out), rp, r, c, rp, self._stream()), "zett_op_transpose_f32")
+        return out
+
+    def colsum(self, x, out=None, accumulate=False):
+        assert x.dim() == 2 and x.stride(1) == 1
+        r, c = x.shape
+        if out is None:
+            out = self.new(c)
+        _lib.check(self.lib.zett_op_colsum_f32(_ptr(x), x.stride(0), r, c, _ptr(out), int(accumulate), self._stream()), "zett_op_colsum_f32")
+        return out
+
+    def _ew(self, op, a, b=None, vec=None, vec2=None, s=None, rows=None, cols=None):
+        ref = a if a is not None else None
+        n = ref.numel() if ref is not None else rows * cols
+        cols = cols if cols is not None else (ref.shape[-1] if ref is not None else 1)
+        out = self.new(*(ref.shape if ref is not None else (rows, cols)))
+        for t in (a, b):
+            assert t is None or t.is_contiguous()
+        _lib.check(self.lib.zett_op_elementwise_f32(op, _ptr(a), _ptr(b), _ptr(vec), _ptr(vec2), _ptr(s), _ptr(out), n, cols, self._stream()),
+                   "zett_op_elementwise_f32")
+        return out
+
+    def add(self, a, b):
+        return self._ew(0, a, b)
+
+    def mul(self, a, b):
+        return self._ew(1, a, b)
+
+    def affine_cols(self, a, vec=None, vec2=None):          # a * vec[col] + vec2[col]
+        return self._ew(2, a, vec=vec, vec2=vec2)
+
+    def add_outer(self, a, s, vec):                          # a + s[row] * vec[col]
+        return self._ew(3, a, vec=vec, s=s)
+
+    def scale_rows(self, a, s):                              # a * s[row]
+        return self._ew(4, a, s=s)
+
+    def rowdot(self, a, w, b=None):
+        assert a.dim() == 2 and a.stride(1) == 1
+        out = self.new(a.shape[0])
+        _lib.check(self.lib.zett_op_rowdot_f32(_ptr(a), a.stride(0), _ptr(w), _ptr(b), _ptr(out), a.shape[0], a.shape[1], self._stream()), "zett_op_rowdot_f32")
+        return out
+
+    def layernorm(self, x, gamma, beta, eps):
+        assert x.dim() == 2 and x.stride(1) == 1
+        r, h = x.shape
+        y, stats = self.new(r, h), self.new(r, 2)
+        _lib.check(self.lib.zett_op_layernorm_fwd_f32(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), _ptr(y), _ptr(stats), r, h, self._stream()),
+                   "zett_op_layernorm_fwd_f32")
+        return y, stats
+
+    def layernorm_bwd(self, dy, x, stats, gamma):
+        """-> dx, dgamma, dbeta"""
+        assert dy.is_contiguous() and x.stride(1) == 1
+        r, h = x.shape
+        dx, dyxhat = self.new(r, h), self.new(r, h)
+        _lib.check(self.lib.zett_op_layernorm_bwd_f32(_ptr(dy), _ptr(x), x.stride(0), _ptr(stats), _ptr(gamma), _ptr(dx), _ptr(dyxhat), r, h, self._stream()),
+                   "zett_op_layernorm_bwd_f32")
+        return dx, self.colsum(dyxhat), self.colsum(dy)
+
+    def gelu(self, z, kind):
+        h = self.new(*z.shape)
+        _lib.check(self.lib.zett_op_gelu_fwd_f32(_ptr(z), _ptr(h), z.numel(), kind, self._stream()), "zett_op_gelu_fwd_f32")
+        return h
+
+    def gelu_bwd(self, z, dh, kind):
+        assert dh.is_contiguous() and z.is_contiguous()
+        dz = self.new(*z.shape)
+        _lib.check(self.lib.zett_op_gelu_bwd_f32(_ptr(z), _ptr(dh), _ptr(dz), z.numel(), kind, self._stream()), "zett_op_gelu_bwd_f32")
+        return dz
+
+    def attention(self, qkv, mask, n, seq, heads, hidden):
+        """qkv [n*seq, 3H] (q | k | v), mask uint8 [n, seq] -> ctx [n*seq, H], probs [n, heads, seq, seq]"""
+        d = hidden // heads
+        ctx, probs = self.new(n * seq, hidden), self.new(n, heads, seq, seq)
+        q, k, v = qkv[:, :hidden], qkv[:, hidden:2 * hidden], qkv[:, 2 * hidden:]
+        _lib.check(self.lib.zett_op_attention_fwd_f32(_ptr(q), _ptr(k), _ptr(v), qkv.stride(0), _ptr(mask), n, seq, heads, d, _ptr(ctx), hidden,
+                                                      _ptr(probs), self._stream()), "zett_op_attention_fwd_f32")
+        return ctx, probs
+
+    def attention_bwd(self, dctx, qkv, probs, n, seq, heads, hidden):
+        d = hidden // heads
+        dqkv = self.new(n * seq, 3 * hidden)
+        q, k, v = qkv[:, :hidden], qkv[:, hidden:2 * hidden], qkv[:, 2 * hidden:]
+        dq, dk, dv = dqkv[:, :hidden], dqkv[:, hidden:2 * hidden], dqkv[:, 2 * hidden:]
+        assert dctx.is_contiguous()
+        _lib.check(self.lib.zett_op_attention_bwd_f32(_ptr(dctx), hidden, _ptr(q), _ptr(k), _ptr(v), qkv.stride(0), _ptr(probs), n, seq, heads, d,
+                                                      _ptr(dq), _ptr(dk), _ptr(dv), 3 * hidden, self._stream()), "zett_op_attention_bwd_f32")
+        return dqkv
+
+    def gather(self, ids, src, v0, fallback, sw, sb):
+        t = ids.numel()
+        x = self.new(t, src.shape[1])
+        _lib.check(self.lib.zett_op_gather_fwd_f32(_ptr(ids), t, _ptr(src), _SRC_DTYPES[src.dtype], src.shape[1], v0, _ptr(fallback), _ptr(sw), _ptr(sb),
+                                                   _ptr(x), self._stream()), "zett_op_gather_fwd_f32")
+        return x
+
+    def gather_bwd(self, ids, src, v0, dx, n_fallback):
+        """-> dfallback [n_fallback, E_in], d in_scaler.w [E_in], d in_scaler.b [E_in]"""
+        t, e_in = dx.shape
+        dfb = torch.zeros((n_fallback, e_in), dtype=torch.float32, device=self.device)
+        prod, keep = self.new(t, e_in), self.new(t, e_in)
+        _lib.check(self.lib.zett_op_gather_bwd_f32(_ptr(ids), t, _ptr(src), _SRC_DTYPES[src.dtype], e_in, v0, _ptr(dx), _ptr(dfb), _ptr(prod), _ptr(keep),
+                                                   self._stream()), "zett_op_gather_bwd_f32")
+        return dfb, self.colsum(prod), self.colsum(keep)
+
+    # ---- Linear backward on the same GEMM: dgrad against W^T, wgrad of the transposed activations
+    def linear_bwd(self, dy, x, w):
+        """y = x w^T + b  ->  dx [M, K], dw [N, K], db [N]"""
+        assert dy.is_contiguous() and dy.shape == (x.shape[0], w.shape[0])
+        if w.shape[0] % K_STEP:
+            raise NotImplementedError(f"the fp32 training GEMM contracts over multiples of {K_STEP}: a Linear with {w.shape[0]} outputs is not supported yet")
+        dx = self.gemm(dy, self.transpose(w))                           # A = dy [M, N], W-operand = w^T [K, N]
+        dw = self.gemm(self.transpose(dy), self.transpose(x))           # A = dy^T [N, M'], W-operand = x^T [K, M'] (M' = rows zero-padded to 32)
+        return dx, dw, self.colsum(dy)
+
+
+def _projector_fwd(ops: Ops, P, prefix, x):
+    """ProjectorBlock (modeling_hypernet.py:22-40): LN_1e-6(gelu_t(W2 gelu_t(W1 x + b1) + b2) + x)"""
+    z1 = ops.gemm(x, P[prefix + "dense1.weight"], P[prefix + "dense1.bias"])
+    h1 = ops.gelu(z1, GELU_TANH)
+    z2 = ops.gemm(h1, P[prefix + "dense2.weight"], P[prefix + "dense2.bias"])
+    h2 = ops.gelu(z2, GELU_TANH)
+    s = ops.add(h2, x)
+    y, st = ops.layernorm(s, P[prefix + "ln.weight"], P[prefix + "ln.bias"], PROJECTOR_LN_EPS)
+    return y, dict(x=x, z1=z1, h1=h1, z2=z2, s=s, st=st)
+
+
+def _projector_bwd(ops: Ops, P, G, prefix, saved, dy):
+    ds, G[prefix + "ln.weight"], G[prefix + "ln.bias"] = ops.layernorm_bwd(dy, saved["s"], saved["st"], P[prefix + "ln.weight"])
+    dz2 = ops.gelu_bwd(saved["z2"], ds, GELU_TANH)
+    dh1, G[prefix + "dense2.weight"], G[prefix + "dense2.bias"] = ops.linear_bwd(dz2, saved["h1"], P[prefix + "dense2.weight"])
+    dz1 = ops.gelu_bwd(saved["z1"], dh1, GELU_TANH)
+    dx, G[prefix + "dense1.weight"], G[prefix + "dense1.bias"] = ops.linear_bwd(dz1, saved["x"], P[prefix + "dense1.weight"])
+    return ops.add(dx, ds)          # the residual branch
+
+
+def forward_train(ops: Ops, dims: HypernetDims, ln_eps: float, P: Dict[str, torch.Tensor], ids: torch.Tensor, src: torch.Tensor, lang: int):
+    """The as-written forward (modeling_hypernet.py:156-267) on HIP primitives, keeping what the backward needs.
+    -> (pred_in, pred_out | None, bias), saved"""
+    n, L = ids.shape
+    lam = 1 if dims.embed_lang else 0
+    Lp, H = L + lam, dims.hidden
+    for name, width in (("n_embd", dims.n_embd), ("n_in_embd", dims.n_in_embd), ("hidden", H), ("intermediate", dims.intermediate)):
+        if width % K_STEP:
+            raise NotImplementedError(f"{name} = {width}: the fp32 training GEMM contracts over multiples of {K_STEP}")
+    S = {}
+    ids32 = ids.to(torch.int32).contiguous()
+    S["ids"] = ids32
+    sw = P["in_scaler.w"].reshape(-1) if dims.rescale else None
+    sb = P["in_scaler.b"].reshape(-1) if dims.rescale else None
+    x0 = ops.gather(ids32.view(-1), src, dims.original_vocab_size, P["fallback_embeddings.weight"], sw, sb)          # [N*L, E_in]
+    y0 = ops.gemm(x0, P["input_projection.0.weight"], P["input_projection.0.bias"])
+    t, S["pb_in"] = _projector_fwd(ops, P, "input_projection.1.", y0)
+    S["x0"] = x0
+    # lang token + RobertaEmbeddings (modeling_hypernet.py:192-229): x + type[0] + pos[p], LayerNorm
+    type0 = P["model.embeddings.token_type_embeddings.weight"][0]
+    pos = P["model.embeddings.position_embeddings.weight"]
+    xin = ops.new(n, Lp, H)
+    xin[:, :L] = t.view(n, L, H)                                           # layout plumbing (copies), not arithmetic
+    if lam:
+        xin[:, L] = P["lang_embeddings.weight"][lang] - (type0 + pos[L])   # parameter-sized glue ([H])
+    posadd = (type0[None, :] + pos[:Lp]).contiguous().view(-1)             # [L'*H], parameter-sized
+    emb = ops.affine_cols(xin.view(n, Lp * H), None, posadd).view(n * Lp, H)
+    z, st = ops.layernorm(emb, P["model.embeddings.LayerNorm.weight"], P["model.embeddings.LayerNorm.bias"], ln_eps)
+    S["emb"], S["emb_st"] = emb, st
+    mask = torch.ones((n, Lp), dtype=torch.uint8, device=ids.device)
+    mask[:, :L] = (ids != dims.pad_token_id).to(torch.uint8)
+    S["mask"] = mask
+    layers = []
+    for l in range(dims.layers):
+        p = f"model.encoder.layer.{l}."
+        a = p + "attention.self."
+        wqkv = torch.cat([P[a + "query.weight"], P[a + "key.weight"], P[a + "value.weight"]], 0)      # fused operand (parameter plumbing)
+        bqkv = torch.cat([P[a + "query.bias"], P[a + "key.bias"], P[a + "value.bias"]], 0)
+        qkv = ops.gemm(z, wqkv, bqkv)
+        ctx, probs = ops.attention(qkv, mask, n, Lp, dims.heads, H)
+        s1 = ops.gemm(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"], residual=z)
+        z1, st1 = ops.layernorm(s1, P[p + "attention.output.LayerNorm.weight"], P[p + "attention.output.LayerNorm.bias"], ln_eps)
+        u = ops.gemm(z1, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"])
+        g = ops.gelu(u, GELU_ERF)
+        s2 = ops.gemm(g, P[p + "output.dense.weight"], P[p + "output.dense.bias"], residual=z1)
+        z2, st2 = ops.layernorm(s2, P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], ln_eps)
+        layers.append(dict(z=z, wqkv=wqkv, qkv=qkv, probs=probs, ctx=ctx, s1=s1, st1=st1, z1=z1, u=u, g=g, s2=s2, st2=st2))
+        z = z2
+    S["layers"] = layers
+    cls = z.view(n, Lp, H)[:, 0].contiguous()                                # hidden[:, 0] (modeling_hypernet.py:234)
+    S["cls"] = cls
+    e = dims.n_embd
+    h_in, S["pb_out0"] = _projector_fwd(ops, P, "output_projection.0.", cls)
+    S["h_in"] = h_in
+    pred = ops.gemm(h_in, P["output_projection.1.weight"], P["output_projection.1.bias"])
+    S["pred_raw"] = pred
+    pred_out = None
+    if dims.single_head:
+        if dims.rescale:
+            scale = torch.cat([P["scaler.w"].reshape(-1)] + ([P["out_scaler.w"].reshape(-1)] if dims.separate_out else []))
+            shift = torch.cat([P["scaler.b"].reshape(-1)] + ([P["out_scaler.b"].reshape(-1)] if dims.separate_out else []))
+            pred = ops.affine_cols(pred, scale, shift)
+        pred_in = pred[:, :e].contiguous()
+        pred_out = pred[:, e:].contiguous() if dims.separate_out else None
+    else:
+        pred_in = ops.affine_cols(pred, P["scaler.w"].reshape(-1), P["scaler.b"].reshape(-1)) if dims.rescale else pred
+        if dims.separate_out:
+            h_out, S["pb_out1"] = _projector_fwd(ops, P, "output_projection_out.0.", cls)
+            S["h_out"] = h_out
+            po = ops.gemm(h_out, P["output_projection_out.1.weight"], P["output_projection_out.1.bias"])
+            S["pred_out_raw"] = po
+            pred_out = ops.affine_cols(po, P["out_scaler.w"].reshape(-1), P["out_scaler.b"].reshape(-1)) if dims.rescale else po
+    if dims.predict_bias:
+        bias = ops.rowdot(cls, P["bias_projection.weight"].reshape(-1), P["bias_projection.bias"].reshape(-1))
+    else:
+        bias = torch.zeros((n,), dtype=torch.float32, device=ids.device)
+    return (pred_in, pred_out, bias), S
+
+
+def backward_train(ops: Ops, dims: HypernetDims, P: Dict[str, torch.Tensor], S, src: torch.Tensor, lang: int,
+                   d_in: Optional[torch.Tensor], d_out: Optional[torch.Tensor], d_bias: Optional[torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Gradients of every hypernetwork parameter, given the gradients of the three outputs."""
+    G: Dict[str, torch.Tensor] = {}
+    n, L = S["ids"].shape
+    lam = 1 if dims.embed_lang else 0
+    Lp, H, e = L + lam, dims.hidden, dims.n_embd
+    dev = S["cls"].device
+    zeros = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    d_in = zeros(n, e) if d_in is None else d_in.contiguous().float()
+    if dims.separate_out:
+        d_out = zeros(n, e) if d_out is None else d_out.contiguous().float()
+    cls = S["cls"]
+    # ---- heads
+    if dims.single_head:
+        dpred = torch.cat([d_in, d_out], 1).contiguous() if dims.separate_out else d_in
+        if dims.rescale:
+            raw = S["pred_raw"]
+            gw, gb = ops.colsum(ops.mul(dpred, raw)), ops.colsum(dpred)
+            G["scaler.w"], G["scaler.b"] = gw[:e].reshape(1, -1).clone(), gb[:e].reshape(1, -1).clone()
+            if dims.separate_out:
+                G["out_scaler.w"], G["out_scaler.b"] = gw[e:].reshape(1, -1).clone(), gb[e:].reshape(1, -1).clone()
+            scale = torch.cat([P["scaler.w"].reshape(-1)] + ([P["out_scaler.w"].reshape(-1)] if dims.separate_out else []))
+            dpred = ops.affine_cols(dpred, scale, None)
+        dh, G["output_projection.1.weight"], G["output_projection.1.bias"] = ops.linear_bwd(dpred, S["h_in"], P["output_projection.1.weight"])
+        dcls = _projector_bwd(ops, P, G, "output_projection.0.", S["pb_out0"], dh)
+    else:
+        dpred = d_in
+        if dims.rescale:
+            G["scaler.w"] = ops.colsum(ops.mul(dpred, S["pred_raw"])).reshape(1, -1)
+            G["scaler.b"] = ops.colsum(dpred).reshape(1, -1)
+            dpred = ops.affine_cols(dpred, P["scaler.w"].reshape(-1), None)
+        dh, G["output_projection.1.weight"], G["output_projection.1.bias"] = ops.linear_bwd(dpred, S["h_in"], P["output_projection.1.weight"])
+        dcls = _projector_bwd(ops, P, G, "output_projection.0.", S["pb_out0"], dh)
+        if dims.separate_out:
+            dpo = d_out
+            if dims.rescale:
+                G["out_scaler.w"] = ops.colsum(ops.mul(dpo, S["pred_out_raw"])).reshape(1, -1)
+                G["out_scaler.b"] = ops.colsum(dpo).reshape(1, -1)
+                dpo = ops.affine_cols(dpo, P["out_scaler.w"].reshape(-1), None)
+            dh2, G["output_projection_out.1.weight"], G["output_projection_out.1.bias"] = ops.linear_bwd(dpo, S["h_out"], P["output_projection_out.1.weight"])
+            dcls = ops.add(dcls, _projector_bwd(ops, P, G, "output_projection_out.0.", S["pb_out1"], dh2))
+    if dims.predict_bias:
+        db = zeros(n) if d_bias is None else d_bias.contiguous().float()
+        wb = P["bias_projection.weight"].reshape(-1)
+        G["bias_projection.weight"] = ops.colsum(ops.scale_rows(cls, db)).reshape(1, -1)
+        G["bias_projection.bias"] = db.view(1, -1).sum(1) if n == 0 else ops.colsum(db.view(-1, 1)).reshape(1)
+        dcls = ops.add_outer(dcls, db, wb)
+    # ---- encoder (only position 0 of the last hidden state carries a gradient)
+    dz = zeros(n, Lp, H)
+    dz[:, 0] = dcls                                                       # layout plumbing
+    dz = dz.view(n * Lp, H)
+    for l in reversed(range(dims.layers)):
+        p = f"model.encoder.layer.{l}."
+        a = p + "attention.self."
+        A = S["layers"][l]
+        ds2, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = ops.layernorm_bwd(dz, A["s2"], A["st2"], P[p + "output.LayerNorm.weight"])
+        dg, G[p + "output.dense.weight"], G[p + "output.dense.bias"] = ops.linear_bwd(ds2, A["g"], P[p + "output.dense.weight"])
+        du = ops.gelu_bwd(A["u"], dg, GELU_ERF)
+        dz1, G[p + "intermediate.dense.weight"], G[p + "intermediate.dense.bias"] = ops.linear_bwd(du, A["z1"], P[p + "intermediate.dense.weight"])
+        dz1 = ops.add(dz1, ds2)                                           # residual of the FFN
+        ds1, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
+            ops.layernorm_bwd(dz1, A["s1"], A["st1"], P[p + "attention.output.LayerNorm.weight"])
+        dctx, G[p + "attention.output.dense.weight"], G[p + "attention.output.dense.bias"] = ops.linear_bwd(ds1, A["ctx"], P[p + "attention.output.dense.weight"])
+        dqkv = ops.attention_bwd(dctx, A["qkv"], A["probs"], n, Lp, dims.heads, H)
+        dzin, dwqkv, dbqkv = ops.linear_bwd(dqkv, A["z"], A["wqkv"])
+        for i, name in enumerate(("query", "key", "value")):
+            G[a + name + ".weight"] = dwqkv[i * H:(i + 1) * H].clone()
+            G[a + name + ".bias"] = dbqkv[i * H:(i + 1) * H].clone()
+        dz = ops.add(dzin, ds1)                                           # residual of the attention block
+    # ---- embeddings
+    demb, G["model.embeddings.LayerNorm.weight"], G["model.embeddings.LayerNorm.bias"] = \
+        ops.layernorm_bwd(dz, S["emb"], S["emb_st"], P["model.embeddings.LayerNorm.weight"])
+    per_pos = ops.colsum(demb.view(n, Lp * H)).view(Lp, H)                # sum over the rows, per position
+    dpos = torch.zeros_like(P["model.embeddings.position_embeddings.weight"])
+    dpos[:L] = per_pos[:L]                                                # (the language token's type / position terms cancel: :192-199)
+    G["model.embeddings.position_embeddings.weight"] = dpos
+    G["model.embeddings.token_type_embeddings.weight"] = ops.colsum(per_pos[:L].contiguous()).reshape(1, -1)
+    if lam:
+        dlang = torch.zeros_like(P["lang_embeddings.weight"])
+        dlang[lang] = per_pos[L]
+        G["lang_embeddings.weight"] = dlang
+    dt = demb.view(n, Lp, H)[:, :L].contiguous().view(n * L, H)           # layout plumbing
+    # ---- input projection
+    dy0 = _projector_bwd(ops, P, G, "input_projection.1.", S["pb_in"], dt)
+    dx0, G["input_projection.0.weight"], G["input_projection.0.bias"] = ops.linear_bwd(dy0, S["x0"], P["input_projection.0.weight"])
+    dfb, dsw, dsb = ops.gather_bwd(S["ids"].view(-1), src, dims.original_vocab_size, dx0, P["fallback_embeddings.weight"].shape[0])
+    G["fallback_embeddings.weight"] = dfb
+    if dims.rescale:
+        # x = w * src + b on source rows: d w = sum dx * src; gather_bwd's `prod` used the raw source row
+        G["in_scaler.w"], G["in_scaler.b"] = dsw.reshape(1, -1), dsb.reshape(1, -1)
+    return G
+
+
+class HypernetFunction(torch.autograd.Function):
+    """(target_surface_forms, source_embeddings, lang_index, *parameters) -> (pred_in, pred_out | empty, bias); gradients for
+    the parameters only (the reference trains the hypernetwork against frozen source embeddings)."""
+
+    @staticmethod
+    def forward(ctx, dims, ln_eps, names, ids, src, lang, *params):
+        ops = Ops(src.device)
+        P = {n: p.detach().float().contiguous() for n, p in zip(names, params)}
+        with torch.no_grad():
+            (pred_in, pred_out, bias), S = forward_train(ops, dims, ln_eps, P, ids, src, int(lang))
+        ctx.dims, ctx.names, ctx.lang, ctx.ops = dims, names, int(lang), ops
+        ctx.P, ctx.S, ctx.src = P, S, src
+        ctx.has_out = pred_out is not None
+        if pred_out is None:
+            pred_out = pred_in.new_zeros((0,))
+        return pred_in, pred_out, bias
+
+    @staticmethod
+    def backward(ctx, d_in, d_out, d_bias):
+        with torch.no_grad():
+            G = backward_train(ctx.ops, ctx.dims, ctx.P, ctx.S, ctx.src, ctx.lang, d_in, d_out if ctx.has_out else None, d_bias)
+        grads = []
+        for name, p in zip(ctx.names, ctx.P.values()):
+            g = G.get(name)
+            grads.append(None if g is None else g.reshape(p.shape))
+        ctx.S = None
+        return (None, None, None, None, None, None, *grads)
+
+
+def differentiable_forward(model, target_surface_forms: torch.Tensor, source_embeddings: torch.Tensor, lang_index: int):
+    """The forward of `model` (a zett_amd.hypernet.ZettHypernet) with gradients to its parameters."""
+    names = [n for n in weight_shapes(model.dims)]
+    params = dict(model.named_parameters())
+    tensors = [params[n] for n in names]
+    src = source_embeddings if source_embeddings.dtype in _SRC_DTYPES else source_embeddings.float()
+    pred_in, pred_out, bias = HypernetFunction.apply(model.dims, model._ln_eps_encoder, tuple(names), target_surface_forms, src.contiguous(),
+                                                     int(lang_index), *tensors)
+    return pred_in, (pred_out if model.dims.separate_out else None), bias

@@ -1,0 +1,441 @@
+// train_ops.hip — C ABI of the training-time primitives (include/zett_hip.h, "training use"): what
+// zett_amd/autograd.py composes the differentiable forward and its backward from (reference call
+// sites train.py:1007-1013, 1191-1197: the hypernetwork forward inside the loss of a training / evaluation step).
+//
+// First slice: fp32 arithmetic, the as-written (dense [N, L', H]) layout of the reference.  The dense contractions —
+// forward, dgrad and wgrad alike — go through the library's TN GEMM family (fp32 MFMA, gemm_launch.hip.h):
+//     forward   y[M,N]  = x[M,K]  · W[N,K]ᵀ                     (A = x,    W-operand = W)
+//     dgrad     dx[M,K] = dy[M,N] · (Wᵀ)[K,N]ᵀ                  (A = dy,   W-operand = Wᵀ: zett_op_transpose)
+//     wgrad     dW[N,K] = (dyᵀ)[N,M] · (xᵀ)[K,M]ᵀ               (A = dyᵀ,  W-operand = xᵀ; M zero-padded to the K step)
+// — the same contraction with swapped / transposed operands, so one kernel family serves all three.  Everything else is a
+// row kernel here: LayerNorm forward / backward, the two GELUs and their derivatives, dense masked attention forward /
+// backward (eager semantics: finfo.min on masked keys, uniform rows when every key is masked), the source-embedding
+// gather with in_scaler / fallback select and its backward, column sums, transposes and three element-wise forms.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/zett_hip.h"
+#include "common.hip.h"
+#include "gemm.hip.h"
+#include "gemm_launch.hip.h"
+
+using namespace zett;
+
+namespace {
+
+__device__ __forceinline__ float t_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float t_block_sum(float v, float* red /* [4] */) {      // 256 threads
+    v = t_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- transposes / reductions / element-wise ----------------------------------------------------------------------
+// out[c, r] = in[r, c] for r < R; out[c, r] = 0 for R <= r < Rpad   (ld_out >= Rpad)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int ld_out,
+                                                        int R, int C, int Rpad) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < C && r < Rpad) out[(size_t)c * ld_out + r] = tile[tx][k];
+    }
+}
+
+// out[c] (+)= sum_r in[r, c]: one workgroup per 64 columns, rows strided over the four waves
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int ld, int R, int C, float* __restrict__ out, int accumulate) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int r = w; r < R; r += 4) s += in[(size_t)r * ld + c];
+    part[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+// op 0: out = a + b;  1: out = a * b;  2: out = a * vec[col] + vec2[col] (vec null: 1, vec2 null: 0);  3: out = a + s[row] * vec[col];
+// 4: out = a * s[row] (a may be null: out = s[row] * vec[col])
+__global__ void elementwise_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ vec,
+                                   const float* __restrict__ vec2, const float* __restrict__ s, float* __restrict__ out, int64_t n, int cols) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int col = (int)(i % cols);
+        const int64_t row = i / cols;
+        float v;
+        switch (op) {
+            case 0: v = a[i] + b[i]; break;
+            case 1: v = a[i] * b[i]; break;
+            case 2: v = (vec ? a[i] * vec[col] : a[i]) + (vec2 ? vec2[col] : 0.f); break;
+            case 3: v = a[i] + s[row] * vec[col]; break;
+            default: v = a ? a[i] * s[row] : s[row] * vec[col]; break;
+        }
+        out[i] = v;
+    }
+}
+
+// out[r] = sum_c a[r, c] * w[c] + (b ? b[0] : 0)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a, int ld, const float* __restrict__ w, const float* __restrict__ b,
+                                                     float* __restrict__ out, int R, int C) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    if (r >= R) return;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += a[(size_t)r * ld + c] * w[c];
+    const float t = t_block_sum(s, red);
+    if (threadIdx.x == 0) out[r] = t + (b ? b[0] : 0.f);
+}
+
+// ---- LayerNorm ------------------------------------------------------------------------------------------------------
+// y = (x - mean) * rstd * gamma + beta; stats[r] = (mean, rstd)   (two-pass variance, as torch.nn.LayerNorm)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, float* __restrict__ y, float* __restrict__ stats, int R, int H) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    if (r >= R) return;
+    const float* xr = x + (size_t)r * ld;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < H; c += 256) s += xr[c];
+    const float mean = t_block_sum(s, red) / (float)H;
+    float q = 0.f;
+    for (int c = threadIdx.x; c < H; c += 256) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(t_block_sum(q, red) / (float)H + eps);
+    if (threadIdx.x == 0) { stats[2 * (size_t)r] = mean; stats[2 * (size_t)r + 1] = rstd; }
+    for (int c = threadIdx.x; c < H; c += 256) y[(size_t)r * H + c] = ln_affine(xr[c], mean, rstd, gamma[c], beta[c]);
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd;
+// dyxhat = dy * xhat (its column sum is dgamma; dbeta is the column sum of dy)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int ld, const float* __restrict__ stats,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ dyxhat, int R, int H) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    if (r >= R) return;
+    const float mean = stats[2 * (size_t)r], rstd = stats[2 * (size_t)r + 1];
+    const float* xr = x + (size_t)r * ld;
+    const float* dyr = dy + (size_t)r * H;
+    float sg = 0.f, sgx = 0.f;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float xh = (xr[c] - mean) * rstd, g = dyr[c] * gamma[c];
+        sg += g; sgx += g * xh;
+    }
+    const float mg = t_block_sum(sg, red) / (float)H;
+    const float mgx = t_block_sum(sgx, red) / (float)H;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float xh = (xr[c] - mean) * rstd, g = dyr[c] * gamma[c];
+        dx[(size_t)r * H + c] = rstd * (g - mg - xh * mgx);
+        dyxhat[(size_t)r * H + c] = dyr[c] * xh;
+    }
+}
+
+// ---- GELU -----------------------------------------------------------------------------------------------------------
+// kind 1: F.gelu(approximate="tanh") (ProjectorBlock), 2: erf form (RobertaIntermediate) — the forward functions of gemm.hip.h
+__global__ void gelu_fwd_kernel(const float* __restrict__ z, float* __restrict__ h, int64_t n, int kind) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) h[i] = kind == 1 ? gelu_tanh_f(z[i]) : gelu_erf_f(z[i]);
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dh, float* __restrict__ dz, int64_t n, int kind) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float x = z[i];
+        float d;
+        if (kind == 1) {       // d/dx [0.5 x (1 + tanh u)], u = sqrt(2/pi) (x + 0.044715 x^3)
+            const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+            const float t = tanhf(u);
+            d = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+        } else {               // Phi(x) + x phi(x)
+            d = 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+        }
+        dz[i] = dh[i] * d;
+    }
+}
+
+// ---- dense masked attention (eager semantics) ---------------------------------------------------------------------------
+// One workgroup of 64 lanes per (row n, head): q, k, v are [N*L, ld] with the head's columns at head*d; mask [N, L] (1 = key
+// visible).  probs [N, heads, L, L] is saved for the backward.  L <= ATT_MAX_L.
+constexpr int ATT_MAX_L = 32;
+
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
+                                                      const uint8_t* __restrict__ mask, int L, int heads, int d, float scaling,
+                                                      float* __restrict__ ctx, int ld_ctx, float* __restrict__ probs) {
+    __shared__ float s[ATT_MAX_L][ATT_MAX_L];
+    const int n = blockIdx.x / heads, hd = blockIdx.x % heads, lane = threadIdx.x;
+    const size_t base = (size_t)n * L;
+    for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j) {
+            float p = 0.f;
+            for (int c = lane; c < d; c += 64) p += q[(base + i) * ld + hd * d + c] * k[(base + j) * ld + hd * d + c];
+            p = t_wave_sum(p);
+            if (lane == 0) s[i][j] = p * scaling + (mask[base + j] ? 0.f : -FLT_MAX);       // finfo(float32).min on masked keys
+        }
+    __syncthreads();
+    if (lane < L) {
+        const int i = lane;
+        float mx = -INFINITY;
+        for (int j = 0; j < L; ++j) mx = fmaxf(mx, s[i][j]);
+        float sum = 0.f;
+        for (int j = 0; j < L; ++j) { const float e = expf(s[i][j] - mx); s[i][j] = e; sum += e; }
+        for (int j = 0; j < L; ++j) {
+            const float p = s[i][j] / sum;
+            s[i][j] = p;
+            probs[(((size_t)n * heads + hd) * L + i) * L + j] = p;
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < L; ++i)
+        for (int c = lane; c < d; c += 64) {
+            float a = 0.f;
+            for (int j = 0; j < L; ++j) a += s[i][j] * v[(base + j) * ld + hd * d + c];
+            ctx[(base + i) * ld_ctx + hd * d + c] = a;
+        }
+}
+
+// dv_j = sum_i p_ij dctx_i;  dp_ij = dctx_i . v_j;  ds_ij = p_ij (dp_ij - sum_j' p_ij' dp_ij');
+// dq_i = scaling sum_j ds_ij k_j;  dk_j = scaling sum_i ds_ij q_i
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ dctx, int ld_ctx, const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, int ld, const float* __restrict__ probs, int L, int heads, int d,
+                                                      float scaling, float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, int ld_d) {
+    __shared__ float p[ATT_MAX_L][ATT_MAX_L], ds[ATT_MAX_L][ATT_MAX_L];
+    const int n = blockIdx.x / heads, hd = blockIdx.x % heads, lane = threadIdx.x;
+    const size_t base = (size_t)n * L;
+    for (int t = lane; t < L * L; t += 64) p[t / L][t % L] = probs[((size_t)n * heads + hd) * L * L + t];
+    __syncthreads();
+    for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j) {
+            float a = 0.f;
+            for (int c = lane; c < d; c += 64) a += dctx[(base + i) * ld_ctx + hd * d + c] * v[(base + j) * ld + hd * d + c];
+            a = t_wave_sum(a);
+            if (lane == 0) ds[i][j] = a;           // dp for now
+        }
+    __syncthreads();
+    if (lane < L) {
+        const int i = lane;
+        float dot = 0.f;
+        for (int j = 0; j < L; ++j) dot += p[i][j] * ds[i][j];
+        for (int j = 0; j < L; ++j) ds[i][j] = p[i][j] * (ds[i][j] - dot);
+    }
+    __syncthreads();
+    for (int c = lane; c < d; c += 64) {
+        for (int j = 0; j < L; ++j) {
+            float av = 0.f, ak = 0.f;
+            for (int i = 0; i < L; ++i) {
+                av += p[i][j] * dctx[(base + i) * ld_ctx + hd * d + c];
+                ak += ds[i][j] * q[(base + i) * ld + hd * d + c];
+            }
+            dv[(base + j) * ld_d + hd * d + c] = av;
+            dk[(base + j) * ld_d + hd * d + c] = ak * scaling;
+        }
+        for (int i = 0; i < L; ++i) {
+            float aq = 0.f;
+            for (int j = 0; j < L; ++j) aq += ds[i][j] * k[(base + j) * ld + hd * d + c];
+            dq[(base + i) * ld_d + hd * d + c] = aq * scaling;
+        }
+    }
+}
+
+// ---- source-embedding gather (A2 + A3) and its backward -----------------------------------------------------------------
+template <int SD> __device__ __forceinline__ float load_src1(const void* base, size_t e);
+template <> __device__ __forceinline__ float load_src1<0>(const void* base, size_t e) { return ((const float*)base)[e]; }
+template <> __device__ __forceinline__ float load_src1<1>(const void* base, size_t e) { return (float)((const _Float16*)base)[e]; }
+template <> __device__ __forceinline__ float load_src1<2>(const void* base, size_t e) { return __uint_as_float(((uint32_t)((const uint16_t*)base)[e]) << 16); }
+
+// x[t] = id < V0 ? sw * src[id] + sb : fallback[id - V0]
+template <int SD>
+__global__ __launch_bounds__(256) void gather_fwd_kernel(const int32_t* __restrict__ ids, int64_t T, const void* __restrict__ src, int e_in, int v0,
+                                                         const float* __restrict__ fallback, const float* __restrict__ sw, const float* __restrict__ sb,
+                                                         float* __restrict__ x) {
+    const int64_t t = blockIdx.x;
+    if (t >= T) return;
+    const int id = ids[t];
+    for (int c = threadIdx.x; c < e_in; c += 256) {
+        float v;
+        if (id >= v0) v = fallback[(size_t)(id - v0) * e_in + c];
+        else { v = load_src1<SD>(src, (size_t)id * e_in + c); if (sw) v = sw[c] * v + sb[c]; }
+        x[(size_t)t * e_in + c] = v;
+    }
+}
+// dfallback[id - V0] += dx[t] (atomics: few rows); prod[t] = dx[t] * src[id] and keep[t] = dx[t] for source rows, 0 for fallback
+// rows — their column sums are d in_scaler.w and d in_scaler.b
+template <int SD>
+__global__ __launch_bounds__(256) void gather_bwd_kernel(const int32_t* __restrict__ ids, int64_t T, const void* __restrict__ src, int e_in, int v0,
+                                                         const float* __restrict__ dx, float* __restrict__ dfallback, float* __restrict__ prod,
+                                                         float* __restrict__ keep) {
+    const int64_t t = blockIdx.x;
+    if (t >= T) return;
+    const int id = ids[t];
+    for (int c = threadIdx.x; c < e_in; c += 256) {
+        const float g = dx[(size_t)t * e_in + c];
+        if (id >= v0) {
+            atomicAdd(dfallback + (size_t)(id - v0) * e_in + c, g);
+            prod[(size_t)t * e_in + c] = 0.f; keep[(size_t)t * e_in + c] = 0.f;
+        } else {
+            prod[(size_t)t * e_in + c] = g * load_src1<SD>(src, (size_t)id * e_in + c);
+            keep[(size_t)t * e_in + c] = g;
+        }
+    }
+}
+
+int grid_for(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 65535); }
+
+}  // namespace
+
+extern "C" {
+
+int zett_op_gemm_f32(const float* a, int32_t lda, const float* w, int32_t ldw, int64_t m, int32_t n, int32_t k, const float* bias, int32_t act,
+                     const float* residual, int32_t ld_res, float* out, int32_t ld_out, void* stream) {
+    if (!a || !w || !out) return fail(ZETT_E_INVALID, "null argument");
+    if (m <= 0 || n <= 0) return 0;
+    if (k <= 0 || k % 32) return fail(ZETT_E_INVALID, "contraction width %d is not a positive multiple of 32", k);
+    if (lda % 4 || ldw % 4) return fail(ZETT_E_INVALID, "operand leading dimensions must be multiples of 4 floats");
+    if (m >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many rows");
+    GemmArgs<float> g{};
+    g.A = a; g.lda = lda; g.W = w; g.ldw = ldw; g.M = (int)m; g.N = n; g.K = k;
+    g.epi.split_col = 0x7fffffff;
+    g.epi.bias = bias; g.epi.act = act; g.epi.residual = residual; g.epi.ld_res = ld_res; g.epi.out_f32 = out; g.epi.ld_f32 = ld_out;
+    // the 256x256 register-staged tile where it pays and its 16-byte drains apply, the 128x128 tile otherwise (identical bits)
+    const bool wide_ok = n % 8 == 0 && ld_out % 4 == 0 && (!residual || ld_res % 4 == 0);
+    const int variant = (m > 128 && n > 128 && wide_ok) ? 2 : 1;
+    const hipError_t e = launch_gemm_variant(variant, g, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int zett_op_transpose_f32(const float* in, int32_t ld_in, float* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream) {
+    if (!in || !out || rows_padded < rows || ld_out < rows_padded) return fail(ZETT_E_INVALID, "bad transpose arguments");
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (unsigned)((rows_padded + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
+                       in, ld_in, out, ld_out, (int)rows, cols, (int)rows_padded);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_colsum_f32(const float* in, int32_t ld, int64_t rows, int32_t cols, float* out, int32_t accumulate, void* stream) {
+    if (!in || !out) return fail(ZETT_E_INVALID, "null argument");
+    if (cols <= 0) return 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, ld, (int)rows, cols, out, accumulate);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_elementwise_f32(int32_t op, const float* a, const float* b, const float* vec, const float* vec2, const float* s, float* out,
+                            int64_t n, int32_t cols, void* stream) {
+    if (!out || op < 0 || op > 4 || cols <= 0) return fail(ZETT_E_INVALID, "bad elementwise arguments");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(elementwise_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, op, a, b, vec, vec2, s, out, n, cols);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_rowdot_f32(const float* a, int32_t ld, const float* w, const float* b, float* out, int64_t rows, int32_t cols, void* stream) {
+    if (!a || !w || !out) return fail(ZETT_E_INVALID, "null argument");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a, ld, w, b, out, (int)rows, cols);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_layernorm_fwd_f32(const float* x, int32_t ld, const float* gamma, const float* beta, float eps, float* y, float* stats,
+                              int64_t rows, int32_t h, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats) return fail(ZETT_E_INVALID, "null argument");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, ld, gamma, beta, eps, y, stats, (int)rows, h);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_layernorm_bwd_f32(const float* dy, const float* x, int32_t ld, const float* stats, const float* gamma, float* dx, float* dyxhat,
+                              int64_t rows, int32_t h, void* stream) {
+    if (!dy || !x || !stats || !gamma || !dx || !dyxhat) return fail(ZETT_E_INVALID, "null argument");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, x, ld, stats, gamma, dx, dyxhat, (int)rows, h);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_gelu_fwd_f32(const float* z, float* h, int64_t n, int32_t kind, void* stream) {
+    if (!z || !h || (kind != 1 && kind != 2)) return fail(ZETT_E_INVALID, "bad gelu arguments");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, h, n, kind);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_gelu_bwd_f32(const float* z, const float* dh, float* dz, int64_t n, int32_t kind, void* stream) {
+    if (!z || !dh || !dz || (kind != 1 && kind != 2)) return fail(ZETT_E_INVALID, "bad gelu arguments");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, dh, dz, n, kind);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_attention_fwd_f32(const float* q, const float* k, const float* v, int32_t ld, const uint8_t* mask, int64_t n_rows, int32_t seq,
+                              int32_t heads, int32_t head_dim, float* ctx, int32_t ld_ctx, float* probs, void* stream) {
+    if (!q || !k || !v || !mask || !ctx || !probs) return fail(ZETT_E_INVALID, "null argument");
+    if (seq < 1 || seq > ATT_MAX_L) return fail(ZETT_E_INVALID, "training attention handles 1 <= L <= %d positions, got %d", ATT_MAX_L, seq);
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(n_rows * heads)), dim3(64), 0, (hipStream_t)stream, q, k, v, ld, mask, seq, heads, head_dim,
+                       1.0f / sqrtf((float)head_dim), ctx, ld_ctx, probs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_attention_bwd_f32(const float* dctx, int32_t ld_ctx, const float* q, const float* k, const float* v, int32_t ld, const float* probs,
+                              int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, float* dq, float* dk, float* dv, int32_t ld_d, void* stream) {
+    if (!dctx || !q || !k || !v || !probs || !dq || !dk || !dv) return fail(ZETT_E_INVALID, "null argument");
+    if (seq < 1 || seq > ATT_MAX_L) return fail(ZETT_E_INVALID, "training attention handles 1 <= L <= %d positions, got %d", ATT_MAX_L, seq);
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(n_rows * heads)), dim3(64), 0, (hipStream_t)stream, dctx, ld_ctx, q, k, v, ld, probs, seq, heads,
+                       head_dim, 1.0f / sqrtf((float)head_dim), dq, dk, dv, ld_d);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_gather_fwd_f32(const int32_t* ids, int64_t n_tokens, const void* src, int32_t src_dtype, int32_t e_in, int32_t v0, const float* fallback,
+                           const float* sw, const float* sb, float* x, void* stream) {
+    if (!ids || !src || !fallback || !x || src_dtype < ZETT_F32 || src_dtype > ZETT_BF16) return fail(ZETT_E_INVALID, "bad gather arguments");
+    if (n_tokens <= 0) return 0;
+    const dim3 grid((unsigned)n_tokens), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == ZETT_F32) hipLaunchKernelGGL(gather_fwd_kernel<0>, grid, block, 0, st, ids, n_tokens, src, e_in, v0, fallback, sw, sb, x);
+    else if (src_dtype == ZETT_F16) hipLaunchKernelGGL(gather_fwd_kernel<1>, grid, block, 0, st, ids, n_tokens, src, e_in, v0, fallback, sw, sb, x);
+    else hipLaunchKernelGGL(gather_fwd_kernel<2>, grid, block, 0, st, ids, n_tokens, src, e_in, v0, fallback, sw, sb, x);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_gather_bwd_f32(const int32_t* ids, int64_t n_tokens, const void* src, int32_t src_dtype, int32_t e_in, int32_t v0, const float* dx,
+                           float* dfallback, float* prod, float* keep, void* stream) {
+    if (!ids || !src || !dx || !dfallback || !prod || !keep || src_dtype < ZETT_F32 || src_dtype > ZETT_BF16) return fail(ZETT_E_INVALID, "bad gather arguments");
+    if (n_tokens <= 0) return 0;
+    const dim3 grid((unsigned)n_tokens), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == ZETT_F32) hipLaunchKernelGGL(gather_bwd_kernel<0>, grid, block, 0, st, ids, n_tokens, src, e_in, v0, dx, dfallback, prod, keep);
+    else if (src_dtype == ZETT_F16) hipLaunchKernelGGL(gather_bwd_kernel<1>, grid, block, 0, st, ids, n_tokens, src, e_in, v0, dx, dfallback, prod, keep);
+    else hipLaunchKernelGGL(gather_bwd_kernel<2>, grid, block, 0, st, ids, n_tokens, src, e_in, v0, dx, dfallback, prod, keep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

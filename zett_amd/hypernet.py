@@ -310,6 +310,11 @@ class ZettHypernet(PreTrainedModel):
             lang = int(lang_index.item()) if torch.is_tensor(lang_index) else int(lang_index)
         else:
             lang = -1
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training use (train.py:1007-1013): the same forward, differentiable with respect to the parameters
+            # (zett_amd/autograd.py: fp32, HIP primitives through the C ABI)
+            from .autograd import differentiable_forward
+            return differentiable_forward(self, target_surface_forms, source_embeddings, lang)
         return self._guarded_forward(device, target_surface_forms, source_embeddings, lang)
 
     def _guarded_forward(self, device, surface_forms, source_embeddings, lang):
