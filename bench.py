@@ -428,6 +428,31 @@ def main():
                                            "bf16: rel-L2 ~0.97e-2 of the fp32 reference at this shape (tolerance 1e-2), f16: ~0.12e-2"}
         engine = main_engine
         alt_engine.close()
+    if world == 1 and args.precision != "f32" and not args.no_alt_precision and not args.rows:
+        # Side measurement, outside the timed region and never `value`: the same workload in exact fp32 MFMA arithmetic — the
+        # mode whose tolerance north_star names (max |err| <= 1e-4 relative to the row maximum against the fp32 reference).
+        engine.close()
+        torch.cuda.empty_cache()
+        f32_engine = HipEngine(dims, 1e-5, device, "f32")
+        f32_engine.load_weights(device_weights(cfg, device, seed=0))
+        f32_engine.set_option("time_gemm", 1)
+        engine = f32_engine
+        for key in acc:
+            acc[key] = 0
+        step()
+        torch.cuda.synchronize()
+        for key in acc:
+            acc[key] = 0
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        dt_f32 = time.perf_counter() - t1
+        f32_tf = acc["gemm_flops_timed"] / (acc["gemm_ms"] * 1e-3) / 1e12 if acc["gemm_ms"] > 0 else 0.0
+        result["f32_mode"] = {"dtype": "f32", "value": rows * 2 / dt_f32, "unit": "token-embeddings/s", "ms_per_step": dt_f32 / 2 * 1e3, "steps": 2,
+                              "gemm_tflops": f32_tf, "roofline_frac": f32_tf / PEAK_TFLOPS["f32"], "peak": PEAK_TFLOPS["f32"],
+                              "note": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32, gemm8r tile); measured after the timed region"}
+        f32_engine.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, ref_out, n_ref = cpu_baseline(cfg, weights_keep, ids_all, src, lang, args.cpu_budget_s)
         result["cpu_baseline"] = cb

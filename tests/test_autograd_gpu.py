@@ -149,7 +149,10 @@ def test_whole_hypernetwork_outputs_and_every_gradient(flags):
     model.precision = "f32"
     with torch.no_grad():
         inference = model(ids, source_embeddings=src, lang_index=None if lang is None else torch.tensor(lang))
-    model.requires_grad_(True)
+    model.requires_grad_(True).eval()
+    eval_out = model(ids, source_embeddings=src, lang_index=None if lang is None else torch.tensor(lang))
+    assert not eval_out[0].requires_grad                   # eval mode (what from_pretrained returns): the inference path, no graph
+    model.train()
     out = model(ids, source_embeddings=src, lang_index=None if lang is None else torch.tensor(lang))
     keep = ~util.all_pad_rows(cfg, ids_np)
     for got, inf, r, what in zip(out, inference, want, ("pred_in", "pred_out", "bias")):
@@ -194,7 +197,7 @@ def test_a_training_step_lowers_the_loss():
     cfg, w, src_np, ids_np = _case({}, seed=41, rows=64)
     model = ZettHypernet(ZettHypernetConfig(**cfg))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
-    model = model.to(DEV).requires_grad_(True)
+    model = model.to(DEV).requires_grad_(True).train()
     src, ids = torch.from_numpy(src_np).to(DEV), torch.from_numpy(ids_np).to(DEV)
     target = torch.randn(64, cfg["n_embd"], device=DEV, generator=torch.Generator(device=DEV).manual_seed(0)) * 0.05
     losses = []

@@ -28,6 +28,6 @@ def test_training_path_refuses_cpu_tensors():
     from zett_amd.config import ZettHypernetConfig
     from zett_amd.hypernet import ZettHypernet
     cfg, *_ = synth.workload("tiny")
-    model = ZettHypernet(ZettHypernetConfig(**cfg)).requires_grad_(True)
+    model = ZettHypernet(ZettHypernetConfig(**cfg)).requires_grad_(True).train()
     with pytest.raises(RuntimeError, match="MI355X"):
         model(torch.zeros(2, 7, dtype=torch.long), source_embeddings=torch.zeros(300, 128), lang_index=torch.tensor(0))

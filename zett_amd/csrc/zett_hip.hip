@@ -712,7 +712,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     // one), and a key space not much larger than the batch (a 250 k-id source vocabulary against 50 k rows repeats few pairs
     // and would pay for clearing and scanning 2 M flags).
     const int64_t PK = pair_keys(c, seq);
-    const bool pair_plan = h->pair_dedupe && c.layers >= 2 && PK <= 4 * max_tok && PK < (int64_t)0x7fffffff;
+    const bool pair_plan = h->pair_dedupe && c.layers >= 2 && PK <= std::max<int64_t>(4 * max_tok, (int64_t)1 << 23) && PK < (int64_t)0x7fffffff;
     if (pair_plan) {
         p.tok_pkey = base; base += max_tok;
         p.tok_pair = base; base += max_tok;

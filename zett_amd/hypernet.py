@@ -233,7 +233,7 @@ class ZettHypernet(PreTrainedModel):
         missing = [m for m in missing if m != "model.embeddings.word_embeddings.weight"]
         if missing or unexpected:
             raise ValueError(f"flax checkpoint does not match the config: missing {missing}, unexpected {list(unexpected)}")
-        return model
+        return model.eval()          # (as from_pretrained does)
 
     # ---- parameter initialisation (same distributions as the torch modules of the reference)
     def _reset_parameters(self) -> None:
@@ -310,9 +310,11 @@ class ZettHypernet(PreTrainedModel):
             lang = int(lang_index.item()) if torch.is_tensor(lang_index) else int(lang_index)
         else:
             lang = -1
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training use (train.py:1007-1013): the same forward, differentiable with respect to the parameters
-            # (zett_amd/autograd.py: fp32, HIP primitives through the C ABI)
+            # (zett_amd/autograd.py: fp32, HIP primitives through the C ABI).  Only in train() mode: a model that
+            # from_pretrained returned (eval mode, whatever its parameters' requires_grad flags say) predicts on the
+            # inference path, which builds no graph
             from .autograd import differentiable_forward
             return differentiable_forward(self, target_surface_forms, source_embeddings, lang)
         return self._guarded_forward(device, target_surface_forms, source_embeddings, lang)

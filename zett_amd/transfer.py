@@ -348,7 +348,9 @@ def main(argv=None):
     print(f"Truncated {n_truncated} tokens.")
 
     target_priors = target_priors_of(tokenizer)                                                          # :210-219
-    pred_in, pred_out, pred_bias = predict_vocabulary(hypernet, sfm.long(), source_embeddings, lang_index, args, target_priors)
+    hypernet.eval()
+    with torch.no_grad():          # inference: the pad-skipping / hoisting forward, no autograd graph
+        pred_in, pred_out, pred_bias = predict_vocabulary(hypernet, sfm.long(), source_embeddings, lang_index, args, target_priors)
 
     # every rank holds the whole prediction; the last collective is over.  The group is torn down HERE, so that no rank
     # sits in a barrier (and no watchdog runs) while rank 0 spends minutes writing a multi-GB model.
