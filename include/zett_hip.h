@@ -285,12 +285,19 @@ int zett_op_layernorm_bwd_f32(const float* dy, const float* x, int32_t ld, const
 /* kind 1: F.gelu(approximate="tanh") (modeling_hypernet.py:36-39), 2: erf form (RobertaIntermediate) */
 int zett_op_gelu_fwd_f32(const float* z, float* h, int64_t n, int32_t kind, void* stream);
 int zett_op_gelu_bwd_f32(const float* z, const float* dh, float* dz, int64_t n, int32_t kind, void* stream);
-/* softmax(q k^T / sqrt(d) + finfo.min * !mask) v per row and head over seq <= 32 positions (eager semantics: a row whose
- * keys are all masked attends uniformly); q, k, v: [n_rows * seq, ld]; probs [n_rows, heads, seq, seq] is kept for the backward */
-int zett_op_attention_fwd_f32(const float* q, const float* k, const float* v, int32_t ld, const uint8_t* mask, int64_t n_rows, int32_t seq,
-                              int32_t heads, int32_t head_dim, float* ctx, int32_t ld_ctx, float* probs, void* stream);
-int zett_op_attention_bwd_f32(const float* dctx, int32_t ld_ctx, const float* q, const float* k, const float* v, int32_t ld, const float* probs,
-                              int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, float* dq, float* dk, float* dv, int32_t ld_d, void* stream);
+/* softmax(q k^T / sqrt(d) + finfo.min * !mask) v per vocabulary row and head (eager semantics: a row whose keys are all
+ * masked attends uniformly).  The positions of row n are rows [row_offset[n], row_offset[n+1]) of k / v (packed: only the
+ * positions the row keeps) or [n*seq, (n+1)*seq) when row_offset is NULL (the reference's dense layout); at most seq <= 32
+ * positions per row; mask[t] = position t is visible as a key.  cls_only: one query per row (position 0), q and ctx hold
+ * one row per vocabulary row (the position-0-only last layer).  probs [n_rows, heads, seq, seq] is kept for the backward. */
+int zett_op_attention_fwd_f32(const float* q, int32_t ldq, const float* k, const float* v, int32_t ld, const uint8_t* mask, const int32_t* row_offset,
+                              int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, int32_t cls_only, float* ctx, int32_t ld_ctx, float* probs, void* stream);
+int zett_op_attention_bwd_f32(const float* dctx, int32_t ld_ctx, const float* q, int32_t ldq, const float* k, const float* v, int32_t ld, const float* probs,
+                              const int32_t* row_offset, int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, int32_t cls_only, float* dq, int32_t ld_dq,
+                              float* dk, float* dv, int32_t ld_d, void* stream);
+/* out[r, :] = a[r, :] + src[idx[r], :] (a NULL: 0);   dst[idx[r], :] += src[r, :] (atomic) */
+int zett_op_gather_rows_f32(const float* a, const float* src, int32_t ld_src, const int32_t* idx, float* out, int64_t rows, int32_t cols, void* stream);
+int zett_op_scatter_add_rows_f32(float* dst, int32_t ld_dst, const int32_t* idx, const float* src, int64_t rows, int32_t cols, void* stream);
 /* A2 + A3 (modeling_hypernet.py:170-188) per position, and its backward: dfallback accumulated in place (zero it first),
  * prod = dx * source row and keep = dx on source rows (0 on fallback rows): their column sums are d in_scaler.w / d in_scaler.b */
 int zett_op_gather_fwd_f32(const int32_t* ids, int64_t n_tokens, const void* src, int32_t src_dtype, int32_t e_in, int32_t v0, const float* fallback,

@@ -83,15 +83,65 @@ def test_attention_forward_backward_match_torch():
     mask[:, 0] = True
     mask[3] = False                                           # a row whose keys are all masked: uniform attention (eager semantics)
     dctx = torch.randn(n * L, H, device=DEV, generator=g)
-    ctx, probs = ops.attention(qkv.detach(), mask.to(torch.uint8), n, L, heads, H)
+    qd = qkv.detach()
+    ctx, probs = ops.attention(qd[:, :H], qd[:, H:2 * H], qd[:, 2 * H:], mask.to(torch.uint8).view(-1), None, n, L, heads, H)
     q, k, v = [t.view(n, L, heads, d).transpose(1, 2) for t in qkv.double().split(H, dim=1)]
     bias = torch.where(mask, 0.0, torch.finfo(torch.float32).min).double()[:, None, None, :]
     p = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5 + bias, -1)
     ref = (p @ v).transpose(1, 2).reshape(n * L, H)
     assert _rel(ctx, ref) < 2e-6 and float((probs[3] - 1.0 / L).abs().max()) < 1e-6
     ref.backward(dctx.double())
-    dqkv = ops.attention_bwd(dctx, qkv.detach(), probs, n, L, heads, H)
+    dqkv = torch.empty_like(qd)
+    ops.attention_bwd(dctx, qd[:, :H], qd[:, H:2 * H], qd[:, 2 * H:], probs, None, n, L, heads, H, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:])
     assert _rel(dqkv, qkv.grad) < 2e-5
+    # packed rows (each row keeps its own number of positions) and the position-0-only query of the last layer
+    lens = torch.randint(1, L + 1, (n,), generator=torch.Generator().manual_seed(4))
+    off = torch.zeros(n + 1, dtype=torch.int32)
+    off[1:] = lens.cumsum(0)
+    T = int(off[-1])
+    pq = torch.randn(T, 3 * H, device=DEV, generator=g).requires_grad_(True)
+    pmask = torch.rand(T, device=DEV, generator=g) < 0.7
+    offd = off.to(DEV)
+    pctx, pprobs = ops.attention(pq.detach()[:, :H], pq.detach()[:, H:2 * H], pq.detach()[:, 2 * H:], pmask.to(torch.uint8), offd, n, L, heads, H)
+    refs = []
+    for r in range(n):
+        a, b = int(off[r]), int(off[r + 1])
+        qq, kk, vv = [t.view(b - a, heads, d).transpose(0, 1) for t in pq[a:b].double().split(H, dim=1)]
+        bb = torch.where(pmask[a:b], 0.0, torch.finfo(torch.float32).min).double()[None, None, :]
+        refs.append((torch.softmax(qq @ kk.transpose(-1, -2) * d ** -0.5 + bb, -1) @ vv).transpose(0, 1).reshape(b - a, H))
+    pref = torch.cat(refs)
+    assert _rel(pctx, pref) < 2e-6
+    dpc = torch.randn(T, H, device=DEV, generator=g)
+    pref.backward(dpc.double())
+    dpq = torch.empty(T, 3 * H, device=DEV)
+    pd = pq.detach()
+    ops.attention_bwd(dpc, pd[:, :H], pd[:, H:2 * H], pd[:, 2 * H:], pprobs, offd, n, L, heads, H, dpq[:, :H], dpq[:, H:2 * H], dpq[:, 2 * H:])
+    assert _rel(dpq, pq.grad) < 2e-5
+    q1 = torch.randn(n, H, device=DEV, generator=g).requires_grad_(True)          # one query per row (position 0)
+    kv = torch.randn(T, 2 * H, device=DEV, generator=g).requires_grad_(True)
+    cctx, cprobs = ops.attention(q1.detach(), kv.detach()[:, :H], kv.detach()[:, H:], pmask.to(torch.uint8), offd, n, L, heads, H, cls_only=True)
+    refs = []
+    for r in range(n):
+        a, b = int(off[r]), int(off[r + 1])
+        qq = q1[r].double().view(heads, 1, d)
+        kk, vv = [t.view(b - a, heads, d).transpose(0, 1) for t in kv[a:b].double().split(H, dim=1)]
+        bb = torch.where(pmask[a:b], 0.0, torch.finfo(torch.float32).min).double()[None, None, :]
+        refs.append((torch.softmax(qq @ kk.transpose(-1, -2) * d ** -0.5 + bb, -1) @ vv).reshape(1, H))
+    cref = torch.cat(refs)
+    assert _rel(cctx, cref) < 2e-6
+    dcc = torch.randn(n, H, device=DEV, generator=g)
+    cref.backward(dcc.double())
+    dq1, dkv = torch.empty(n, H, device=DEV), torch.empty(T, 2 * H, device=DEV)
+    ops.attention_bwd(dcc, q1.detach(), kv.detach()[:, :H], kv.detach()[:, H:], cprobs, offd, n, L, heads, H, dq1, dkv[:, :H], dkv[:, H:], cls_only=True)
+    assert _rel(dq1, q1.grad) < 2e-5 and _rel(dkv, kv.grad) < 2e-5
+    # indexed rows
+    src = torch.randn(40, 96, device=DEV, generator=g)
+    idx = torch.randint(0, 40, (300,), device=DEV, generator=g, dtype=torch.int32)
+    a = torch.randn(300, 96, device=DEV, generator=g)
+    assert torch.equal(ops.gather_rows(src, idx), src[idx.long()]) and torch.equal(ops.gather_rows(src, idx, a), a + src[idx.long()])
+    dst = torch.zeros(40, 96, device=DEV)
+    ops.scatter_add_rows(dst, idx, a)
+    assert _rel(dst, torch.zeros(40, 96, device=DEV, dtype=torch.float64).index_add_(0, idx.long(), a.double())) < 1e-6
 
 
 def test_gather_forward_backward_match_torch():
@@ -128,8 +178,11 @@ FLAGS = [dict(), dict(hn_embed_lang_id=False), dict(separate_out_embeddings=Fals
          dict(hn_rescale_embeddings=False), dict(hn_predict_bias=False), dict(hn_single_head=True, separate_out_embeddings=False, hn_embed_lang_id=False)]
 
 
+@pytest.mark.parametrize("packed", [True, False], ids=["packed", "dense"])
 @pytest.mark.parametrize("flags", FLAGS, ids=lambda f: "+".join(f"{k[3:] if k.startswith('hn_') else k}={int(v)}" for k, v in f.items()) or "default")
-def test_whole_hypernetwork_outputs_and_every_gradient(flags):
+def test_whole_hypernetwork_outputs_and_every_gradient(flags, packed):
+    """packed: the inference path's schedule (pad skipping, input projection per distinct id, position-0-only last layer);
+    dense: the reference's layout.  Both must reproduce float64 torch autograd of the as-written math."""
     from oracle import hypernet_ref
     from zett_amd.config import ZettHypernetConfig
     from zett_amd.hypernet import ZettHypernet
@@ -153,6 +206,7 @@ def test_whole_hypernetwork_outputs_and_every_gradient(flags):
     eval_out = model(ids, source_embeddings=src, lang_index=None if lang is None else torch.tensor(lang))
     assert not eval_out[0].requires_grad                   # eval mode (what from_pretrained returns): the inference path, no graph
     model.train()
+    model.train_packed = packed
     out = model(ids, source_embeddings=src, lang_index=None if lang is None else torch.tensor(lang))
     keep = ~util.all_pad_rows(cfg, ids_np)
     for got, inf, r, what in zip(out, inference, want, ("pred_in", "pred_out", "bias")):

@@ -15,9 +15,12 @@ the two GELUs, masked attention and the source-embedding gather have forward and
 tensors and the autograd tape, allocates, slices and concatenates (layout plumbing, parameter-sized glue); it computes
 nothing of size O(rows x hidden).  There is no CPU path.
 
-What this slice does not do yet: the 16-bit MFMA modes, and the exact levers of the inference path (pad skipping, the
-per-distinct-id input projection, the position-0-only last layer) — all of them exact for gradients too (a position
-that cannot influence hidden[:, 0] receives a zero gradient), so they are a schedule change, not a change of results.
+Two schedules, same results to fp32 round-off (tests/test_autograd_gpu.py holds both to float64 torch autograd):
+``forward_train`` / ``backward_train`` is the reference's dense layout, every position computed; ``forward_packed`` /
+``backward_packed`` (the default) is the inference path's schedule — pad skipping, the input projection once per distinct
+referenced id, the position-0-only last layer: exact for gradients too (a position that cannot influence hidden[:, 0]
+receives a zero gradient; a value computed once and used k times receives the sum of the k gradients), 3.3x fewer FLOPs on
+the headline workload.  Not yet: the 16-bit MFMA modes.
 """
 from __future__ import annotations
 
@@ -139,24 +142,38 @@ class Ops:
         _lib.check(self.lib.zett_op_gelu_bwd_f32(_ptr(z), _ptr(dh), _ptr(dz), z.numel(), kind, self._stream()), "zett_op_gelu_bwd_f32")
         return dz
 
-    def attention(self, qkv, mask, n, seq, heads, hidden):
-        """qkv [n*seq, 3H] (q | k | v), mask uint8 [n, seq] -> ctx [n*seq, H], probs [n, heads, seq, seq]"""
+    def attention(self, q, k, v, mask, row_offset, n_rows, seq, heads, hidden, cls_only=False):
+        """q [Tq, *] (Tq = positions, or n_rows when cls_only), k / v [T, *] column views, mask uint8 [T] (key visible),
+        row_offset int32 [n_rows + 1] or None (dense: seq positions per row) -> ctx [Tq, H], probs [n_rows, heads, seq, seq]"""
+        assert k.stride(0) == v.stride(0) and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
         d = hidden // heads
-        ctx, probs = self.new(n * seq, hidden), self.new(n, heads, seq, seq)
-        q, k, v = qkv[:, :hidden], qkv[:, hidden:2 * hidden], qkv[:, 2 * hidden:]
-        _lib.check(self.lib.zett_op_attention_fwd_f32(_ptr(q), _ptr(k), _ptr(v), qkv.stride(0), _ptr(mask), n, seq, heads, d, _ptr(ctx), hidden,
-                                                      _ptr(probs), self._stream()), "zett_op_attention_fwd_f32")
+        ctx, probs = self.new(q.shape[0], hidden), torch.zeros((n_rows, heads, seq, seq), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.zett_op_attention_fwd_f32(_ptr(q), q.stride(0), _ptr(k), _ptr(v), k.stride(0), _ptr(mask), _ptr(row_offset), n_rows, seq, heads, d,
+                                                      int(cls_only), _ptr(ctx), hidden, _ptr(probs), self._stream()), "zett_op_attention_fwd_f32")
         return ctx, probs
 
-    def attention_bwd(self, dctx, qkv, probs, n, seq, heads, hidden):
+    def attention_bwd(self, dctx, q, k, v, probs, row_offset, n_rows, seq, heads, hidden, dq, dk, dv, cls_only=False):
+        """writes dq (rows like q), dk / dv (rows like k; column views of one buffer with equal row stride)"""
+        assert dctx.is_contiguous() and dk.stride(0) == dv.stride(0)
         d = hidden // heads
-        dqkv = self.new(n * seq, 3 * hidden)
-        q, k, v = qkv[:, :hidden], qkv[:, hidden:2 * hidden], qkv[:, 2 * hidden:]
-        dq, dk, dv = dqkv[:, :hidden], dqkv[:, hidden:2 * hidden], dqkv[:, 2 * hidden:]
-        assert dctx.is_contiguous()
-        _lib.check(self.lib.zett_op_attention_bwd_f32(_ptr(dctx), hidden, _ptr(q), _ptr(k), _ptr(v), qkv.stride(0), _ptr(probs), n, seq, heads, d,
-                                                      _ptr(dq), _ptr(dk), _ptr(dv), 3 * hidden, self._stream()), "zett_op_attention_bwd_f32")
-        return dqkv
+        _lib.check(self.lib.zett_op_attention_bwd_f32(_ptr(dctx), hidden, _ptr(q), q.stride(0), _ptr(k), _ptr(v), k.stride(0), _ptr(probs), _ptr(row_offset),
+                                                      n_rows, seq, heads, d, int(cls_only), _ptr(dq), dq.stride(0), _ptr(dk), _ptr(dv), dk.stride(0),
+                                                      self._stream()), "zett_op_attention_bwd_f32")
+
+    def gather_rows(self, src, idx, a=None):
+        """out[r] = (a[r] if a is given else 0) + src[idx[r]]"""
+        assert src.stride(1) == 1 and idx.dtype == torch.int32 and (a is None or a.is_contiguous())
+        out = self.new(idx.numel(), src.shape[1])
+        _lib.check(self.lib.zett_op_gather_rows_f32(_ptr(a), _ptr(src), src.stride(0), _ptr(idx), _ptr(out), idx.numel(), src.shape[1], self._stream()),
+                   "zett_op_gather_rows_f32")
+        return out
+
+    def scatter_add_rows(self, dst, idx, src):
+        """dst[idx[r]] += src[r] (in place; dst must be initialised)"""
+        assert dst.stride(1) == 1 and src.is_contiguous() and idx.dtype == torch.int32 and idx.numel() == src.shape[0]
+        _lib.check(self.lib.zett_op_scatter_add_rows_f32(_ptr(dst), dst.stride(0), _ptr(idx), _ptr(src), idx.numel(), src.shape[1], self._stream()),
+                   "zett_op_scatter_add_rows_f32")
+        return dst
 
     def gather(self, ids, src, v0, fallback, sw, sb):
         t = ids.numel()
@@ -205,6 +222,83 @@ def _projector_bwd(ops: Ops, P, G, prefix, saved, dy):
     return ops.add(dx, ds)          # the residual branch
 
 
+def _heads_fwd(ops: Ops, dims: HypernetDims, P, S, cls, n, device):
+    """CLS -> output heads, Rescalers, bias head (modeling_hypernet.py:231-267) -> (pred_in, pred_out | None, bias)"""
+    e = dims.n_embd
+    h_in, S["pb_out0"] = _projector_fwd(ops, P, "output_projection.0.", cls)
+    S["h_in"] = h_in
+    pred = ops.gemm(h_in, P["output_projection.1.weight"], P["output_projection.1.bias"])
+    S["pred_raw"] = pred
+    pred_out = None
+    if dims.single_head:
+        if dims.rescale:
+            scale = torch.cat([P["scaler.w"].reshape(-1)] + ([P["out_scaler.w"].reshape(-1)] if dims.separate_out else []))
+            shift = torch.cat([P["scaler.b"].reshape(-1)] + ([P["out_scaler.b"].reshape(-1)] if dims.separate_out else []))
+            pred = ops.affine_cols(pred, scale, shift)
+        pred_in = pred[:, :e].contiguous()
+        pred_out = pred[:, e:].contiguous() if dims.separate_out else None
+    else:
+        pred_in = ops.affine_cols(pred, P["scaler.w"].reshape(-1), P["scaler.b"].reshape(-1)) if dims.rescale else pred
+        if dims.separate_out:
+            h_out, S["pb_out1"] = _projector_fwd(ops, P, "output_projection_out.0.", cls)
+            S["h_out"] = h_out
+            po = ops.gemm(h_out, P["output_projection_out.1.weight"], P["output_projection_out.1.bias"])
+            S["pred_out_raw"] = po
+            pred_out = ops.affine_cols(po, P["out_scaler.w"].reshape(-1), P["out_scaler.b"].reshape(-1)) if dims.rescale else po
+    if dims.predict_bias:
+        bias = ops.rowdot(cls, P["bias_projection.weight"].reshape(-1), P["bias_projection.bias"].reshape(-1))
+    else:
+        bias = torch.zeros((n,), dtype=torch.float32, device=device)
+    return pred_in, pred_out, bias
+
+
+def _heads_bwd(ops: Ops, dims: HypernetDims, P, S, G, n, d_in, d_out, d_bias):
+    """Backward of _heads_fwd: fills G for the heads' parameters, returns the gradient of hidden[:, 0] [n, H]"""
+    e = dims.n_embd
+    cls = S["cls"]
+    dev = cls.device
+    zeros = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    d_in = zeros(n, e) if d_in is None else d_in.contiguous().float()
+    if dims.separate_out:
+        d_out = zeros(n, e) if d_out is None else d_out.contiguous().float()
+    # ---- heads
+    if dims.single_head:
+        dpred = torch.cat([d_in, d_out], 1).contiguous() if dims.separate_out else d_in
+        if dims.rescale:
+            raw = S["pred_raw"]
+            gw, gb = ops.colsum(ops.mul(dpred, raw)), ops.colsum(dpred)
+            G["scaler.w"], G["scaler.b"] = gw[:e].reshape(1, -1).clone(), gb[:e].reshape(1, -1).clone()
+            if dims.separate_out:
+                G["out_scaler.w"], G["out_scaler.b"] = gw[e:].reshape(1, -1).clone(), gb[e:].reshape(1, -1).clone()
+            scale = torch.cat([P["scaler.w"].reshape(-1)] + ([P["out_scaler.w"].reshape(-1)] if dims.separate_out else []))
+            dpred = ops.affine_cols(dpred, scale, None)
+        dh, G["output_projection.1.weight"], G["output_projection.1.bias"] = ops.linear_bwd(dpred, S["h_in"], P["output_projection.1.weight"])
+        dcls = _projector_bwd(ops, P, G, "output_projection.0.", S["pb_out0"], dh)
+    else:
+        dpred = d_in
+        if dims.rescale:
+            G["scaler.w"] = ops.colsum(ops.mul(dpred, S["pred_raw"])).reshape(1, -1)
+            G["scaler.b"] = ops.colsum(dpred).reshape(1, -1)
+            dpred = ops.affine_cols(dpred, P["scaler.w"].reshape(-1), None)
+        dh, G["output_projection.1.weight"], G["output_projection.1.bias"] = ops.linear_bwd(dpred, S["h_in"], P["output_projection.1.weight"])
+        dcls = _projector_bwd(ops, P, G, "output_projection.0.", S["pb_out0"], dh)
+        if dims.separate_out:
+            dpo = d_out
+            if dims.rescale:
+                G["out_scaler.w"] = ops.colsum(ops.mul(dpo, S["pred_out_raw"])).reshape(1, -1)
+                G["out_scaler.b"] = ops.colsum(dpo).reshape(1, -1)
+                dpo = ops.affine_cols(dpo, P["out_scaler.w"].reshape(-1), None)
+            dh2, G["output_projection_out.1.weight"], G["output_projection_out.1.bias"] = ops.linear_bwd(dpo, S["h_out"], P["output_projection_out.1.weight"])
+            dcls = ops.add(dcls, _projector_bwd(ops, P, G, "output_projection_out.0.", S["pb_out1"], dh2))
+    if dims.predict_bias:
+        db = zeros(n) if d_bias is None else d_bias.contiguous().float()
+        wb = P["bias_projection.weight"].reshape(-1)
+        G["bias_projection.weight"] = ops.colsum(ops.scale_rows(cls, db)).reshape(1, -1)
+        G["bias_projection.bias"] = db.view(1, -1).sum(1) if n == 0 else ops.colsum(db.view(-1, 1)).reshape(1)
+        dcls = ops.add_outer(dcls, db, wb)
+    return dcls
+
+
 def forward_train(ops: Ops, dims: HypernetDims, ln_eps: float, P: Dict[str, torch.Tensor], ids: torch.Tensor, src: torch.Tensor, lang: int):
     """The as-written forward (modeling_hypernet.py:156-267) on HIP primitives, keeping what the backward needs.
     -> (pred_in, pred_out | None, bias), saved"""
@@ -244,7 +338,7 @@ def forward_train(ops: Ops, dims: HypernetDims, ln_eps: float, P: Dict[str, torc
         wqkv = torch.cat([P[a + "query.weight"], P[a + "key.weight"], P[a + "value.weight"]], 0)      # fused operand (parameter plumbing)
         bqkv = torch.cat([P[a + "query.bias"], P[a + "key.bias"], P[a + "value.bias"]], 0)
         qkv = ops.gemm(z, wqkv, bqkv)
-        ctx, probs = ops.attention(qkv, mask, n, Lp, dims.heads, H)
+        ctx, probs = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask.view(-1), None, n, Lp, dims.heads, H)
         s1 = ops.gemm(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"], residual=z)
         z1, st1 = ops.layernorm(s1, P[p + "attention.output.LayerNorm.weight"], P[p + "attention.output.LayerNorm.bias"], ln_eps)
         u = ops.gemm(z1, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"])
@@ -256,32 +350,7 @@ def forward_train(ops: Ops, dims: HypernetDims, ln_eps: float, P: Dict[str, torc
     S["layers"] = layers
     cls = z.view(n, Lp, H)[:, 0].contiguous()                                # hidden[:, 0] (modeling_hypernet.py:234)
     S["cls"] = cls
-    e = dims.n_embd
-    h_in, S["pb_out0"] = _projector_fwd(ops, P, "output_projection.0.", cls)
-    S["h_in"] = h_in
-    pred = ops.gemm(h_in, P["output_projection.1.weight"], P["output_projection.1.bias"])
-    S["pred_raw"] = pred
-    pred_out = None
-    if dims.single_head:
-        if dims.rescale:
-            scale = torch.cat([P["scaler.w"].reshape(-1)] + ([P["out_scaler.w"].reshape(-1)] if dims.separate_out else []))
-            shift = torch.cat([P["scaler.b"].reshape(-1)] + ([P["out_scaler.b"].reshape(-1)] if dims.separate_out else []))
-            pred = ops.affine_cols(pred, scale, shift)
-        pred_in = pred[:, :e].contiguous()
-        pred_out = pred[:, e:].contiguous() if dims.separate_out else None
-    else:
-        pred_in = ops.affine_cols(pred, P["scaler.w"].reshape(-1), P["scaler.b"].reshape(-1)) if dims.rescale else pred
-        if dims.separate_out:
-            h_out, S["pb_out1"] = _projector_fwd(ops, P, "output_projection_out.0.", cls)
-            S["h_out"] = h_out
-            po = ops.gemm(h_out, P["output_projection_out.1.weight"], P["output_projection_out.1.bias"])
-            S["pred_out_raw"] = po
-            pred_out = ops.affine_cols(po, P["out_scaler.w"].reshape(-1), P["out_scaler.b"].reshape(-1)) if dims.rescale else po
-    if dims.predict_bias:
-        bias = ops.rowdot(cls, P["bias_projection.weight"].reshape(-1), P["bias_projection.bias"].reshape(-1))
-    else:
-        bias = torch.zeros((n,), dtype=torch.float32, device=ids.device)
-    return (pred_in, pred_out, bias), S
+    return _heads_fwd(ops, dims, P, S, cls, n, ids.device), S
 
 
 def backward_train(ops: Ops, dims: HypernetDims, P: Dict[str, torch.Tensor], S, src: torch.Tensor, lang: int,
@@ -293,45 +362,7 @@ def backward_train(ops: Ops, dims: HypernetDims, P: Dict[str, torch.Tensor], S, 
     Lp, H, e = L + lam, dims.hidden, dims.n_embd
     dev = S["cls"].device
     zeros = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-    d_in = zeros(n, e) if d_in is None else d_in.contiguous().float()
-    if dims.separate_out:
-        d_out = zeros(n, e) if d_out is None else d_out.contiguous().float()
-    cls = S["cls"]
-    # ---- heads
-    if dims.single_head:
-        dpred = torch.cat([d_in, d_out], 1).contiguous() if dims.separate_out else d_in
-        if dims.rescale:
-            raw = S["pred_raw"]
-            gw, gb = ops.colsum(ops.mul(dpred, raw)), ops.colsum(dpred)
-            G["scaler.w"], G["scaler.b"] = gw[:e].reshape(1, -1).clone(), gb[:e].reshape(1, -1).clone()
-            if dims.separate_out:
-                G["out_scaler.w"], G["out_scaler.b"] = gw[e:].reshape(1, -1).clone(), gb[e:].reshape(1, -1).clone()
-            scale = torch.cat([P["scaler.w"].reshape(-1)] + ([P["out_scaler.w"].reshape(-1)] if dims.separate_out else []))
-            dpred = ops.affine_cols(dpred, scale, None)
-        dh, G["output_projection.1.weight"], G["output_projection.1.bias"] = ops.linear_bwd(dpred, S["h_in"], P["output_projection.1.weight"])
-        dcls = _projector_bwd(ops, P, G, "output_projection.0.", S["pb_out0"], dh)
-    else:
-        dpred = d_in
-        if dims.rescale:
-            G["scaler.w"] = ops.colsum(ops.mul(dpred, S["pred_raw"])).reshape(1, -1)
-            G["scaler.b"] = ops.colsum(dpred).reshape(1, -1)
-            dpred = ops.affine_cols(dpred, P["scaler.w"].reshape(-1), None)
-        dh, G["output_projection.1.weight"], G["output_projection.1.bias"] = ops.linear_bwd(dpred, S["h_in"], P["output_projection.1.weight"])
-        dcls = _projector_bwd(ops, P, G, "output_projection.0.", S["pb_out0"], dh)
-        if dims.separate_out:
-            dpo = d_out
-            if dims.rescale:
-                G["out_scaler.w"] = ops.colsum(ops.mul(dpo, S["pred_out_raw"])).reshape(1, -1)
-                G["out_scaler.b"] = ops.colsum(dpo).reshape(1, -1)
-                dpo = ops.affine_cols(dpo, P["out_scaler.w"].reshape(-1), None)
-            dh2, G["output_projection_out.1.weight"], G["output_projection_out.1.bias"] = ops.linear_bwd(dpo, S["h_out"], P["output_projection_out.1.weight"])
-            dcls = ops.add(dcls, _projector_bwd(ops, P, G, "output_projection_out.0.", S["pb_out1"], dh2))
-    if dims.predict_bias:
-        db = zeros(n) if d_bias is None else d_bias.contiguous().float()
-        wb = P["bias_projection.weight"].reshape(-1)
-        G["bias_projection.weight"] = ops.colsum(ops.scale_rows(cls, db)).reshape(1, -1)
-        G["bias_projection.bias"] = db.view(1, -1).sum(1) if n == 0 else ops.colsum(db.view(-1, 1)).reshape(1)
-        dcls = ops.add_outer(dcls, db, wb)
+    dcls = _heads_bwd(ops, dims, P, S, G, n, d_in, d_out, d_bias)
     # ---- encoder (only position 0 of the last hidden state carries a gradient)
     dz = zeros(n, Lp, H)
     dz[:, 0] = dcls                                                       # layout plumbing
@@ -348,7 +379,10 @@ def backward_train(ops: Ops, dims: HypernetDims, P: Dict[str, torch.Tensor], S, 
         ds1, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
             ops.layernorm_bwd(dz1, A["s1"], A["st1"], P[p + "attention.output.LayerNorm.weight"])
         dctx, G[p + "attention.output.dense.weight"], G[p + "attention.output.dense.bias"] = ops.linear_bwd(ds1, A["ctx"], P[p + "attention.output.dense.weight"])
-        dqkv = ops.attention_bwd(dctx, A["qkv"], A["probs"], n, Lp, dims.heads, H)
+        dqkv = ops.new(n * Lp, 3 * H)
+        qkv = A["qkv"]
+        ops.attention_bwd(dctx, qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], A["probs"], None, n, Lp, dims.heads, H,
+                          dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:])
         dzin, dwqkv, dbqkv = ops.linear_bwd(dqkv, A["z"], A["wqkv"])
         for i, name in enumerate(("query", "key", "value")):
             G[a + name + ".weight"] = dwqkv[i * H:(i + 1) * H].clone()
@@ -378,16 +412,184 @@ def backward_train(ops: Ops, dims: HypernetDims, P: Dict[str, torch.Tensor], S, 
     return G
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# The same forward on the PACKED schedule of the inference path: three of its exact levers are exact for gradients too —
+# a position that cannot influence hidden[:, 0] receives a zero gradient, and a value computed once and used k times gets
+# the sum of the k gradients.
+#   1. pad skipping: a row keeps position 0, its non-pad positions and the language token (all-masked rows keep all L);
+#   2. the input projection once per DISTINCT referenced source id (gradients of the uses are scatter-added);
+#   3. the last layer computes K / V for every kept position and Q / O-proj / FFN / LayerNorms for position 0 only.
+# (Lever 4, layer 0's Q/K/V per distinct (id, position) pair, is left to the inference path.)
+def plan_packed(ids: torch.Tensor, pad: int, lam: int):
+    """Integer plumbing on the device: which positions a row keeps.  -> dict of int32 / uint8 tensors"""
+    n, L = ids.shape
+    vis = ids != pad
+    uniform = (~vis).all(1) & (lam == 0)              # every key masked: uniform attention over ALL L positions (eager semantics)
+    keep = vis | uniform[:, None]
+    keep[:, 0] = True                                 # position 0 is the query that is read out, pad or not
+    if lam:
+        one = torch.ones((n, 1), dtype=torch.bool, device=ids.device)
+        keep, vis = torch.cat([keep, one], 1), torch.cat([vis, one], 1)
+    tok_row, tok_pos = keep.nonzero(as_tuple=True)    # row-major: sorted by row, then position
+    counts = keep.sum(1)
+    row_offset = torch.zeros(n + 1, dtype=torch.int32, device=ids.device)
+    row_offset[1:] = counts.cumsum(0)
+    return dict(tok_row=tok_row, tok_pos=tok_pos.to(torch.int32), tok_key=vis[tok_row, tok_pos].to(torch.uint8).contiguous(),
+                row_offset=row_offset, cls=row_offset[:-1].contiguous(), n_tokens=int(tok_row.numel()), max_len=int(counts.max()))
+
+
+def forward_packed(ops: Ops, dims: HypernetDims, ln_eps: float, P, ids: torch.Tensor, src: torch.Tensor, lang: int):
+    n, L = ids.shape
+    lam = 1 if dims.embed_lang else 0
+    Lp, H = L + lam, dims.hidden
+    for name, width in (("n_embd", dims.n_embd), ("n_in_embd", dims.n_in_embd), ("hidden", H), ("intermediate", dims.intermediate)):
+        if width % K_STEP:
+            raise NotImplementedError(f"{name} = {width}: the fp32 training GEMM contracts over multiples of {K_STEP}")
+    S = dict(packed=True)
+    plan = plan_packed(ids, dims.pad_token_id, lam)
+    S["plan"] = plan
+    T, seq = plan["n_tokens"], plan["max_len"]
+    # ---- lever 2: the input projection per distinct referenced id
+    is_tok = plan["tok_pos"] < L
+    tok_ids = ids[plan["tok_row"][is_tok], plan["tok_pos"][is_tok].long()]
+    uniq, inv = torch.unique(tok_ids, return_inverse=True)
+    uniq32 = uniq.to(torch.int32).contiguous()
+    S["uniq"] = uniq32
+    sw = P["in_scaler.w"].reshape(-1) if dims.rescale else None
+    sb = P["in_scaler.b"].reshape(-1) if dims.rescale else None
+    x0 = ops.gather(uniq32, src, dims.original_vocab_size, P["fallback_embeddings.weight"], sw, sb)      # [D, E_in]
+    y0 = ops.gemm(x0, P["input_projection.0.weight"], P["input_projection.0.bias"])
+    table, S["pb_in"] = _projector_fwd(ops, P, "input_projection.1.", y0)
+    S["x0"] = x0
+    d_ids = table.shape[0]
+    type0 = P["model.embeddings.token_type_embeddings.weight"][0]
+    pos = P["model.embeddings.position_embeddings.weight"]
+    slot = torch.full((T,), d_ids, dtype=torch.int32, device=ids.device)       # the language token takes the extra row
+    slot[is_tok] = inv.to(torch.int32)
+    S["slot"] = slot
+    if lam:
+        table = torch.cat([table, (P["lang_embeddings.weight"][lang] - (type0 + pos[L]))[None, :]], 0)      # parameter-sized glue
+    posadd = (type0[None, :] + pos[:Lp]).contiguous()
+    emb = ops.gather_rows(posadd, plan["tok_pos"], ops.gather_rows(table, slot))        # table[slot] + (type + position)
+    z, st = ops.layernorm(emb, P["model.embeddings.LayerNorm.weight"], P["model.embeddings.LayerNorm.bias"], ln_eps)
+    S["emb"], S["emb_st"] = emb, st
+    off, key = plan["row_offset"], plan["tok_key"]
+    layers = []
+    for l in range(dims.layers):
+        p = f"model.encoder.layer.{l}."
+        a = p + "attention.self."
+        last = l == dims.layers - 1
+        wqkv = torch.cat([P[a + "query.weight"], P[a + "key.weight"], P[a + "value.weight"]], 0)
+        bqkv = torch.cat([P[a + "query.bias"], P[a + "key.bias"], P[a + "value.bias"]], 0)
+        A = dict(z=z, wqkv=wqkv)
+        if not last:
+            qkv = ops.gemm(z, wqkv, bqkv)
+            ctx, probs = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], key, off, n, seq, dims.heads, H)
+            res = z
+            A.update(qkv=qkv)
+        else:
+            # ---- lever 3: keys / values for every kept position, the query (and everything behind it) for position 0 only
+            kv = ops.gemm(z, wqkv[H:], bqkv[H:])
+            zc = ops.gather_rows(z, plan["cls"])
+            qc = ops.gemm(zc, wqkv[:H], bqkv[:H])
+            ctx, probs = ops.attention(qc, kv[:, :H], kv[:, H:], key, off, n, seq, dims.heads, H, cls_only=True)
+            res = zc
+            A.update(kv=kv, zc=zc, qc=qc)
+        s1 = ops.gemm(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"], residual=res)
+        z1, st1 = ops.layernorm(s1, P[p + "attention.output.LayerNorm.weight"], P[p + "attention.output.LayerNorm.bias"], ln_eps)
+        u = ops.gemm(z1, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"])
+        g = ops.gelu(u, GELU_ERF)
+        s2 = ops.gemm(g, P[p + "output.dense.weight"], P[p + "output.dense.bias"], residual=z1)
+        z, st2 = ops.layernorm(s2, P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], ln_eps)
+        A.update(probs=probs, ctx=ctx, s1=s1, st1=st1, z1=z1, u=u, g=g, s2=s2, st2=st2)
+        layers.append(A)
+    S["layers"] = layers
+    S["seq"] = seq
+    cls = z                                            # [n, H]: the last layer ran on position 0 only
+    S["cls"] = cls
+    S["ids"] = ids
+    return _heads_fwd(ops, dims, P, S, cls, n, ids.device), S
+
+
+def backward_packed(ops: Ops, dims: HypernetDims, P, S, src, lang, d_in, d_out, d_bias):
+    G: Dict[str, torch.Tensor] = {}
+    ids = S["ids"]
+    n, L = ids.shape
+    lam = 1 if dims.embed_lang else 0
+    Lp, H = L + lam, dims.hidden
+    plan, seq = S["plan"], S["seq"]
+    T = plan["n_tokens"]
+    off = plan["row_offset"]
+    dev = ids.device
+    dz = _heads_bwd(ops, dims, P, S, G, n, d_in, d_out, d_bias)              # [n, H]: gradient of hidden[:, 0]
+    for l in reversed(range(dims.layers)):
+        p = f"model.encoder.layer.{l}."
+        a = p + "attention.self."
+        A = S["layers"][l]
+        last = l == dims.layers - 1
+        ds2, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = ops.layernorm_bwd(dz, A["s2"], A["st2"], P[p + "output.LayerNorm.weight"])
+        dg, G[p + "output.dense.weight"], G[p + "output.dense.bias"] = ops.linear_bwd(ds2, A["g"], P[p + "output.dense.weight"])
+        du = ops.gelu_bwd(A["u"], dg, GELU_ERF)
+        dz1, G[p + "intermediate.dense.weight"], G[p + "intermediate.dense.bias"] = ops.linear_bwd(du, A["z1"], P[p + "intermediate.dense.weight"])
+        dz1 = ops.add(dz1, ds2)
+        ds1, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
+            ops.layernorm_bwd(dz1, A["s1"], A["st1"], P[p + "attention.output.LayerNorm.weight"])
+        dctx, G[p + "attention.output.dense.weight"], G[p + "attention.output.dense.bias"] = ops.linear_bwd(ds1, A["ctx"], P[p + "attention.output.dense.weight"])
+        wqkv = A["wqkv"]
+        if not last:
+            qkv = A["qkv"]
+            dqkv = ops.new(T, 3 * H)
+            ops.attention_bwd(dctx, qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], A["probs"], off, n, seq, dims.heads, H,
+                              dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:])
+            dzin, dwqkv, dbqkv = ops.linear_bwd(dqkv, A["z"], wqkv)
+            dz = ops.add(dzin, ds1)
+        else:
+            kv, qc = A["kv"], A["qc"]
+            dqc, dkv = ops.new(n, H), ops.new(T, 2 * H)
+            ops.attention_bwd(dctx, qc, kv[:, :H], kv[:, H:], A["probs"], off, n, seq, dims.heads, H, dqc, dkv[:, :H], dkv[:, H:], cls_only=True)
+            dzc, dwq, dbq = ops.linear_bwd(dqc, A["zc"], wqkv[:H])
+            dzc = ops.add(dzc, ds1)                                             # the residual of the attention block, position 0 only
+            dz, dwkv, dbkv = ops.linear_bwd(dkv, A["z"], wqkv[H:])
+            ops.scatter_add_rows(dz, plan["cls"], dzc)
+            dwqkv, dbqkv = torch.cat([dwq, dwkv], 0), torch.cat([dbq, dbkv], 0)
+        for i, name in enumerate(("query", "key", "value")):
+            G[a + name + ".weight"] = dwqkv[i * H:(i + 1) * H].clone()
+            G[a + name + ".bias"] = dbqkv[i * H:(i + 1) * H].clone()
+    demb, G["model.embeddings.LayerNorm.weight"], G["model.embeddings.LayerNorm.bias"] = \
+        ops.layernorm_bwd(dz, S["emb"], S["emb_st"], P["model.embeddings.LayerNorm.weight"])
+    per_pos = torch.zeros((Lp, H), dtype=torch.float32, device=dev)
+    ops.scatter_add_rows(per_pos, plan["tok_pos"], demb)
+    dpos = torch.zeros_like(P["model.embeddings.position_embeddings.weight"])
+    dpos[:L] = per_pos[:L]                                                     # (the language token's type / position terms cancel)
+    G["model.embeddings.position_embeddings.weight"] = dpos
+    G["model.embeddings.token_type_embeddings.weight"] = ops.colsum(per_pos[:L].contiguous()).reshape(1, -1)
+    d_ids = S["uniq"].numel()
+    dtable = torch.zeros((d_ids + lam, H), dtype=torch.float32, device=dev)
+    ops.scatter_add_rows(dtable, S["slot"], demb)                               # lever 2 backwards: the uses of an id add up
+    if lam:
+        dlang = torch.zeros_like(P["lang_embeddings.weight"])
+        dlang[lang] = dtable[d_ids]
+        G["lang_embeddings.weight"] = dlang
+    dy0 = _projector_bwd(ops, P, G, "input_projection.1.", S["pb_in"], dtable[:d_ids].contiguous())
+    dx0, G["input_projection.0.weight"], G["input_projection.0.bias"] = ops.linear_bwd(dy0, S["x0"], P["input_projection.0.weight"])
+    dfb, dsw, dsb = ops.gather_bwd(S["uniq"], src, dims.original_vocab_size, dx0, P["fallback_embeddings.weight"].shape[0])
+    G["fallback_embeddings.weight"] = dfb
+    if dims.rescale:
+        G["in_scaler.w"], G["in_scaler.b"] = dsw.reshape(1, -1), dsb.reshape(1, -1)
+    return G
+
+
 class HypernetFunction(torch.autograd.Function):
     """(target_surface_forms, source_embeddings, lang_index, *parameters) -> (pred_in, pred_out | empty, bias); gradients for
     the parameters only (the reference trains the hypernetwork against frozen source embeddings)."""
 
     @staticmethod
-    def forward(ctx, dims, ln_eps, names, ids, src, lang, *params):
+    def forward(ctx, dims, ln_eps, names, packed, ids, src, lang, *params):
         ops = Ops(src.device)
         P = {n: p.detach().float().contiguous() for n, p in zip(names, params)}
         with torch.no_grad():
-            (pred_in, pred_out, bias), S = forward_train(ops, dims, ln_eps, P, ids, src, int(lang))
+            fwd = forward_packed if packed else forward_train
+            (pred_in, pred_out, bias), S = fwd(ops, dims, ln_eps, P, ids, src, int(lang))
         ctx.dims, ctx.names, ctx.lang, ctx.ops = dims, names, int(lang), ops
         ctx.P, ctx.S, ctx.src = P, S, src
         ctx.has_out = pred_out is not None
@@ -398,21 +600,24 @@ class HypernetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_in, d_out, d_bias):
         with torch.no_grad():
-            G = backward_train(ctx.ops, ctx.dims, ctx.P, ctx.S, ctx.src, ctx.lang, d_in, d_out if ctx.has_out else None, d_bias)
+            bwd = backward_packed if ctx.S.get("packed") else backward_train
+            G = bwd(ctx.ops, ctx.dims, ctx.P, ctx.S, ctx.src, ctx.lang, d_in, d_out if ctx.has_out else None, d_bias)
         grads = []
         for name, p in zip(ctx.names, ctx.P.values()):
             g = G.get(name)
             grads.append(None if g is None else g.reshape(p.shape))
         ctx.S = None
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
-def differentiable_forward(model, target_surface_forms: torch.Tensor, source_embeddings: torch.Tensor, lang_index: int):
-    """The forward of `model` (a zett_amd.hypernet.ZettHypernet) with gradients to its parameters."""
+def differentiable_forward(model, target_surface_forms: torch.Tensor, source_embeddings: torch.Tensor, lang_index: int, packed: bool = True):
+    """The forward of `model` (a zett_amd.hypernet.ZettHypernet) with gradients to its parameters.  packed = True (default):
+    the schedule of the inference path (pad skipping, input projection per distinct id, position-0-only last layer);
+    False: the reference's dense layout, every position computed — same outputs and gradients to fp32 round-off."""
     names = [n for n in weight_shapes(model.dims)]
     params = dict(model.named_parameters())
     tensors = [params[n] for n in names]
     src = source_embeddings if source_embeddings.dtype in _SRC_DTYPES else source_embeddings.float()
-    pred_in, pred_out, bias = HypernetFunction.apply(model.dims, model._ln_eps_encoder, tuple(names), target_surface_forms, src.contiguous(),
+    pred_in, pred_out, bias = HypernetFunction.apply(model.dims, model._ln_eps_encoder, tuple(names), bool(packed), target_surface_forms, src.contiguous(),
                                                      int(lang_index), *tensors)
     return pred_in, (pred_out if model.dims.separate_out else None), bias

@@ -22,12 +22,15 @@ HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC")
 OBJ_DIR = os.path.join(CSRC, "build")
 
 
+TRAINING_ONLY = ("train_ops.hip",)      # primitives of zett_amd/autograd.py: not on the path bench.py measures
+
+
 def source_hash() -> str:
-    """sha256 over the HIP sources the library is built from: ties a measurement (profiles/pmc_traffic.json) to the
-    kernels it was taken on."""
+    """sha256 over the HIP sources the FORWARD (what bench.py measures) is built from: ties a measurement
+    (profiles/pmc_traffic.json) to the kernels it was taken on."""
     import hashlib
     h = hashlib.sha256()
-    for rel in sorted(SOURCES + tuple(f for f in HEADERS if not f.startswith(".."))):
+    for rel in sorted(tuple(f for f in SOURCES if f not in TRAINING_ONLY) + tuple(f for f in HEADERS if not f.startswith(".."))):
         with open(os.path.join(CSRC, rel), "rb") as f:
             h.update(rel.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

@@ -172,26 +172,32 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ z, const float* __rest
     }
 }
 
-// ---- dense masked attention (eager semantics) ---------------------------------------------------------------------------
-// One workgroup of 64 lanes per (row n, head): q, k, v are [N*L, ld] with the head's columns at head*d; mask [N, L] (1 = key
-// visible).  probs [N, heads, L, L] is saved for the backward.  L <= ATT_MAX_L.
+// ---- masked attention (eager semantics), dense or packed ------------------------------------------------------------------
+// One workgroup of 64 lanes per (vocabulary row n, head).  The positions of row n are rows [t0, t1) of k / v (and of q / ctx
+// unless cls_only): t0 = row_offset[n], t1 = row_offset[n + 1] (packed: only the positions the row keeps), or n * seq and
+// (n + 1) * seq when row_offset is null (the reference's dense layout).  mask[t] = 1: position t is visible as a key.
+// cls_only: the query is position 0 only, q and ctx hold ONE row per vocabulary row (the position-0-only last layer).
+// probs [n_rows, heads, seq, seq] (row-major in the padded seq) is kept for the backward.  t1 - t0 <= seq <= ATT_MAX_L.
 constexpr int ATT_MAX_L = 32;
 
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
-                                                      const uint8_t* __restrict__ mask, int L, int heads, int d, float scaling,
-                                                      float* __restrict__ ctx, int ld_ctx, float* __restrict__ probs) {
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ld,
+                                                      const uint8_t* __restrict__ mask, const int32_t* __restrict__ row_offset, int seq, int heads, int d,
+                                                      float scaling, int cls_only, float* __restrict__ ctx, int ld_ctx, float* __restrict__ probs) {
     __shared__ float s[ATT_MAX_L][ATT_MAX_L];
     const int n = blockIdx.x / heads, hd = blockIdx.x % heads, lane = threadIdx.x;
-    const size_t base = (size_t)n * L;
-    for (int i = 0; i < L; ++i)
+    const size_t base = row_offset ? (size_t)row_offset[n] : (size_t)n * seq;
+    const int L = row_offset ? row_offset[n + 1] - row_offset[n] : seq;
+    const int nq = cls_only ? 1 : L;
+    const size_t qbase = cls_only ? (size_t)n : base;
+    for (int i = 0; i < nq; ++i)
         for (int j = 0; j < L; ++j) {
             float p = 0.f;
-            for (int c = lane; c < d; c += 64) p += q[(base + i) * ld + hd * d + c] * k[(base + j) * ld + hd * d + c];
+            for (int c = lane; c < d; c += 64) p += q[(qbase + i) * ldq + hd * d + c] * k[(base + j) * ld + hd * d + c];
             p = t_wave_sum(p);
             if (lane == 0) s[i][j] = p * scaling + (mask[base + j] ? 0.f : -FLT_MAX);       // finfo(float32).min on masked keys
         }
     __syncthreads();
-    if (lane < L) {
+    if (lane < nq) {
         const int i = lane;
         float mx = -INFINITY;
         for (int j = 0; j < L; ++j) mx = fmaxf(mx, s[i][j]);
@@ -200,37 +206,41 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
         for (int j = 0; j < L; ++j) {
             const float p = s[i][j] / sum;
             s[i][j] = p;
-            probs[(((size_t)n * heads + hd) * L + i) * L + j] = p;
+            probs[(((size_t)n * heads + hd) * seq + i) * seq + j] = p;
         }
     }
     __syncthreads();
-    for (int i = 0; i < L; ++i)
+    for (int i = 0; i < nq; ++i)
         for (int c = lane; c < d; c += 64) {
             float a = 0.f;
             for (int j = 0; j < L; ++j) a += s[i][j] * v[(base + j) * ld + hd * d + c];
-            ctx[(base + i) * ld_ctx + hd * d + c] = a;
+            ctx[(qbase + i) * ld_ctx + hd * d + c] = a;
         }
 }
 
 // dv_j = sum_i p_ij dctx_i;  dp_ij = dctx_i . v_j;  ds_ij = p_ij (dp_ij - sum_j' p_ij' dp_ij');
 // dq_i = scaling sum_j ds_ij k_j;  dk_j = scaling sum_i ds_ij q_i
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ dctx, int ld_ctx, const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, int ld, const float* __restrict__ probs, int L, int heads, int d,
-                                                      float scaling, float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, int ld_d) {
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ dctx, int ld_ctx, const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                      const float* __restrict__ v, int ld, const float* __restrict__ probs, const int32_t* __restrict__ row_offset,
+                                                      int seq, int heads, int d, float scaling, int cls_only, float* __restrict__ dq, int ld_dq,
+                                                      float* __restrict__ dk, float* __restrict__ dv, int ld_d) {
     __shared__ float p[ATT_MAX_L][ATT_MAX_L], ds[ATT_MAX_L][ATT_MAX_L];
     const int n = blockIdx.x / heads, hd = blockIdx.x % heads, lane = threadIdx.x;
-    const size_t base = (size_t)n * L;
-    for (int t = lane; t < L * L; t += 64) p[t / L][t % L] = probs[((size_t)n * heads + hd) * L * L + t];
+    const size_t base = row_offset ? (size_t)row_offset[n] : (size_t)n * seq;
+    const int L = row_offset ? row_offset[n + 1] - row_offset[n] : seq;
+    const int nq = cls_only ? 1 : L;
+    const size_t qbase = cls_only ? (size_t)n : base;
+    for (int t = lane; t < nq * L; t += 64) p[t / L][t % L] = probs[(((size_t)n * heads + hd) * seq + t / L) * seq + t % L];
     __syncthreads();
-    for (int i = 0; i < L; ++i)
+    for (int i = 0; i < nq; ++i)
         for (int j = 0; j < L; ++j) {
             float a = 0.f;
-            for (int c = lane; c < d; c += 64) a += dctx[(base + i) * ld_ctx + hd * d + c] * v[(base + j) * ld + hd * d + c];
+            for (int c = lane; c < d; c += 64) a += dctx[(qbase + i) * ld_ctx + hd * d + c] * v[(base + j) * ld + hd * d + c];
             a = t_wave_sum(a);
             if (lane == 0) ds[i][j] = a;           // dp for now
         }
     __syncthreads();
-    if (lane < L) {
+    if (lane < nq) {
         const int i = lane;
         float dot = 0.f;
         for (int j = 0; j < L; ++j) dot += p[i][j] * ds[i][j];
@@ -240,19 +250,33 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
     for (int c = lane; c < d; c += 64) {
         for (int j = 0; j < L; ++j) {
             float av = 0.f, ak = 0.f;
-            for (int i = 0; i < L; ++i) {
-                av += p[i][j] * dctx[(base + i) * ld_ctx + hd * d + c];
-                ak += ds[i][j] * q[(base + i) * ld + hd * d + c];
+            for (int i = 0; i < nq; ++i) {
+                av += p[i][j] * dctx[(qbase + i) * ld_ctx + hd * d + c];
+                ak += ds[i][j] * q[(qbase + i) * ldq + hd * d + c];
             }
             dv[(base + j) * ld_d + hd * d + c] = av;
             dk[(base + j) * ld_d + hd * d + c] = ak * scaling;
         }
-        for (int i = 0; i < L; ++i) {
+        for (int i = 0; i < nq; ++i) {
             float aq = 0.f;
             for (int j = 0; j < L; ++j) aq += ds[i][j] * k[(base + j) * ld + hd * d + c];
-            dq[(base + i) * ld_d + hd * d + c] = aq * scaling;
+            dq[(qbase + i) * ld_dq + hd * d + c] = aq * scaling;
         }
     }
+}
+
+// ---- indexed rows: out[r] = (a ? a[r] : 0) + src[idx[r]];  dst[idx[r]] += src[r] -------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ a, const float* __restrict__ src, int ld_src, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ out, int cols) {
+    const size_t r = blockIdx.x;
+    const float* s = src + (size_t)idx[r] * ld_src;
+    for (int c = threadIdx.x; c < cols; c += 256) out[r * cols + c] = (a ? a[r * cols + c] : 0.f) + s[c];
+}
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* __restrict__ dst, int ld_dst, const int32_t* __restrict__ idx, const float* __restrict__ src,
+                                                               int cols) {
+    const size_t r = blockIdx.x;
+    float* d = dst + (size_t)idx[r] * ld_dst;
+    for (int c = threadIdx.x; c < cols; c += 256) atomicAdd(d + c, src[r * cols + c]);
 }
 
 // ---- source-embedding gather (A2 + A3) and its backward -----------------------------------------------------------------
@@ -390,24 +414,41 @@ int zett_op_gelu_bwd_f32(const float* z, const float* dh, float* dz, int64_t n, 
     return 0;
 }
 
-int zett_op_attention_fwd_f32(const float* q, const float* k, const float* v, int32_t ld, const uint8_t* mask, int64_t n_rows, int32_t seq,
-                              int32_t heads, int32_t head_dim, float* ctx, int32_t ld_ctx, float* probs, void* stream) {
+int zett_op_attention_fwd_f32(const float* q, int32_t ldq, const float* k, const float* v, int32_t ld, const uint8_t* mask, const int32_t* row_offset,
+                              int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, int32_t cls_only, float* ctx, int32_t ld_ctx, float* probs, void* stream) {
     if (!q || !k || !v || !mask || !ctx || !probs) return fail(ZETT_E_INVALID, "null argument");
     if (seq < 1 || seq > ATT_MAX_L) return fail(ZETT_E_INVALID, "training attention handles 1 <= L <= %d positions, got %d", ATT_MAX_L, seq);
     if (n_rows <= 0) return 0;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(n_rows * heads)), dim3(64), 0, (hipStream_t)stream, q, k, v, ld, mask, seq, heads, head_dim,
-                       1.0f / sqrtf((float)head_dim), ctx, ld_ctx, probs);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(n_rows * heads)), dim3(64), 0, (hipStream_t)stream, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim,
+                       1.0f / sqrtf((float)head_dim), cls_only, ctx, ld_ctx, probs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int zett_op_attention_bwd_f32(const float* dctx, int32_t ld_ctx, const float* q, const float* k, const float* v, int32_t ld, const float* probs,
-                              int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, float* dq, float* dk, float* dv, int32_t ld_d, void* stream) {
+int zett_op_attention_bwd_f32(const float* dctx, int32_t ld_ctx, const float* q, int32_t ldq, const float* k, const float* v, int32_t ld, const float* probs,
+                              const int32_t* row_offset, int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, int32_t cls_only, float* dq, int32_t ld_dq,
+                              float* dk, float* dv, int32_t ld_d, void* stream) {
     if (!dctx || !q || !k || !v || !probs || !dq || !dk || !dv) return fail(ZETT_E_INVALID, "null argument");
     if (seq < 1 || seq > ATT_MAX_L) return fail(ZETT_E_INVALID, "training attention handles 1 <= L <= %d positions, got %d", ATT_MAX_L, seq);
     if (n_rows <= 0) return 0;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(n_rows * heads)), dim3(64), 0, (hipStream_t)stream, dctx, ld_ctx, q, k, v, ld, probs, seq, heads,
-                       head_dim, 1.0f / sqrtf((float)head_dim), dq, dk, dv, ld_d);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(n_rows * heads)), dim3(64), 0, (hipStream_t)stream, dctx, ld_ctx, q, ldq, k, v, ld, probs, row_offset, seq,
+                       heads, head_dim, 1.0f / sqrtf((float)head_dim), cls_only, dq, ld_dq, dk, dv, ld_d);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_gather_rows_f32(const float* a, const float* src, int32_t ld_src, const int32_t* idx, float* out, int64_t rows, int32_t cols, void* stream) {
+    if (!src || !idx || !out) return fail(ZETT_E_INVALID, "null argument");
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a, src, ld_src, idx, out, cols);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_scatter_add_rows_f32(float* dst, int32_t ld_dst, const int32_t* idx, const float* src, int64_t rows, int32_t cols, void* stream) {
+    if (!dst || !idx || !src) return fail(ZETT_E_INVALID, "null argument");
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dst, ld_dst, idx, src, cols);
     HIP_TRY(hipGetLastError());
     return 0;
 }

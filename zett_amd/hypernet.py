@@ -316,7 +316,7 @@ class ZettHypernet(PreTrainedModel):
             # from_pretrained returned (eval mode, whatever its parameters' requires_grad flags say) predicts on the
             # inference path, which builds no graph
             from .autograd import differentiable_forward
-            return differentiable_forward(self, target_surface_forms, source_embeddings, lang)
+            return differentiable_forward(self, target_surface_forms, source_embeddings, lang, packed=getattr(self, "train_packed", True))
         return self._guarded_forward(device, target_surface_forms, source_embeddings, lang)
 
     def _guarded_forward(self, device, surface_forms, source_embeddings, lang):
