@@ -131,3 +131,17 @@ def test_special_tokens_outside_the_byte_alphabet_match_by_string():
     assert out.cpu().tolist() == want and n_trunc == 0
     with pytest.raises(KeyError):
         rt(["a▁b"], 4)
+
+
+def test_byt5_hn_tokenizer_branch():
+    """zett/utils.py:677-678: with a ByT5 hn tokenizer every BYTE is one id (ord + the tokenizer's offset), no merges; special
+    tokens are matched by string first.  The fixture is the reference's own output with transformers' ByT5Tokenizer()."""
+    from transformers import ByT5Tokenizer
+
+    from zett_amd.surface_forms import get_surface_form_matrix
+    g = json.load(open(os.path.join(util.GOLDEN, "byt5_case.json")))
+    hn = ByT5Tokenizer()
+    for maxlen, case in g["cases"].items():
+        got, n_tr = get_surface_form_matrix(g["tokens"], int(maxlen), hn)
+        np.testing.assert_array_equal(got, np.array(case["expected"], dtype=np.int32))
+        assert n_tr == case["n_truncated"]

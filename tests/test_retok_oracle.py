@@ -58,3 +58,27 @@ def test_bench_surface_forms_retokenize_to_the_workload_ids(name):
     om = retok_ref.model_from_tokenizer_json({"model": model}, ["<unk>", "<s>", "</s>"], [0, 1, 2])
     got, n_trunc = retok_ref.surface_form_matrix_c(om, tokens, ids.shape[1], cfg["pad_token_id"])
     assert n_trunc == 0 and (got == ids).all()
+
+
+def test_byt5_branch_is_a_byte_bpe_without_merges():
+    """The product maps a ByT5 hn tokenizer (zett/utils.py:677-678) onto a BPE model of 256 single-byte pieces without merges;
+    the oracle run on that model must reproduce the reference's own output (tests/golden/byt5_case.json)."""
+    import json
+    import os
+
+    import numpy as np
+    from transformers import ByT5Tokenizer
+
+    from oracle import retok_ref
+    from tests import util
+    from zett_amd.surface_forms import BYTES_TO_CHARS_LIST
+    g = json.load(open(os.path.join(util.GOLDEN, "byt5_case.json")))
+    hn = ByT5Tokenizer()
+    ids = hn.convert_tokens_to_ids([chr(b) for b in range(256)])
+    specials = list(hn.all_special_tokens)
+    model = retok_ref.model_from_tokenizer_json({"model": {"type": "BPE", "vocab": {BYTES_TO_CHARS_LIST[b]: int(i) for b, i in enumerate(ids)}, "merges": []}},
+                                                specials, [hn.convert_tokens_to_ids(s) for s in specials])
+    for maxlen, case in g["cases"].items():
+        got, n_tr = retok_ref.surface_form_matrix_py(model, g["tokens"], int(maxlen), g["pad_token_id"])
+        np.testing.assert_array_equal(np.asarray(got), np.array(case["expected"], dtype=np.int32))
+        assert n_tr == case["n_truncated"]

@@ -154,7 +154,12 @@ class HnTokenizerSpec:
     def from_tokenizer(cls, tokenizer) -> "HnTokenizerSpec":
         """From the object the reference passes as ``tokenizer_to_use`` (a transformers fast tokenizer)."""
         if type(tokenizer).__name__ == "ByT5Tokenizer":
-            raise NotImplementedError("ByT5 hn tokenizers (zett/utils.py:677-678) are not used by any shipped config")
+            # zett/utils.py:677-678: ids = convert_tokens_to_ids([chr(b) for b in token_bytes]) — one id per BYTE (ord + the
+            # tokenizer's offset), no merges.  On the device that is a BPE model of 256 single-byte pieces without merges.
+            specials = list(tokenizer.all_special_tokens)
+            byte_ids = tokenizer.convert_tokens_to_ids([chr(b) for b in range(256)])
+            model = {"type": "BPE", "vocab": {BYTES_TO_CHARS_LIST[b]: int(i) for b, i in enumerate(byte_ids)}, "merges": []}
+            return cls.from_model_json(model, specials, [tokenizer.convert_tokens_to_ids(s) for s in specials], tokenizer.pad_token_id)
         data = json.loads(tokenizer._tokenizer.to_str())
         specials = list(tokenizer.all_special_tokens)
         ids = [tokenizer.convert_tokens_to_ids(s) for s in specials]
