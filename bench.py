@@ -119,6 +119,53 @@ def cpu_baseline(cfg, weights, ids, src, lang, budget_s=15.0):
                              f"on a sample the per-distinct-id table amortises less than on the whole vocab), {dt_l:.1f} s"}, out, rows
 
 
+def measure_traffic_live(args, timeout_s=240):
+    """HBM bytes per GEMM launch of THIS build on THIS box: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — separate
+    passes, `--pmc` only with `--kernel-trace`, as MI355X_MICROARCH.md prescribes) over a child run of this script (one
+    instrumented + one uninstrumented warm-up-free step of the same workload and precision), after the timed region.
+    FETCH_SIZE is doubled (the gfx950 correction for wide coalesced reads), WRITE_SIZE taken as reported; both are KiB.
+    Returns (bytes per launch, details) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    totals, launches = {}, {}
+    work = tempfile.mkdtemp(prefix="zett_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(work, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "t", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--workload", args.workload, "--precision", args.precision,
+                   "--no-cpu-baseline", "--no-alt-precision", "--no-live-traffic"]
+            env = dict(os.environ, TMPDIR=work)
+            res = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if res.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode}): {res.stderr[-300:]}"
+            tot, n = 0.0, 0
+            for path in files:
+                for r in csv.DictReader(open(path)):
+                    if r.get("Counter_Name") == counter and "gemm" in r.get("Kernel_Name", "") and "zett" in r.get("Kernel_Name", ""):
+                        tot += float(r["Counter_Value"])
+                        n += 1
+            if n == 0:
+                return None, f"no GEMM rows in the {counter} pass"
+            totals[counter], launches[counter] = tot, n
+    except Exception as e:          # a profiler that cannot run must not take the benchmark line with it
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    per_launch = totals["FETCH_SIZE"] * 2 * 1024 / launches["FETCH_SIZE"] + totals["WRITE_SIZE"] * 1024 / launches["WRITE_SIZE"]
+    return per_launch, {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over a child run of this bench.py after the timed region; "
+                                  "FETCH_SIZE x2 (gfx950), KiB -> bytes; GEMM kernels, launch-weighted", "launches_counted": launches["FETCH_SIZE"],
+                        "read_bytes_per_launch": totals["FETCH_SIZE"] * 2 * 1024 / launches["FETCH_SIZE"],
+                        "write_bytes_per_launch": totals["WRITE_SIZE"] * 1024 / launches["WRITE_SIZE"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +184,8 @@ def main():
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the side measurement of the same steps in the other 16-bit arithmetic (N = 1; reported as alt_precision, never as value)")
     ap.add_argument("--no-pair-dedupe", action="store_true", help="A/B only: layer 0's Q/K/V per packed position instead of per distinct (source id, position) pair (zett_set_option pair_dedupe 0; same bits)")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B only: the encoder's LayerNorms as launches instead of folded into the GEMMs around them (zett_set_option ln_fold 0)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 PMC passes that measure roofline.traffic after the timed region (N = 1, default workload sizes); "
+                    "the figure then comes from profiles/pmc_traffic.json if that still matches the HIP sources, else null")
     ap.add_argument("--no-retokenize", action="store_true", help="A/B only: start every step from the id matrix instead of the surface forms")
     ap.add_argument("--chunks", type=int, default=2, help="N > 1: row blocks per step (zett_amd/sharding.py: the all-gather of a block overlaps the next block's forward)")
     ap.add_argument("--serial-allgather", action="store_true", help="N > 1: one block per step, i.e. forward, then all-gather (A/B)")
@@ -453,6 +502,17 @@ def main():
                               "gemm_tflops": f32_tf, "roofline_frac": f32_tf / PEAK_TFLOPS["f32"], "peak": PEAK_TFLOPS["f32"],
                               "note": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32, gemm8r tile); measured after the timed region"}
         f32_engine.close()
+    if rank == 0 and world == 1 and not args.no_live_traffic and not args.rows:
+        # roofline.traffic measured HERE: same build, same box, same workload, right after the timed region
+        live, info = measure_traffic_live(args)
+        if live is not None:
+            result["roofline"]["traffic"] = live
+            result["roofline"]["traffic_source"] = dict(info, live=True)
+            if alg_launches:
+                result["roofline"]["traffic_over_algorithmic"] = live / (alg_bytes / alg_launches)
+        else:
+            src_info = result["roofline"].get("traffic_source") or {}
+            result["roofline"]["traffic_source"] = dict(src_info, live=False, live_failure=str(info))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, ref_out, n_ref = cpu_baseline(cfg, weights_keep, ids_all, src, lang, args.cpu_budget_s)
         result["cpu_baseline"] = cb
