@@ -74,12 +74,28 @@ class Ops:
         _lib.check(self.lib.zett_op_transpose_f32(_ptr(x), x.stride(0), _ptr(out), rp, r, c, rp, self._stream()), "zett_op_transpose_f32")
         return out
 
-    def colsum(self, x, out=None, accumulate=False):
+    def _colsum_raw(self, x, out=None, accumulate=False):
         assert x.dim() == 2 and x.stride(1) == 1
         r, c = x.shape
         if out is None:
             out = self.new(c)
         _lib.check(self.lib.zett_op_colsum_f32(_ptr(x), x.stride(0), r, c, _ptr(out), int(accumulate), self._stream()), "zett_op_colsum_f32")
+        return out
+
+    def colsum(self, x, out=None, accumulate=False):
+        """out[c] (+)= sum_r x[r, c].  The kernel gives one workgroup 64 columns and all rows: a tall, narrow matrix (80 k rows x
+        768 columns) would run on 12 workgroups.  Tall contiguous inputs are therefore summed in two deterministic passes on
+        the same kernel: viewed as [R/k, k*C] (a view row = k consecutive rows) the first pass yields k partial vectors on
+        k*C/64 workgroups, the second adds them; the < k rows left over are accumulated on top."""
+        r, c = x.shape
+        k = min(r // 64, max(1, 65536 // c)) if r >= 128 else 1
+        if k <= 1 or not x.is_contiguous():
+            return self._colsum_raw(x, out, accumulate)
+        r0 = (r // k) * k
+        part = self._colsum_raw(x[:r0].view(r0 // k, k * c))
+        out = self._colsum_raw(part.view(k, c), out, accumulate)
+        if r0 < r:
+            out = self._colsum_raw(x[r0:], out, True)
         return out
 
     def _ew(self, op, a, b=None, vec=None, vec2=None, s=None, rows=None, cols=None):
