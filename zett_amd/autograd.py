@@ -603,7 +603,7 @@ class HypernetFunction(torch.autograd.Function):
     def forward(ctx, dims, ln_eps, names, packed, ids, src, lang, *params):
         ops = Ops(src.device)
         P = {n: p.detach().float().contiguous() for n, p in zip(names, params)}
-        with torch.no_grad():
+        with torch.no_grad(), torch.cuda.device(src.device):          # (the primitives launch on the CURRENT device and stream)
             fwd = forward_packed if packed else forward_train
             (pred_in, pred_out, bias), S = fwd(ops, dims, ln_eps, P, ids, src, int(lang))
         ctx.dims, ctx.names, ctx.lang, ctx.ops = dims, names, int(lang), ops
@@ -615,7 +615,7 @@ class HypernetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_in, d_out, d_bias):
-        with torch.no_grad():
+        with torch.no_grad(), torch.cuda.device(ctx.src.device):
             bwd = backward_packed if ctx.S.get("packed") else backward_train
             G = bwd(ctx.ops, ctx.dims, ctx.P, ctx.S, ctx.src, ctx.lang, d_in, d_out if ctx.has_out else None, d_bias)
         grads = []
