@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force one GEMM tile variant (zett_set_option gemm_variant); 0 = per-launch choice")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the side measurement of the same steps in the other 16-bit arithmetic (N = 1; reported as alt_precision, never as value)")
     ap.add_argument("--no-pair-dedupe", action="store_true", help="A/B only: layer 0's Q/K/V per packed position instead of per distinct (source id, position) pair (zett_set_option pair_dedupe 0; same bits)")
+    ap.add_argument("--ln-fold", type=int, default=1, help="A/B only: zett_set_option ln_fold (1 = encoder and output heads, default; 2 = encoder only; 0 = off)")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B only: the encoder's LayerNorms as launches instead of folded into the GEMMs around them (zett_set_option ln_fold 0)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 PMC passes that measure roofline.traffic after the timed region (N = 1, default workload sizes); "
                     "the figure then comes from profiles/pmc_traffic.json if that still matches the HIP sources, else null")
@@ -243,6 +244,8 @@ def main():
         engine.set_option("pair_dedupe", 0)
     if args.no_ln_fold:
         engine.set_option("ln_fold", 0)
+    elif args.ln_fold != 1:
+        engine.set_option("ln_fold", args.ln_fold)
     # the same weights in the OTHER 16-bit arithmetic, for the side measurement after the timed region (N = 1 only)
     alt_precision = {"f16": "bf16", "bf16": "f16"}.get(args.precision) if (world == 1 and not args.no_alt_precision) else None
     alt_engine = None

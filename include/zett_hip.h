@@ -195,9 +195,10 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
  * workspace, at least 131072 positions: 131072 at H = 4096, ~640 k at H = 768), "time_gemm" (0/1: bracket every
  * GEMM launch with HIP events on the launch stream and report the sum in
  * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "pair_dedupe" (0/1, default 1: layer 0's
- * Q/K/V once per distinct (source id, position) pair; same bits either way), "ln_fold" (0/1, default 1: in the 16-bit
- * modes the LayerNorms inside the encoder are folded into the GEMMs around them instead of launched; same values to the
- * rounding of the arithmetic, not the same bits; off whenever a tile variant is forced), "gemm_variant"
+ * Q/K/V once per distinct (source id, position) pair; same bits either way), "ln_fold" (0/1/2, default 1: in the 16-bit
+ * modes the LayerNorms inside the encoder AND the ProjectorBlock LayerNorm in front of each output head's final Linear are
+ * folded into the GEMMs around them instead of launched; 2 = the encoder's only (A/B); same values to the rounding of the
+ * arithmetic, not the same bits; off whenever a tile variant is forced), "gemm_variant"
  * (0 = choose per launch, 1 = 128x128, 2 = 256x256 register-staged eight-wave,
  * 3 = 384x256 LDS-DMA, 7 = 256x256 four-wave direct-to-LDS (the choice for 16-bit
  * operands and K >= "gemm4d_min_k", default 512), 8 = as 7 with the generic epilogue drain; all produce

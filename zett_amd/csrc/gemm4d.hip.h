@@ -87,7 +87,11 @@ __device__ int g4d_stagger_ticks, g4d_stagger_mode;
 //   F32_LN     as F32 with a residual, plus the 16-bit copy of the fp32 rows (out_lo) and per-row partial statistics over
 //              the wave's 128 columns (stats_part): the producer half of the LayerNorm fold
 //   LO_FOLD    as LO on an un-normalised operand: acc <- rstd_row * (acc - mean_row * fold_c[col]) in front of the bias
-enum { G4D_EPI_GENERIC = 0, G4D_EPI_LO = 1, G4D_EPI_F32 = 2, G4D_EPI_F32_SCALE = 3, G4D_EPI_BOTH = 4, G4D_EPI_F32_LN = 5, G4D_EPI_LO_FOLD = 6 };
+//   LO_LN      the producer of the output heads' ProjectorBlock LayerNorm (dense2: tanh-GELU + plain fp32 residual): ONLY the
+//              16-bit copy of the sum and the partial statistics leave — nothing reads the fp32 sum again
+//   F32_SCALE_FOLD   its consumer: the final Linear with the Rescaler, on the un-normalised operand (as LO_FOLD, fp32 output)
+enum { G4D_EPI_GENERIC = 0, G4D_EPI_LO = 1, G4D_EPI_F32 = 2, G4D_EPI_F32_SCALE = 3, G4D_EPI_BOTH = 4, G4D_EPI_F32_LN = 5, G4D_EPI_LO_FOLD = 6,
+       G4D_EPI_LO_LN = 7, G4D_EPI_F32_SCALE_FOLD = 8 };
 constexpr int G4D_EPI_STRIDE = 132;                                   // floats per staged row: 128 columns + 4 of padding
 constexpr int G4D_EPI_REGION = 64 * G4D_EPI_STRIDE * 4;               // bytes per wave
 constexpr int G4D_LDS_BYTES = 4 * G4D_EPI_REGION;                     // 132 KiB (the K loop uses the first 128)
@@ -314,9 +318,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     } else {
         // ---- streamlined epilogues (see the header).  No barrier here: the last K step carries it.
-        constexpr bool LO = EPI == G4D_EPI_LO || EPI == G4D_EPI_LO_FOLD, SCALE = EPI == G4D_EPI_F32_SCALE;
-        constexpr bool LNP = EPI == G4D_EPI_F32_LN, FOLD = EPI == G4D_EPI_LO_FOLD;
-        static_assert(!LNP || (RES && ACT == ACT_NONE), "the LayerNorm producer is the residual epilogue");
+        constexpr bool LO = EPI == G4D_EPI_LO || EPI == G4D_EPI_LO_FOLD, SCALE = EPI == G4D_EPI_F32_SCALE || EPI == G4D_EPI_F32_SCALE_FOLD;
+        constexpr bool LNP = EPI == G4D_EPI_F32_LN || EPI == G4D_EPI_LO_LN, FOLD = EPI == G4D_EPI_LO_FOLD || EPI == G4D_EPI_F32_SCALE_FOLD;
+        constexpr bool WF32 = EPI != G4D_EPI_LO_LN;          // the fp32 output is written
+        static_assert(!LNP || RES, "a LayerNorm producer is a residual epilogue");
+        static_assert(EPI != G4D_EPI_F32_LN || ACT == ACT_NONE, "the encoder's producer has no activation");
         constexpr int CPL = LO ? 8 : 4;            // columns per lane
         constexpr int LPR = 128 / CPL;             // lanes per row
         constexpr int RPI = 64 / LPR;              // rows per wave instruction
@@ -530,10 +536,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const float4 b = make_float4(v[u * 8 + 4], v[u * 8 + 5], v[u * 8 + 6], v[u * 8 + 7]);
                         store_out8<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, a, b);
                     } else {
-                        float* d = e.out_f32 + (size_t)grow * e.ld_f32 + gcol;
                         const f32x4 x = {v[u * 4], v[u * 4 + 1], v[u * 4 + 2], v[u * 4 + 3]};
-                        if (RES) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(d), "v"(x) : "memory");
-                        else *(f32x4*)d = x;
+                        if constexpr (WF32) {
+                            float* d = e.out_f32 + (size_t)grow * e.ld_f32 + gcol;
+                            if (RES) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(d), "v"(x) : "memory");
+                            else *(f32x4*)d = x;
+                        }
                         if constexpr (EPI == G4D_EPI_BOTH || LNP)      // the same four values as the next GEMM's operand: 8 bytes per lane, 256 per row
                             store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, make_float4(x[0], x[1], x[2], x[3]));
                     }
@@ -601,12 +609,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <typename T>
 inline int gemm4d_epi_mode(const GemmArgs<T>& g) {
     const GemmEpilogue<T>& e = g.epi;
-    if (e.stats_part)      // LayerNorm producer: only this instantiation writes the partial statistics
-        return (e.out_f32 && e.out_lo && e.residual && e.act == ACT_NONE && !e.scale && !e.shift && !e.out_f32_b && e.split_col >= g.N &&
-                g.N % 128 == 0 && e.ld_f32 % 4 == 0 && e.ld_lo % 4 == 0 && e.ld_res % 4 == 0) ? G4D_EPI_F32_LN : -1;
-    if (e.fold_stats)      // LayerNorm consumer
-        return (e.fold_c && e.out_lo && !e.out_f32 && !e.residual && !e.scale && !e.shift && !e.out_f32_b && e.split_col >= g.N &&
-                g.N % 8 == 0 && e.ld_lo % 8 == 0) ? G4D_EPI_LO_FOLD : -1;
+    if (e.stats_part) {    // LayerNorm producer: only these instantiations write the partial statistics
+        const bool common = e.out_lo && e.residual && !e.scale && !e.shift && !e.out_f32_b && e.split_col >= g.N && g.N % 128 == 0 &&
+                            e.ld_lo % 4 == 0 && e.ld_res % 4 == 0;
+        if (common && e.out_f32 && e.act == ACT_NONE && e.ld_f32 % 4 == 0) return G4D_EPI_F32_LN;
+        if (common && !e.out_f32 && e.act == ACT_GELU_TANH && !e.res_stats && !e.res_index) return G4D_EPI_LO_LN;
+        return -1;
+    }
+    if (e.fold_stats) {    // LayerNorm consumer
+        if (e.fold_c && e.out_lo && !e.out_f32 && !e.residual && !e.scale && !e.shift && !e.out_f32_b && e.split_col >= g.N &&
+            g.N % 8 == 0 && e.ld_lo % 8 == 0) return G4D_EPI_LO_FOLD;
+        if (e.fold_c && e.out_f32 && !e.out_lo && !e.residual && e.scale && e.shift && e.act == ACT_NONE && !e.out_f32_b && e.split_col >= g.N &&
+            g.N % 4 == 0 && e.ld_f32 % 4 == 0) return G4D_EPI_F32_SCALE_FOLD;
+        return -1;
+    }
     if (e.out_f32_b || e.split_col < g.N) return G4D_EPI_GENERIC;
     if (e.res_stats && (e.act != ACT_NONE || !e.residual)) return G4D_EPI_GENERIC;
     if (e.out_lo && !e.out_f32 && !e.residual && !e.scale && !e.shift && g.N % 8 == 0 && e.ld_lo % 8 == 0) return G4D_EPI_LO;
@@ -656,6 +672,8 @@ inline hipError_t launch_gemm4d(const GemmArgs<T>& g, hipStream_t stream, bool f
     const int mode = (force_generic && !g.epi.stats_part && !g.epi.fold_stats) ? G4D_EPI_GENERIC : gemm4d_epi_mode(g);
     if (mode < 0) return hipErrorInvalidValue;       // a LayerNorm-fold launch whose outputs no instantiation carries
     if (mode == G4D_EPI_F32_LN) return launch_gemm4d_inst<T, ACT_NONE, true, G4D_EPI_F32_LN>(g, stream);
+    if (mode == G4D_EPI_LO_LN) return launch_gemm4d_inst<T, ACT_GELU_TANH, true, G4D_EPI_LO_LN>(g, stream);
+    if (mode == G4D_EPI_F32_SCALE_FOLD) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE_FOLD>(g, stream);
     if (mode == G4D_EPI_F32_SCALE) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE>(g, stream);
     if (mode == G4D_EPI_BOTH) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_BOTH>(g, stream);
     switch (g.epi.act) {

@@ -63,6 +63,9 @@ struct zett_hypernet {
     // attention-output LayerNorm) — with their row sums and beta-folded biases
     struct Folded { void* w = nullptr; float* c = nullptr; float* b = nullptr; };
     std::vector<Folded> fold_qkv, fold_up;
+    Folded fold_head_in, fold_head_out;    // the final Linear of each output head, folded with its ProjectorBlock's LayerNorm
+    float* head_one = nullptr;        // [head_out_width] ones / zeros: the Rescaler of a config without hn_rescale_embeddings, for the
+    float* head_zero = nullptr;       // folded head epilogue, which is compiled with it
     int ln_fold = 1;
     float* head_scale = nullptr;      // [head_out_width] scaler.w (| out_scaler.w for single_head)
     float* head_shift = nullptr;
@@ -387,6 +390,22 @@ int zett_finalize(zett_hypernet* h) {
             }
             if (int rc = fold(tmp, 3 * H, H, h->w[pp + "weight"].f32, h->w[pp + "bias"].f32, h->qkv_b[l], h->fold_qkv[l])) return rc;
         }
+        // the output heads: Linear(LN_1e-6(.)) with the ProjectorBlock's LayerNorm folded in (not for the split single head,
+        // whose two-destination epilogue is the generic one)
+        if (!(c.single_head && c.separate_out)) {
+            const size_t w0 = c.single_head ? c.n_in_embd : c.n_embd;
+            if (int rc = fold(h->w["output_projection.1.weight"].f32, w0, H, h->w["output_projection.0.ln.weight"].f32,
+                              h->w["output_projection.0.ln.bias"].f32, h->w["output_projection.1.bias"].f32, h->fold_head_in)) return rc;
+            if (c.separate_out && !c.single_head)
+                if (int rc = fold(h->w["output_projection_out.1.weight"].f32, c.n_embd, H, h->w["output_projection_out.0.ln.weight"].f32,
+                                  h->w["output_projection_out.0.ln.bias"].f32, h->w["output_projection_out.1.bias"].f32, h->fold_head_out)) return rc;
+            std::vector<float> ones(w0, 1.0f), zeros(w0, 0.0f);
+            HIP_TRY(hipMalloc((void**)&h->head_one, w0 * 4));
+            HIP_TRY(hipMalloc((void**)&h->head_zero, w0 * 4));
+            h->owned.push_back(h->head_one); h->owned.push_back(h->head_zero);
+            HIP_TRY(hipMemcpy(h->head_one, ones.data(), w0 * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->head_zero, zeros.data(), w0 * 4, hipMemcpyHostToDevice));
+        }
         HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(tmp);
     }
@@ -432,7 +451,8 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "pair_dedupe") {
         h->pair_dedupe = value != 0;
     } else if (k == "ln_fold") {
-        h->ln_fold = value != 0;
+        if (value < 0 || value > 2) return fail(ZETT_E_INVALID, "ln_fold must be 0 (off), 1 (encoder and output heads) or 2 (encoder only: A/B)");
+        h->ln_fold = (int)value;
     } else if (k == "gemm_tile_order") {
         if (value < 0 || value > 1) return fail(ZETT_E_INVALID, "gemm_tile_order must be 0 or 1");
         h->gemm_tile_order = (int)value;
@@ -658,16 +678,23 @@ struct Runner {
 
     // ProjectorBlock (modeling_hypernet.py:22-40) on rows already projected to H:
     //   out = LN_1e-6( gelu_t(W2·gelu_t(W1·x + b1) + b2) + x )
-    void projector(const std::string& p, const T* x_lo, const float* x_f32, int rows, T* big, float* pre, float* of, T* ol) {
+    // fold_parts != null (output heads, LayerNorm fold): the block's LayerNorm is not launched — dense2 writes the 16-bit copy of
+    // the pre-LayerNorm sum to `ol` and partial row statistics, fold_stats receives (mean, rstd), and the caller's next GEMM
+    // runs on the gamma-folded weight (no fp32 sum is written: nothing else reads it)
+    void projector(const std::string& p, const T* x_lo, const float* x_f32, int rows, T* big, float* pre, float* of, T* ol,
+                   float2* fold_parts = nullptr, int ld_part = 0, float* fold_stats = nullptr) {
         const zett_config& c = h->cfg;
         GemmEpilogue<T> e1 = epi();
         e1.bias = Wf(p + "dense1.bias"); e1.act = ACT_GELU_TANH; e1.out_lo = big; e1.ld_lo = c.intermediate;
         gemm(x_lo, c.hidden, Wlo(p + "dense1.weight"), c.hidden, rows, c.intermediate, c.hidden, e1);
         GemmEpilogue<T> e2 = epi();
         e2.bias = Wf(p + "dense2.bias"); e2.act = ACT_GELU_TANH; e2.residual = x_f32; e2.ld_res = c.hidden;
-        e2.out_f32 = pre; e2.ld_f32 = c.hidden;
+        e2.ld_f32 = c.hidden;
+        if (fold_parts) { e2.out_lo = ol; e2.ld_lo = c.hidden; e2.stats_part = fold_parts; e2.ld_part = ld_part; }
+        else e2.out_f32 = pre;
         gemm(big, c.intermediate, Wlo(p + "dense2.weight"), c.intermediate, rows, c.hidden, c.intermediate, e2);
-        layernorm(pre, rows, Wf(p + "ln.weight"), Wf(p + "ln.bias"), c.ln_eps_projector, of, ol);
+        if (fold_parts) ln_stats(fold_parts, ld_part, rows, c.ln_eps_projector, fold_stats);
+        else layernorm(pre, rows, Wf(p + "ln.weight"), Wf(p + "ln.bias"), c.ln_eps_projector, of, ol);
     }
 };
 
@@ -976,26 +1003,32 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         if (last_chunk && !R.rc) HIP_TRY(hipEventRecord(h->out_ready[ZETT_OUT_BIAS], st));      // out_bias complete (zett_stream_wait_output)
 
         // output heads (modeling_hypernet.py:236-258)
+        // LayerNorm fold of the heads (r3): the ProjectorBlock's LayerNorm in front of each final Linear is not a launch either
+        const bool fold_heads = fold && h->ln_fold == 1 && h->fold_head_in.w != nullptr;
         {
-            R.projector("output_projection.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX);
+            if (fold_heads) R.projector("output_projection.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX, PARTS, (int)MC, STa);
+            else R.projector("output_projection.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX);
             GemmEpilogue<T> e = R.epi();
-            e.bias = R.Wf("output_projection.1.bias");
-            e.scale = c.rescale ? h->head_scale : nullptr;
-            e.shift = c.rescale ? h->head_shift : nullptr;
+            e.bias = fold_heads ? h->fold_head_in.b : R.Wf("output_projection.1.bias");
+            e.scale = c.rescale ? h->head_scale : (fold_heads ? h->head_one : nullptr);
+            e.shift = c.rescale ? h->head_shift : (fold_heads ? h->head_zero : nullptr);
+            if (fold_heads) { e.fold_stats = STa; e.fold_c = h->fold_head_in.c; }
             e.out_f32 = out_in + (size_t)r0 * E; e.ld_f32 = E; e.range_final = 1;
             const int width = c.single_head ? EIN : E;
             if (c.single_head && c.separate_out) { e.split_col = E; e.out_f32_b = out_out + (size_t)r0 * E; }
-            R.gemm(CTX, H, R.Wlo("output_projection.1.weight"), H, rows, width, H, e);
+            R.gemm(CTX, H, fold_heads ? (const T*)h->fold_head_in.w : R.Wlo("output_projection.1.weight"), H, rows, width, H, e);
             if (last_chunk && !R.rc) HIP_TRY(hipEventRecord(h->out_ready[ZETT_OUT_IN], st));     // out_in complete: the second head runs behind it
         }
         if (c.separate_out && !c.single_head) {
-            R.projector("output_projection_out.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX);
+            if (fold_heads) R.projector("output_projection_out.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX, PARTS, (int)MC, STa);
+            else R.projector("output_projection_out.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX);
             GemmEpilogue<T> e = R.epi();
-            e.bias = R.Wf("output_projection_out.1.bias");
-            e.scale = c.rescale ? R.Wf("out_scaler.w") : nullptr;
-            e.shift = c.rescale ? R.Wf("out_scaler.b") : nullptr;
+            e.bias = fold_heads ? h->fold_head_out.b : R.Wf("output_projection_out.1.bias");
+            e.scale = c.rescale ? R.Wf("out_scaler.w") : (fold_heads ? h->head_one : nullptr);
+            e.shift = c.rescale ? R.Wf("out_scaler.b") : (fold_heads ? h->head_zero : nullptr);
+            if (fold_heads) { e.fold_stats = STa; e.fold_c = h->fold_head_out.c; }
             e.out_f32 = out_out + (size_t)r0 * E; e.ld_f32 = E; e.range_final = 1;
-            R.gemm(CTX, H, R.Wlo("output_projection_out.1.weight"), H, rows, E, H, e);
+            R.gemm(CTX, H, fold_heads ? (const T*)h->fold_head_out.w : R.Wlo("output_projection_out.1.weight"), H, rows, E, H, e);
         }
         r0 = r1;
     }
