@@ -38,6 +38,14 @@ def test_gemm_and_linear_backward_match_torch():
         assert _rel(dx, dy.double() @ w.double()) < 2e-6 and _rel(dw, dy.double().T @ x.double()) < 2e-6 and _rel(db, dy.double().sum(0)) < 2e-6
     with pytest.raises(ValueError):
         ops.gemm(torch.randn(4, 20, device=DEV), torch.randn(8, 20, device=DEV))         # contraction width not a multiple of 32
+    # tall and narrow: the weight gradient is summed from row slices that run as concurrent launches
+    x = torch.randn(40001, 384, device=DEV, generator=g)
+    w = torch.randn(256, 384, device=DEV, generator=g) * 0.1
+    dy = torch.randn(40001, 256, device=DEV, generator=g)
+    dx, dw, db = ops.linear_bwd(dy, x, w)
+    assert _rel(dw, dy.double().T @ x.double()) < 2e-6 and _rel(dx, dy.double() @ w.double()) < 2e-6
+    dw2 = ops.linear_bwd(dy, x, w)[1]
+    assert torch.equal(dw, dw2)                                                          # deterministic: fixed slices, fixed order of the sum
 
 
 def test_layernorm_gelu_rowops_match_torch():

@@ -57,14 +57,42 @@ class Ops:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     # ---- dense contraction: y[M,N] = act(x[M,K] . w[N,K]^T + bias) + residual
-    def gemm(self, x, w, bias=None, act=ACT_NONE, residual=None):
+    def gemm(self, x, w, bias=None, act=ACT_NONE, residual=None, out=None):
         assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.stride(1) == 1 and w.stride(1) == 1
         m, k = x.shape
         n = w.shape[0]
-        out = self.new(m, n)
+        if out is None:
+            out = self.new(m, n)
+        assert out.shape == (m, n) and out.is_contiguous()
         _lib.check(self.lib.zett_op_gemm_f32(_ptr(x), x.stride(0), _ptr(w), w.stride(0), m, n, k, _ptr(bias), act,
                                              _ptr(residual), 0 if residual is None else residual.stride(0), _ptr(out), n, self._stream()), "zett_op_gemm_f32")
         return out
+
+    def wgrad(self, dy_t, x_t):
+        """dW[N, K] = dy_t[N, M'] . x_t[K, M']^T (M' = rows, zero-padded to the K step).  The output is N*K/65536 tiles of 256x256
+        whatever the batch: for a narrow hypernetwork (N, K <= 2304: 9-54 tiles) one launch would leave most of the 256 CUs
+        idle while each tile walks tens of thousands of rows.  Then the rows are cut into S slices, the S partial products run
+        as concurrent launches on side streams (same kernel, same arithmetic per slice) and one deterministic column sum
+        over the [S, N*K] partials adds them."""
+        n, k, mp = dy_t.shape[0], x_t.shape[0], dy_t.shape[1]
+        tiles = -(-n // 256) * -(-k // 256)
+        s_max = min(16, 256 // max(tiles, 1), mp // 2048)
+        if s_max < 2:
+            return self.gemm(dy_t, x_t)
+        per = -(-(mp // K_STEP) // s_max) * K_STEP                     # slice width, a multiple of the K step
+        bounds = [(a, min(a + per, mp)) for a in range(0, mp, per)]
+        part = self.new(len(bounds), n, k)
+        if not hasattr(self, "_side"):
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(16)]
+        main = torch.cuda.current_stream(self.device)
+        for i, (a, b) in enumerate(bounds):
+            st = self._side[i]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self.gemm(dy_t[:, a:b], x_t[:, a:b], out=part[i])
+        for i in range(len(bounds)):
+            main.wait_stream(self._side[i])
+        return self._colsum_raw(part.view(len(bounds), n * k)).view(n, k)
 
     def transpose(self, x, pad_to=K_STEP):
         assert x.dim() == 2 and x.stride(1) == 1
@@ -214,7 +242,7 @@ class Ops:
         if w.shape[0] % K_STEP:
             raise NotImplementedError(f"the fp32 training GEMM contracts over multiples of {K_STEP}: a Linear with {w.shape[0]} outputs is not supported yet")
         dx = self.gemm(dy, self.transpose(w))                           # A = dy [M, N], W-operand = w^T [K, N]
-        dw = self.gemm(self.transpose(dy), self.transpose(x))           # A = dy^T [N, M'], W-operand = x^T [K, M'] (M' = rows zero-padded to 32)
+        dw = self.wgrad(self.transpose(dy), self.transpose(x))          # A = dy^T [N, M'], W-operand = x^T [K, M'] (M' = rows zero-padded to 32)
         return dx, dw, self.colsum(dy)
 
 
