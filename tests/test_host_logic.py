@@ -64,6 +64,17 @@ def test_no_cpu_fallback():
         model(torch.zeros(2, 7, dtype=torch.long), source_embeddings=torch.zeros(300, 128), lang_index=torch.tensor(0))
 
 
+def test_concat_last_hidden_state_beyond_one_position_is_refused():
+    """modeling_hypernet.py:231-232: the reference's own heads take hn_hidden_size inputs, so it raises (a shape error) for
+    more than one position itself; here that is a NotImplementedError before anything is computed."""
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg = dict(synth.workload("tiny")[0], hn_concat_last_hidden_state=True)
+    model = ZettHypernet(ZettHypernetConfig(**cfg)).eval()
+    with pytest.raises(NotImplementedError, match="concat"):
+        model(torch.zeros(2, 7, dtype=torch.long), source_embeddings=torch.zeros(300, 128), lang_index=torch.tensor(0))
+
+
 def test_product_never_imports_oracle():
     for root, _, files in os.walk(os.path.join(REPO, "zett_amd")):
         for f in files:

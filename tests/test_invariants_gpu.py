@@ -201,6 +201,25 @@ def test_output_completion_events():
     side.synchronize()
 
 
+def test_concat_last_hidden_state_with_one_position_is_the_cls_path():
+    """hn_concat_last_hidden_state reshapes the hidden states to [N, L' * H]; for L' = 1 (the only case the reference's own
+    heads can take: checked against it in the build container) that is hidden[:, 0]."""
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg = dict(synth.workload("tiny")[0], hn_embed_lang_id=False)
+    w = synth.make_weights(cfg, seed=12)
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 12)).cuda()
+    ids = torch.from_numpy(synth.make_surface_forms(cfg, 50, seed=12, seq=1)).cuda()
+    outs = []
+    for flag in (False, True):
+        model = ZettHypernet(ZettHypernetConfig(**dict(cfg, hn_concat_last_hidden_state=flag)))
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+        model = model.to("cuda:0").eval()
+        model.precision = "f32"
+        outs.append(model(ids, source_embeddings=src))
+    assert _eq(outs[0], outs[1])
+
+
 def test_pad_content_independence():
     """Changing the pad token's source embedding must change nothing for rows with a visible key."""
     cfg, *_ = synth.workload("tiny")

@@ -293,7 +293,12 @@ class ZettHypernet(PreTrainedModel):
         if not getattr(self.config, "hn_embed_using_source_embeddings", False):
             raise NotImplementedError()                          # modeling_hypernet.py:167-168
         if getattr(self.config, "hn_concat_last_hidden_state", False):
-            raise NotImplementedError("hn_concat_last_hidden_state is not set by any shipped config")
+            # modeling_hypernet.py:231-232 reshapes the hidden states to [N, L' * H], but the port builds its output heads with
+            # in_features = hn_hidden_size (:112-144): the reference itself only runs for L' = 1, where the reshape IS hidden[:, 0]
+            n_pos = int(torch.as_tensor(target_surface_forms).shape[1]) + (1 if self.dims.embed_lang else 0)
+            if n_pos != 1:
+                raise NotImplementedError("hn_concat_last_hidden_state with more than one position: the reference's own heads "
+                                          "(in_features = hn_hidden_size) cannot take the concatenated states either")
         if source_embeddings is None:
             raise ValueError("source_embeddings is required")
         if not torch.is_tensor(target_surface_forms):
