@@ -268,6 +268,14 @@ int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* of
  * k % 32 == 0, lda / ldw % 4 == 0) */
 int zett_op_gemm_f32(const float* a, int32_t lda, const float* w, int32_t ldw, int64_t m, int32_t n, int32_t k, const float* bias, int32_t act,
                      const float* residual, int32_t ld_res, float* out, int32_t ld_out, void* stream);
+/* The same contraction on 16-bit MFMA operands (prec = ZETT_PREC_BF16 | ZETT_PREC_F16), fp32 accumulate, fp32 epilogue and output
+ * (k % 64 == 0, lda / ldw % 8 == 0): the tile kernels of the inference path.  Operands are made by zett_op_convert_lo
+ * (out[r, c] = lo(in[r, c]), columns zero-padded to cols_padded) and zett_op_transpose_lo (out[c, r] = lo(in[r, c]), rows
+ * zero-padded to rows_padded): the conversion is fused with the layout change dgrad / wgrad need anyway. */
+int zett_op_gemm_lo(int32_t prec, const void* a, int32_t lda, const void* w, int32_t ldw, int64_t m, int32_t n, int32_t k, const float* bias, int32_t act,
+                    const float* residual, int32_t ld_res, float* out, int32_t ld_out, void* stream);
+int zett_op_convert_lo(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int32_t cols_padded, void* stream);
+int zett_op_transpose_lo(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream);
 /* out[c, r] = in[r, c] (r < rows), 0 for rows <= r < rows_padded */
 int zett_op_transpose_f32(const float* in, int32_t ld_in, float* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream);
 /* out[c] (+)= sum_r in[r, c] */

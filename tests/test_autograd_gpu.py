@@ -252,6 +252,42 @@ def test_whole_hypernetwork_outputs_and_every_gradient(flags, packed):
     assert len(worst) >= 40
 
 
+@pytest.mark.parametrize("precision,lim", [("bf16", 6e-2), ("f16", 1e-2)])
+def test_sixteen_bit_contractions_in_training(precision, lim):
+    """model.train_precision = "bf16" / "f16": every forward / dgrad / wgrad contraction on 16-bit MFMA operands (the tile kernels
+    of the inference path), fp32 accumulation, everything else fp32.  Outputs meet the tolerance of that arithmetic against
+    the oracle; every parameter's gradient stays within the operand rounding of float64 torch autograd."""
+    from oracle import hypernet_ref
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg, w, src_np, ids_np = _case({}, seed=33, rows=300)
+    W64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in w.items()}
+    ref = torch_port.forward(W64, cfg, torch.from_numpy(ids_np).long(), torch.from_numpy(src_np), 2)
+    model = ZettHypernet(ZettHypernetConfig(**cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model = model.to(DEV).requires_grad_(True).train()
+    model.train_precision = precision
+    src, ids = torch.from_numpy(src_np).to(DEV), torch.from_numpy(ids_np).to(DEV)
+    out = model(ids, source_embeddings=src, lang_index=torch.tensor(2))
+    keep = ~util.all_pad_rows(cfg, ids_np)
+    for got, r, what in zip(out, ref, ("pred_in", "pred_out", "bias")):
+        util.CLOSE[precision](got.detach().cpu().numpy()[keep], r.detach().numpy()[keep].astype(np.float32), f"{precision} training forward {what}")
+    gen = torch.Generator().manual_seed(5)
+    cot = [torch.randn(r.shape, generator=gen, dtype=torch.float64) for r in ref]
+    sum((r * c).sum() for r, c in zip(ref, cot)).backward()
+    sum((o.double() * c.to(DEV)).sum() for o, c in zip(out, cot)).backward()
+    params = dict(model.named_parameters())
+    worst = {}
+    for name, p64 in W64.items():
+        if name not in params or params[name].grad is None or p64.grad is None:
+            continue
+        denom = float(p64.grad.norm())
+        if denom > 1e-12:
+            worst[name] = float((params[name].grad.double().cpu() - p64.grad).norm()) / denom
+    bad = {k: v for k, v in worst.items() if v > lim}
+    assert not bad and len(worst) >= 40, bad
+
+
 def test_a_training_step_lowers_the_loss():
     """What train.py does with the path: predict embeddings, take a loss on them, step the hypernetwork's parameters."""
     from zett_amd.config import ZettHypernetConfig

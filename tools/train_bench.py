@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "f16"], help="arithmetic of the dense contractions (forward, dgrad, wgrad)")
     ap.add_argument("--dense", action="store_true", help="the reference's dense layout instead of the packed schedule")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -44,6 +45,8 @@ def main():
             dict(model.named_parameters())[name].copy_(w)
     model.requires_grad_(True).train()
     model.train_packed = not args.dense
+    model.train_precision = args.precision
+    peak = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}[args.precision]
     src = torch.from_numpy(synth.make_source_embeddings(cfg, seed=0, dtype=src_dtype)).to(dev)
     ids = torch.from_numpy(synth.make_surface_forms(cfg, rows, seed=0, hist=hist)).to(dev)
     lang = torch.tensor(3) if cfg.get("hn_embed_lang_id") else None
@@ -51,7 +54,7 @@ def main():
     orig = autograd.Ops.gemm
 
     def counted(self, x, w, *a, **k):
-        flops["n"] += 2.0 * x.shape[0] * w.shape[0] * x.shape[1]
+        flops["n"] += 2.0 * x.shape[0] * w.shape[0] * min(x.shape[1], w.shape[1])
         return orig(self, x, w, *a, **k)
 
     autograd.Ops.gemm = counted
@@ -86,11 +89,11 @@ def main():
     dt = time.perf_counter() - t0
     per = flops["n"] / args.steps
     print(json.dumps({"metric": "training step of the embedding-prediction path (forward + backward to every parameter)",
-                      "workload": args.workload, "rows": rows, "schedule": "dense" if args.dense else "packed (levers 1-3)", "dtype": "f32",
+                      "workload": args.workload, "rows": rows, "schedule": "dense" if args.dense else "packed (levers 1-3)", "dtype": args.precision,
                       "rows_per_s": rows * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                       "forward_ms": t_f / args.steps, "backward_ms": t_b / args.steps,
-                      "gemm_tflop_per_step": per / 1e12, "gemm_tflops_lower_bound": per / (dt / args.steps) / 1e12, "fp32_mfma_peak_tflops": 157.3,
-                      "frac_lower_bound": per / (dt / args.steps) / 1e12 / 157.3,
+                      "gemm_tflop_per_step": per / 1e12, "gemm_tflops_lower_bound": per / (dt / args.steps) / 1e12, "mfma_peak_tflops": peak,
+                      "frac_lower_bound": per / (dt / args.steps) / 1e12 / peak,
                       "peak_memory_gb": torch.cuda.max_memory_allocated() / 1e9}))
 
 

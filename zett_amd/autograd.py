@@ -20,7 +20,9 @@ Two schedules, same results to fp32 round-off (tests/test_autograd_gpu.py holds 
 ``backward_packed`` (the default) is the inference path's schedule — pad skipping, the input projection once per distinct
 referenced id, the position-0-only last layer: exact for gradients too (a position that cannot influence hidden[:, 0]
 receives a zero gradient; a value computed once and used k times receives the sum of the k gradients), 3.3x fewer FLOPs on
-the headline workload.  Not yet: the 16-bit MFMA modes.
+the headline workload.  The dense contractions run in exact fp32 MFMA (default) or on 16-bit MFMA operands (bf16 / f16:
+``model.train_precision``; operands converted — and for dgrad / wgrad transposed in the same pass — per launch, fp32
+accumulation, everything else fp32).
 """
 from __future__ import annotations
 
@@ -44,11 +46,19 @@ def _ptr(t: Optional[torch.Tensor]):
 class Ops:
     """The HIP primitives on torch tensors (fp32, one cuda device, current stream)."""
 
-    def __init__(self, device: torch.device):
+    def __init__(self, device: torch.device, precision: str = "f32"):
         if device.type != "cuda":
             raise RuntimeError("zett_amd computes on MI355X only: the differentiable forward needs cuda (ROCm) tensors; there is no CPU path")
+        if precision not in ("f32", "bf16", "f16"):
+            raise ValueError("training precision must be f32, bf16 or f16")
         self.lib = _lib.load()
         self.device = device
+        # arithmetic of the dense contractions (forward, dgrad, wgrad): exact fp32 MFMA, or 16-bit MFMA operands with fp32
+        # accumulation and fp32 everything else (parameters, activations, LayerNorm / GELU / softmax, gradients)
+        self.precision = precision
+        self.prec = {"f32": None, "bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16}[precision]
+        self.lo_dtype = {"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}[precision]
+        self.kstep = K_STEP if self.prec is None else 64          # contraction widths are multiples of this
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -57,8 +67,29 @@ class Ops:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     # ---- dense contraction: y[M,N] = act(x[M,K] . w[N,K]^T + bias) + residual
+    def to_lo(self, x):
+        """fp32 [R, C] -> 16-bit [R, C'] (C' = C zero-padded to the 64-wide K step): an operand of zett_op_gemm_lo"""
+        assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+        r, c = x.shape
+        cp = -(-c // 64) * 64
+        out = torch.empty((r, cp), dtype=self.lo_dtype, device=self.device)
+        _lib.check(self.lib.zett_op_convert_lo(self.prec, _ptr(x), x.stride(0), _ptr(out), cp, r, c, cp, self._stream()), "zett_op_convert_lo")
+        return out
+
     def gemm(self, x, w, bias=None, act=ACT_NONE, residual=None, out=None):
-        assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.stride(1) == 1 and w.stride(1) == 1
+        assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+        if self.prec is not None:
+            xa = x if x.dtype == self.lo_dtype else self.to_lo(x)
+            wa = w if w.dtype == self.lo_dtype else self.to_lo(w)
+            assert xa.shape[1] == wa.shape[1]
+            m, k, n = xa.shape[0], xa.shape[1], wa.shape[0]
+            if out is None:
+                out = self.new(m, n)
+            assert out.shape == (m, n) and out.is_contiguous()
+            _lib.check(self.lib.zett_op_gemm_lo(self.prec, _ptr(xa), xa.stride(0), _ptr(wa), wa.stride(0), m, n, k, _ptr(bias), act,
+                                                _ptr(residual), 0 if residual is None else residual.stride(0), _ptr(out), n, self._stream()), "zett_op_gemm_lo")
+            return out
+        assert x.shape[1] == w.shape[1]
         m, k = x.shape
         n = w.shape[0]
         if out is None:
@@ -79,7 +110,7 @@ class Ops:
         s_max = min(16, 256 // max(tiles, 1), mp // 2048)
         if s_max < 2:
             return self.gemm(dy_t, x_t)
-        per = -(-(mp // K_STEP) // s_max) * K_STEP                     # slice width, a multiple of the K step
+        per = -(-(mp // self.kstep) // s_max) * self.kstep             # slice width, a multiple of the K step
         bounds = [(a, min(a + per, mp)) for a in range(0, mp, per)]
         part = self.new(len(bounds), n, k)
         if not hasattr(self, "_side"):
@@ -94,10 +125,17 @@ class Ops:
             main.wait_stream(self._side[i])
         return self._colsum_raw(part.view(len(bounds), n * k)).view(n, k)
 
-    def transpose(self, x, pad_to=K_STEP):
+    def transpose(self, x, pad_to=None):
+        """[R, C] -> [C, R'] (R' = R zero-padded to the K step), in the operand type of the training GEMMs (fp32, or 16-bit:
+        the conversion rides on the transposition)"""
         assert x.dim() == 2 and x.stride(1) == 1
         r, c = x.shape
+        pad_to = pad_to or self.kstep
         rp = -(-r // pad_to) * pad_to
+        if self.prec is not None:
+            out = torch.empty((c, rp), dtype=self.lo_dtype, device=self.device)
+            _lib.check(self.lib.zett_op_transpose_lo(self.prec, _ptr(x), x.stride(0), _ptr(out), rp, r, c, rp, self._stream()), "zett_op_transpose_lo")
+            return out
         out = self.new(c, rp)
         _lib.check(self.lib.zett_op_transpose_f32(_ptr(x), x.stride(0), _ptr(out), rp, r, c, rp, self._stream()), "zett_op_transpose_f32")
         return out
@@ -239,8 +277,8 @@ class Ops:
     def linear_bwd(self, dy, x, w):
         """y = x w^T + b  ->  dx [M, K], dw [N, K], db [N]"""
         assert dy.is_contiguous() and dy.shape == (x.shape[0], w.shape[0])
-        if w.shape[0] % K_STEP:
-            raise NotImplementedError(f"the fp32 training GEMM contracts over multiples of {K_STEP}: a Linear with {w.shape[0]} outputs is not supported yet")
+        if w.shape[0] % self.kstep:
+            raise NotImplementedError(f"the training GEMM contracts over multiples of {self.kstep}: a Linear with {w.shape[0]} outputs is not supported yet")
         dx = self.gemm(dy, self.transpose(w))                           # A = dy [M, N], W-operand = w^T [K, N]
         dw = self.wgrad(self.transpose(dy), self.transpose(x))          # A = dy^T [N, M'], W-operand = x^T [K, M'] (M' = rows zero-padded to 32)
         return dx, dw, self.colsum(dy)
@@ -350,8 +388,8 @@ def forward_train(ops: Ops, dims: HypernetDims, ln_eps: float, P: Dict[str, torc
     lam = 1 if dims.embed_lang else 0
     Lp, H = L + lam, dims.hidden
     for name, width in (("n_embd", dims.n_embd), ("n_in_embd", dims.n_in_embd), ("hidden", H), ("intermediate", dims.intermediate)):
-        if width % K_STEP:
-            raise NotImplementedError(f"{name} = {width}: the fp32 training GEMM contracts over multiples of {K_STEP}")
+        if width % ops.kstep:
+            raise NotImplementedError(f"{name} = {width}: the training GEMM contracts over multiples of {ops.kstep}")
     S = {}
     ids32 = ids.to(torch.int32).contiguous()
     S["ids"] = ids32
@@ -487,8 +525,8 @@ def forward_packed(ops: Ops, dims: HypernetDims, ln_eps: float, P, ids: torch.Te
     lam = 1 if dims.embed_lang else 0
     Lp, H = L + lam, dims.hidden
     for name, width in (("n_embd", dims.n_embd), ("n_in_embd", dims.n_in_embd), ("hidden", H), ("intermediate", dims.intermediate)):
-        if width % K_STEP:
-            raise NotImplementedError(f"{name} = {width}: the fp32 training GEMM contracts over multiples of {K_STEP}")
+        if width % ops.kstep:
+            raise NotImplementedError(f"{name} = {width}: the training GEMM contracts over multiples of {ops.kstep}")
     S = dict(packed=True)
     plan = plan_packed(ids, dims.pad_token_id, lam)
     S["plan"] = plan
@@ -628,8 +666,8 @@ class HypernetFunction(torch.autograd.Function):
     the parameters only (the reference trains the hypernetwork against frozen source embeddings)."""
 
     @staticmethod
-    def forward(ctx, dims, ln_eps, names, packed, ids, src, lang, *params):
-        ops = Ops(src.device)
+    def forward(ctx, dims, ln_eps, names, packed, precision, ids, src, lang, *params):
+        ops = Ops(src.device, precision)
         P = {n: p.detach().float().contiguous() for n, p in zip(names, params)}
         with torch.no_grad(), torch.cuda.device(src.device):          # (the primitives launch on the CURRENT device and stream)
             fwd = forward_packed if packed else forward_train
@@ -651,17 +689,20 @@ class HypernetFunction(torch.autograd.Function):
             g = G.get(name)
             grads.append(None if g is None else g.reshape(p.shape))
         ctx.S = None
-        return (None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, *grads)
 
 
-def differentiable_forward(model, target_surface_forms: torch.Tensor, source_embeddings: torch.Tensor, lang_index: int, packed: bool = True):
+def differentiable_forward(model, target_surface_forms: torch.Tensor, source_embeddings: torch.Tensor, lang_index: int, packed: bool = True,
+                           precision: str = "f32"):
     """The forward of `model` (a zett_amd.hypernet.ZettHypernet) with gradients to its parameters.  packed = True (default):
     the schedule of the inference path (pad skipping, input projection per distinct id, position-0-only last layer);
-    False: the reference's dense layout, every position computed — same outputs and gradients to fp32 round-off."""
+    False: the reference's dense layout, every position computed — same outputs and gradients to fp32 round-off.
+    precision: "f32" (exact fp32 MFMA) or "bf16" / "f16" (16-bit MFMA operands in every forward / dgrad / wgrad contraction,
+    fp32 accumulation, fp32 parameters, activations and gradients)."""
     names = [n for n in weight_shapes(model.dims)]
     params = dict(model.named_parameters())
     tensors = [params[n] for n in names]
     src = source_embeddings if source_embeddings.dtype in _SRC_DTYPES else source_embeddings.float()
-    pred_in, pred_out, bias = HypernetFunction.apply(model.dims, model._ln_eps_encoder, tuple(names), bool(packed), target_surface_forms, src.contiguous(),
+    pred_in, pred_out, bias = HypernetFunction.apply(model.dims, model._ln_eps_encoder, tuple(names), bool(packed), str(precision), target_surface_forms, src.contiguous(),
                                                      int(lang_index), *tensors)
     return pred_in, (pred_out if model.dims.separate_out else None), bias

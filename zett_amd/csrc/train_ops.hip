@@ -58,6 +58,34 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// 16-bit operands of the training GEMMs: out[r, c] = lo(in[r, c]) (columns zero-padded to cols_padded), and the transposed
+// form out[c, r] = lo(in[r, c]) (rows zero-padded to rows_padded): conversion fused with the layout change
+template <typename T>
+__global__ void convert_lo_kernel(const float* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int64_t rows, int cols, int cols_padded) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = rows * cols_padded, stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int64_t r = i / cols_padded;
+        const int c = (int)(i % cols_padded);
+        out[r * ld_out + c] = to_lo<T>(c < cols ? in[r * ld_in + c] : 0.f);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_lo_kernel(const float* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int R, int C, int Rpad) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < C && r < Rpad) out[(size_t)c * ld_out + r] = to_lo<T>(tile[tx][k]);
+    }
+}
+
 // out[c] (+)= sum_r in[r, c]: one workgroup per 64 columns, rows strided over the four waves
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int ld, int R, int C, float* __restrict__ out, int accumulate) {
     __shared__ float part[4][64];
@@ -325,6 +353,22 @@ int grid_for(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 65535);
 
 }  // namespace
 
+// 16-bit MFMA operands, fp32 accumulate and output: the tile choice of the inference path (gemm4d from K = 512, gemm8r below,
+// 128x128 for small or unaligned outputs); prec = ZETT_PREC_BF16 | ZETT_PREC_F16
+template <typename T>
+static int gemm_lo(const T* a, int lda, const T* w, int ldw, int64_t m, int n, int k, const float* bias, int act, const float* residual, int ld_res,
+                   float* out, int ld_out, hipStream_t st) {
+    GemmArgs<T> g{};
+    g.A = a; g.lda = lda; g.W = w; g.ldw = ldw; g.M = (int)m; g.N = n; g.K = k;
+    g.epi.split_col = 0x7fffffff;
+    g.epi.bias = bias; g.epi.act = act; g.epi.residual = residual; g.epi.ld_res = ld_res; g.epi.out_f32 = out; g.epi.ld_f32 = ld_out;
+    const bool wide_ok = n % 8 == 0 && ld_out % 4 == 0 && (!residual || ld_res % 4 == 0);
+    const int variant = (m > 128 && n > 128 && wide_ok) ? (k >= 512 ? 7 : 2) : 1;
+    const hipError_t e = launch_gemm_variant(variant, g, st);
+    if (e != hipSuccess) return fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 extern "C" {
 
 int zett_op_gemm_f32(const float* a, int32_t lda, const float* w, int32_t ldw, int64_t m, int32_t n, int32_t k, const float* bias, int32_t act,
@@ -343,6 +387,40 @@ int zett_op_gemm_f32(const float* a, int32_t lda, const float* w, int32_t ldw, i
     const int variant = (m > 128 && n > 128 && wide_ok) ? 2 : 1;
     const hipError_t e = launch_gemm_variant(variant, g, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ZETT_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int zett_op_gemm_lo(int32_t prec, const void* a, int32_t lda, const void* w, int32_t ldw, int64_t m, int32_t n, int32_t k, const float* bias, int32_t act,
+                    const float* residual, int32_t ld_res, float* out, int32_t ld_out, void* stream) {
+    if (!a || !w || !out) return fail(ZETT_E_INVALID, "null argument");
+    if (prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "zett_op_gemm_lo takes ZETT_PREC_BF16 or ZETT_PREC_F16");
+    if (m <= 0 || n <= 0) return 0;
+    if (k <= 0 || k % 64) return fail(ZETT_E_INVALID, "contraction width %d is not a positive multiple of 64", k);
+    if (lda % 8 || ldw % 8) return fail(ZETT_E_INVALID, "operand leading dimensions must be multiples of 8 elements");
+    if (m >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many rows");
+    if (prec == ZETT_PREC_F16) return gemm_lo<f16_t>((const f16_t*)a, lda, (const f16_t*)w, ldw, m, n, k, bias, act, residual, ld_res, out, ld_out, (hipStream_t)stream);
+    return gemm_lo<bf16_t>((const bf16_t*)a, lda, (const bf16_t*)w, ldw, m, n, k, bias, act, residual, ld_res, out, ld_out, (hipStream_t)stream);
+}
+
+int zett_op_convert_lo(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int32_t cols_padded, void* stream) {
+    if (!in || !out || cols_padded < cols || ld_out < cols_padded) return fail(ZETT_E_INVALID, "bad conversion arguments");
+    if (prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "zett_op_convert_lo takes ZETT_PREC_BF16 or ZETT_PREC_F16");
+    if (rows <= 0 || cols <= 0) return 0;
+    const int grid = grid_for(rows * cols_padded);
+    if (prec == ZETT_PREC_F16) hipLaunchKernelGGL(convert_lo_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, (f16_t*)out, ld_out, rows, cols, cols_padded);
+    else hipLaunchKernelGGL(convert_lo_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, (bf16_t*)out, ld_out, rows, cols, cols_padded);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_transpose_lo(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream) {
+    if (!in || !out || rows_padded < rows || ld_out < rows_padded) return fail(ZETT_E_INVALID, "bad transpose arguments");
+    if (prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "zett_op_transpose_lo takes ZETT_PREC_BF16 or ZETT_PREC_F16");
+    if (rows <= 0 || cols <= 0) return 0;
+    const dim3 grid((cols + 31) / 32, (unsigned)((rows_padded + 31) / 32));
+    if (prec == ZETT_PREC_F16) hipLaunchKernelGGL(transpose_lo_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (f16_t*)out, ld_out, (int)rows, cols, (int)rows_padded);
+    else hipLaunchKernelGGL(transpose_lo_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (bf16_t*)out, ld_out, (int)rows, cols, (int)rows_padded);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

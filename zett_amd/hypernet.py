@@ -321,7 +321,8 @@ class ZettHypernet(PreTrainedModel):
             # from_pretrained returned (eval mode, whatever its parameters' requires_grad flags say) predicts on the
             # inference path, which builds no graph
             from .autograd import differentiable_forward
-            return differentiable_forward(self, target_surface_forms, source_embeddings, lang, packed=getattr(self, "train_packed", True))
+            return differentiable_forward(self, target_surface_forms, source_embeddings, lang, packed=getattr(self, "train_packed", True),
+                                          precision=getattr(self, "train_precision", "f32"))
         return self._guarded_forward(device, target_surface_forms, source_embeddings, lang)
 
     def _guarded_forward(self, device, surface_forms, source_embeddings, lang):
