@@ -70,19 +70,49 @@ __global__ void convert_lo_kernel(const float* __restrict__ in, int ld_in, T* __
         out[r * ld_out + c] = to_lo<T>(c < cols ? in[r * ld_in + c] : 0.f);
     }
 }
+// the common case (no column padding, widths multiples of 4): 16-byte loads, 8-byte stores, one row per workgroup pass
+template <typename T>
+__global__ __launch_bounds__(256) void convert_lo4_kernel(const float* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int64_t rows, int cols) {
+    const int c4 = cols >> 2;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float4* src = (const float4*)(in + r * ld_in);
+        uint2* dst = (uint2*)(out + r * ld_out);
+        for (int c = threadIdx.x; c < c4; c += 256) {
+            const float4 v = src[c];
+            dst[c] = make_uint2(pack2_lo<T>(v.x, v.y), pack2_lo<T>(v.z, v.w));
+        }
+    }
+}
+// 64 x 64 tiles through LDS: 16-byte loads along the input rows, 8-byte stores (four converted values) along the output rows
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_lo_kernel(const float* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int R, int C, int Rpad) {
-    __shared__ float tile[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k = ty; k < 32; k += 8) {
-        const int r = r0 + k, c = c0 + tx;
-        tile[k][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : 0.f;
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int t = threadIdx.x;
+    for (int k = t; k < 64 * 16; k += 256) {           // 64 rows x 16 float4
+        const int rr = k >> 4, cc = (k & 15) << 2;
+        const int r = r0 + rr, c = c0 + cc;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R) {
+            if (c + 3 < C && ((ld_in & 3) == 0)) v = *(const float4*)(in + (size_t)r * ld_in + c);
+            else {
+                if (c < C) v.x = in[(size_t)r * ld_in + c];
+                if (c + 1 < C) v.y = in[(size_t)r * ld_in + c + 1];
+                if (c + 2 < C) v.z = in[(size_t)r * ld_in + c + 2];
+                if (c + 3 < C) v.w = in[(size_t)r * ld_in + c + 3];
+            }
+        }
+        tile[rr][cc] = v.x; tile[rr][cc + 1] = v.y; tile[rr][cc + 2] = v.z; tile[rr][cc + 3] = v.w;
     }
     __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-        const int c = c0 + k, r = r0 + tx;
-        if (c < C && r < Rpad) out[(size_t)c * ld_out + r] = to_lo<T>(tile[tx][k]);
+    for (int k = t; k < 64 * 16; k += 256) {           // 64 output rows (= input columns) x 16 groups of four input rows
+        const int cc = k >> 4, rr = (k & 15) << 2;
+        const int c = c0 + cc, r = r0 + rr;
+        if (c >= C || r >= Rpad) continue;
+        if (r + 3 < Rpad && ((ld_out & 3) == 0))
+            *(uint2*)(out + (size_t)c * ld_out + r) = make_uint2(pack2_lo<T>(tile[rr][cc], tile[rr + 1][cc]), pack2_lo<T>(tile[rr + 2][cc], tile[rr + 3][cc]));
+        else
+            for (int j = 0; j < 4 && r + j < Rpad; ++j) out[(size_t)c * ld_out + r + j] = to_lo<T>(tile[rr + j][cc]);
     }
 }
 
@@ -406,9 +436,15 @@ int zett_op_convert_lo(int32_t prec, const float* in, int32_t ld_in, void* out, 
     if (!in || !out || cols_padded < cols || ld_out < cols_padded) return fail(ZETT_E_INVALID, "bad conversion arguments");
     if (prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "zett_op_convert_lo takes ZETT_PREC_BF16 or ZETT_PREC_F16");
     if (rows <= 0 || cols <= 0) return 0;
-    const int grid = grid_for(rows * cols_padded);
-    if (prec == ZETT_PREC_F16) hipLaunchKernelGGL(convert_lo_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, (f16_t*)out, ld_out, rows, cols, cols_padded);
-    else hipLaunchKernelGGL(convert_lo_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, (bf16_t*)out, ld_out, rows, cols, cols_padded);
+    if (cols_padded == cols && cols % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 7) == 0) {
+        const int grid = (int)std::min<int64_t>(rows, 65535);
+        if (prec == ZETT_PREC_F16) hipLaunchKernelGGL(convert_lo4_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, (f16_t*)out, ld_out, rows, cols);
+        else hipLaunchKernelGGL(convert_lo4_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, (bf16_t*)out, ld_out, rows, cols);
+    } else {
+        const int grid = grid_for(rows * cols_padded);
+        if (prec == ZETT_PREC_F16) hipLaunchKernelGGL(convert_lo_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, (f16_t*)out, ld_out, rows, cols, cols_padded);
+        else hipLaunchKernelGGL(convert_lo_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, (bf16_t*)out, ld_out, rows, cols, cols_padded);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -417,7 +453,8 @@ int zett_op_transpose_lo(int32_t prec, const float* in, int32_t ld_in, void* out
     if (!in || !out || rows_padded < rows || ld_out < rows_padded) return fail(ZETT_E_INVALID, "bad transpose arguments");
     if (prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "zett_op_transpose_lo takes ZETT_PREC_BF16 or ZETT_PREC_F16");
     if (rows <= 0 || cols <= 0) return 0;
-    const dim3 grid((cols + 31) / 32, (unsigned)((rows_padded + 31) / 32));
+    const dim3 grid((cols + 63) / 64, (unsigned)((rows_padded + 63) / 64));
+    if (((uintptr_t)in & 15) != 0 || ((uintptr_t)out & 7) != 0) return fail(ZETT_E_INVALID, "zett_op_transpose_lo needs a 16-byte aligned input and an 8-byte aligned output");
     if (prec == ZETT_PREC_F16) hipLaunchKernelGGL(transpose_lo_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (f16_t*)out, ld_out, (int)rows, cols, (int)rows_padded);
     else hipLaunchKernelGGL(transpose_lo_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (bf16_t*)out, ld_out, (int)rows, cols, (int)rows_padded);
     HIP_TRY(hipGetLastError());
