@@ -81,6 +81,66 @@ def test_layernorm_gelu_rowops_match_torch():
     assert torch.equal(ops.affine_cols(a, w, None), a * w) and torch.equal(ops.affine_cols(a, None, w), a + w)
 
 
+def test_layernorm_widths_residual_gradient_and_partials():
+    """every register layout of the LayerNorm kernels (H <= 1024, 2048, 4096, 8192 incl. a partly filled last pass), more rows
+    than workgroups (the partial sums of the parameter gradients), and the second gradient input (the residual branch)"""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for rows, h in ((3, 64), (130, 768), (1500, 1024), (70, 2048), (33, 3072), (20, 4096), (9, 8192)):
+        x = (torch.randn(rows, h, device=DEV, generator=g) * 2 - 0.3).requires_grad_(True)
+        gamma = (1 + 0.1 * torch.randn(h, device=DEV, generator=g)).requires_grad_(True)
+        beta = (0.1 * torch.randn(h, device=DEV, generator=g)).requires_grad_(True)
+        dy, dy2 = torch.randn(rows, h, device=DEV, generator=g), torch.randn(rows, h, device=DEV, generator=g)
+        y, st = ops.layernorm(x.detach(), gamma.detach(), beta.detach(), 1e-5)
+        ref = torch.nn.functional.layer_norm(x.double(), (h,), gamma.double(), beta.double(), 1e-5)
+        assert _rel(y, ref) < 1e-6, (rows, h)
+        ref.backward(dy.double() + dy2.double())
+        dx, dg, db = ops.layernorm_bwd(dy, x.detach(), st, gamma.detach(), dy2=dy2)
+        assert _rel(dx, x.grad) < 2e-5 and _rel(dg, gamma.grad) < 1e-5 and _rel(db, beta.grad) < 1e-5, (rows, h)
+        again = ops.layernorm_bwd(dy, x.detach(), st, gamma.detach(), dy2=dy2)
+        assert all(torch.equal(a, b) for a, b in zip((dx, dg, db), again))                   # fixed grid, fixed order: deterministic
+    with pytest.raises(Exception):
+        ops.layernorm(torch.randn(4, 8200, device=DEV), torch.ones(8200, device=DEV), torch.zeros(8200, device=DEV), 1e-5)
+
+
+def test_elementwise_and_gelu_wide_and_narrow_paths_agree():
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(12)
+    for rows, cols in ((50, 64), (7, 30), (33, 1028)):                                      # 16-byte path, scalar path (cols % 4 != 0), wide again
+        a, b = torch.randn(rows, cols, device=DEV, generator=g), torch.randn(rows, cols, device=DEV, generator=g)
+        w, s = torch.randn(cols, device=DEV, generator=g), torch.randn(rows, device=DEV, generator=g)
+        assert torch.equal(ops.add(a, b), a + b) and torch.equal(ops.mul(a, b), a * b)
+        assert torch.equal(ops.scale_rows(a, s), a * s[:, None])
+        assert torch.equal(ops.affine_cols(a, w, None), a * w) and torch.equal(ops.affine_cols(a, None, w), a + w)
+        assert _rel(ops.add_outer(a, s, w), a.double() + s.double()[:, None] * w.double()[None, :]) < 1e-6
+        for kind in (1, 2):
+            z, dh = a.reshape(-1), b.reshape(-1)
+            h1, h2 = ops.gelu(z, kind), ops.gelu(z[1:].clone(), kind)                        # (an odd length takes the scalar path)
+            assert torch.equal(h1[1:], h2) or z.numel() % 4
+            assert _rel(ops.gelu_bwd(z[1:].clone(), dh[1:].clone(), kind), ops.gelu_bwd(z, dh, kind)[1:]) < 1e-7
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_grad_operands_one_read_matches_the_separate_kernels(precision):
+    """zett_op_grad_operands_lo: lo(dy), lo(dy)^T (zero-padded) and the column sums from one read of dy — bit-equal to the
+    conversion and transposition kernels, the sums to float64"""
+    from zett_amd.autograd import Ops
+    ops = Ops(torch.device(DEV), precision)
+    g = torch.Generator(device=DEV).manual_seed(13)
+    for m, n in ((1, 64), (63, 128), (64, 64), (1000, 192), (4097, 320)):
+        dy = torch.randn(m, n, device=DEV, generator=g) * 3
+        lo, t, cs = ops.grad_operands(dy)
+        assert torch.equal(lo, ops.to_lo(dy)) and torch.equal(t, ops.transpose(dy))
+        assert t.shape[1] % 64 == 0 and bool((t[:, m:] == 0).all())
+        assert _rel(cs, dy.double().sum(0)) < 1e-6
+    x = torch.randn(5000, 256, device=DEV, generator=g)
+    w = torch.randn(128, 256, device=DEV, generator=g) * 0.1
+    dy = torch.randn(5000, 128, device=DEV, generator=g)
+    dx, dw, db = ops.linear_bwd(dy, x, w)
+    tol = 2e-2 if precision == "bf16" else 3e-3
+    assert _rel(dx, dy.double() @ w.double()) < tol and _rel(dw, dy.double().T @ x.double()) < tol and _rel(db, dy.double().sum(0)) < 1e-6
+
+
 def test_attention_forward_backward_match_torch():
     ops = _ops()
     g = torch.Generator(device=DEV).manual_seed(2)

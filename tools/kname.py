@@ -18,6 +18,6 @@ def demangle(name: str) -> str:
 
 
 def short(name: str, limit: int = 0) -> str:
-    name = demangle(name)
+    name = demangle(name).replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name).replace("void ", "").replace("unsigned short", "bf16")
     return name if (name.startswith("zett::") or not limit) else name[:limit]

@@ -204,14 +204,17 @@ class Ops:
                    "zett_op_layernorm_fwd_f32")
         return y, stats
 
-    def layernorm_bwd(self, dy, x, stats, gamma):
-        """-> dx, dgamma, dbeta"""
-        assert dy.is_contiguous() and x.stride(1) == 1
+    def layernorm_bwd(self, dy, x, stats, gamma, dy2=None):
+        """-> dx, dgamma, dbeta for the gradient dy (+ dy2: the part arriving over the residual branch, added inside the kernel).
+        The parameter gradients leave the kernel as per-workgroup partial sums (no [R, H] product is written)."""
+        assert dy.is_contiguous() and x.stride(1) == 1 and (dy2 is None or (dy2.is_contiguous() and dy2.shape == dy.shape))
         r, h = x.shape
-        dx, dyxhat = self.new(r, h), self.new(r, h)
-        _lib.check(self.lib.zett_op_layernorm_bwd_f32(_ptr(dy), _ptr(x), x.stride(0), _ptr(stats), _ptr(gamma), _ptr(dx), _ptr(dyxhat), r, h, self._stream()),
-                   "zett_op_layernorm_bwd_f32")
-        return dx, self.colsum(dyxhat), self.colsum(dy)
+        n_part = max(1, min(r, 1024))
+        dx, part = self.new(r, h), self.new(n_part, 2 * h)
+        _lib.check(self.lib.zett_op_layernorm_bwd_f32(_ptr(dy), _ptr(dy2), _ptr(x), x.stride(0), _ptr(stats), _ptr(gamma), _ptr(dx), _ptr(part), n_part, r, h,
+                                                      self._stream()), "zett_op_layernorm_bwd_f32")
+        g = self._colsum_raw(part)
+        return dx, g[:h], g[h:]
 
     def gelu(self, z, kind):
         h = self.new(*z.shape)
@@ -274,11 +277,26 @@ class Ops:
         return dfb, self.colsum(prod), self.colsum(keep)
 
     # ---- Linear backward on the same GEMM: dgrad against W^T, wgrad of the transposed activations
+    def grad_operands(self, dy):
+        """16-bit arithmetic: one read of dy [M, N] -> (lo(dy) [M, N], lo(dy)^T [N, M'], column sums of dy [N])"""
+        m, n = dy.shape
+        mp = -(-m // self.kstep) * self.kstep
+        bands = -(-m // 64)
+        dy_lo = torch.empty((m, n), dtype=self.lo_dtype, device=self.device)
+        dy_t = torch.empty((n, mp), dtype=self.lo_dtype, device=self.device)
+        part = self.new(bands, n)
+        _lib.check(self.lib.zett_op_grad_operands_lo(self.prec, _ptr(dy), dy.stride(0), m, n, mp, _ptr(dy_lo), n, _ptr(dy_t), mp, _ptr(part), self._stream()),
+                   "zett_op_grad_operands_lo")
+        return dy_lo, dy_t, self.colsum(part)
+
     def linear_bwd(self, dy, x, w):
         """y = x w^T + b  ->  dx [M, K], dw [N, K], db [N]"""
         assert dy.is_contiguous() and dy.shape == (x.shape[0], w.shape[0])
         if w.shape[0] % self.kstep:
             raise NotImplementedError(f"the training GEMM contracts over multiples of {self.kstep}: a Linear with {w.shape[0]} outputs is not supported yet")
+        if self.prec is not None and dy.shape[0] > 0:
+            dy_lo, dy_t, db = self.grad_operands(dy)
+            return self.gemm(dy_lo, self.transpose(w)), self.wgrad(dy_t, self.transpose(x)), db
         dx = self.gemm(dy, self.transpose(w))                           # A = dy [M, N], W-operand = w^T [K, N]
         dw = self.wgrad(self.transpose(dy), self.transpose(x))          # A = dy^T [N, M'], W-operand = x^T [K, M'] (M' = rows zero-padded to 32)
         return dx, dw, self.colsum(dy)
@@ -448,18 +466,17 @@ def backward_train(ops: Ops, dims: HypernetDims, P: Dict[str, torch.Tensor], S, 
     # ---- encoder (only position 0 of the last hidden state carries a gradient)
     dz = zeros(n, Lp, H)
     dz[:, 0] = dcls                                                       # layout plumbing
-    dz = dz.view(n * Lp, H)
+    dz, dz_res = dz.view(n * Lp, H), None                                 # dz_res: the part of the gradient that came over a residual branch
     for l in reversed(range(dims.layers)):
         p = f"model.encoder.layer.{l}."
         a = p + "attention.self."
         A = S["layers"][l]
-        ds2, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = ops.layernorm_bwd(dz, A["s2"], A["st2"], P[p + "output.LayerNorm.weight"])
+        ds2, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = ops.layernorm_bwd(dz, A["s2"], A["st2"], P[p + "output.LayerNorm.weight"], dy2=dz_res)
         dg, G[p + "output.dense.weight"], G[p + "output.dense.bias"] = ops.linear_bwd(ds2, A["g"], P[p + "output.dense.weight"])
         du = ops.gelu_bwd(A["u"], dg, GELU_ERF)
         dz1, G[p + "intermediate.dense.weight"], G[p + "intermediate.dense.bias"] = ops.linear_bwd(du, A["z1"], P[p + "intermediate.dense.weight"])
-        dz1 = ops.add(dz1, ds2)                                           # residual of the FFN
         ds1, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
-            ops.layernorm_bwd(dz1, A["s1"], A["st1"], P[p + "attention.output.LayerNorm.weight"])
+            ops.layernorm_bwd(dz1, A["s1"], A["st1"], P[p + "attention.output.LayerNorm.weight"], dy2=ds2)        # + the residual of the FFN
         dctx, G[p + "attention.output.dense.weight"], G[p + "attention.output.dense.bias"] = ops.linear_bwd(ds1, A["ctx"], P[p + "attention.output.dense.weight"])
         dqkv = ops.new(n * Lp, 3 * H)
         qkv = A["qkv"]
@@ -469,10 +486,10 @@ def backward_train(ops: Ops, dims: HypernetDims, P: Dict[str, torch.Tensor], S, 
         for i, name in enumerate(("query", "key", "value")):
             G[a + name + ".weight"] = dwqkv[i * H:(i + 1) * H].clone()
             G[a + name + ".bias"] = dbqkv[i * H:(i + 1) * H].clone()
-        dz = ops.add(dzin, ds1)                                           # residual of the attention block
+        dz, dz_res = dzin, ds1                                            # residual of the attention block: added inside the next LayerNorm backward
     # ---- embeddings
     demb, G["model.embeddings.LayerNorm.weight"], G["model.embeddings.LayerNorm.bias"] = \
-        ops.layernorm_bwd(dz, S["emb"], S["emb_st"], P["model.embeddings.LayerNorm.weight"])
+        ops.layernorm_bwd(dz, S["emb"], S["emb_st"], P["model.embeddings.LayerNorm.weight"], dy2=dz_res)
     per_pos = ops.colsum(demb.view(n, Lp * H)).view(Lp, H)                # sum over the rows, per position
     dpos = torch.zeros_like(P["model.embeddings.position_embeddings.weight"])
     dpos[:L] = per_pos[:L]                                                # (the language token's type / position terms cancel: :192-199)
@@ -603,19 +620,18 @@ def backward_packed(ops: Ops, dims: HypernetDims, P, S, src, lang, d_in, d_out, 
     T = plan["n_tokens"]
     off = plan["row_offset"]
     dev = ids.device
-    dz = _heads_bwd(ops, dims, P, S, G, n, d_in, d_out, d_bias)              # [n, H]: gradient of hidden[:, 0]
+    dz, dz_res = _heads_bwd(ops, dims, P, S, G, n, d_in, d_out, d_bias), None    # [n, H]: gradient of hidden[:, 0]
     for l in reversed(range(dims.layers)):
         p = f"model.encoder.layer.{l}."
         a = p + "attention.self."
         A = S["layers"][l]
         last = l == dims.layers - 1
-        ds2, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = ops.layernorm_bwd(dz, A["s2"], A["st2"], P[p + "output.LayerNorm.weight"])
+        ds2, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = ops.layernorm_bwd(dz, A["s2"], A["st2"], P[p + "output.LayerNorm.weight"], dy2=dz_res)
         dg, G[p + "output.dense.weight"], G[p + "output.dense.bias"] = ops.linear_bwd(ds2, A["g"], P[p + "output.dense.weight"])
         du = ops.gelu_bwd(A["u"], dg, GELU_ERF)
         dz1, G[p + "intermediate.dense.weight"], G[p + "intermediate.dense.bias"] = ops.linear_bwd(du, A["z1"], P[p + "intermediate.dense.weight"])
-        dz1 = ops.add(dz1, ds2)
         ds1, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
-            ops.layernorm_bwd(dz1, A["s1"], A["st1"], P[p + "attention.output.LayerNorm.weight"])
+            ops.layernorm_bwd(dz1, A["s1"], A["st1"], P[p + "attention.output.LayerNorm.weight"], dy2=ds2)        # + the residual of the FFN
         dctx, G[p + "attention.output.dense.weight"], G[p + "attention.output.dense.bias"] = ops.linear_bwd(ds1, A["ctx"], P[p + "attention.output.dense.weight"])
         wqkv = A["wqkv"]
         if not last:
@@ -624,7 +640,7 @@ def backward_packed(ops: Ops, dims: HypernetDims, P, S, src, lang, d_in, d_out, 
             ops.attention_bwd(dctx, qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], A["probs"], off, n, seq, dims.heads, H,
                               dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:])
             dzin, dwqkv, dbqkv = ops.linear_bwd(dqkv, A["z"], wqkv)
-            dz = ops.add(dzin, ds1)
+            dz, dz_res = dzin, ds1                                              # (added inside the next LayerNorm backward)
         else:
             kv, qc = A["kv"], A["qc"]
             dqc, dkv = ops.new(n, H), ops.new(T, 2 * H)
@@ -633,12 +649,13 @@ def backward_packed(ops: Ops, dims: HypernetDims, P, S, src, lang, d_in, d_out, 
             dzc = ops.add(dzc, ds1)                                             # the residual of the attention block, position 0 only
             dz, dwkv, dbkv = ops.linear_bwd(dkv, A["z"], wqkv[H:])
             ops.scatter_add_rows(dz, plan["cls"], dzc)
+            dz_res = None
             dwqkv, dbqkv = torch.cat([dwq, dwkv], 0), torch.cat([dbq, dbkv], 0)
         for i, name in enumerate(("query", "key", "value")):
             G[a + name + ".weight"] = dwqkv[i * H:(i + 1) * H].clone()
             G[a + name + ".bias"] = dbqkv[i * H:(i + 1) * H].clone()
     demb, G["model.embeddings.LayerNorm.weight"], G["model.embeddings.LayerNorm.bias"] = \
-        ops.layernorm_bwd(dz, S["emb"], S["emb_st"], P["model.embeddings.LayerNorm.weight"])
+        ops.layernorm_bwd(dz, S["emb"], S["emb_st"], P["model.embeddings.LayerNorm.weight"], dy2=dz_res)
     per_pos = torch.zeros((Lp, H), dtype=torch.float32, device=dev)
     ops.scatter_add_rows(per_pos, plan["tok_pos"], demb)
     dpos = torch.zeros_like(P["model.embeddings.position_embeddings.weight"])

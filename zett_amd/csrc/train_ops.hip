@@ -83,9 +83,13 @@ __global__ __launch_bounds__(256) void convert_lo4_kernel(const float* __restric
         }
     }
 }
-// 64 x 64 tiles through LDS: 16-byte loads along the input rows, 8-byte stores (four converted values) along the output rows
+// 64 x 64 tiles through LDS: 16-byte loads along the input rows, 8-byte stores (four converted values) along the output rows.
+// One read of a gradient serves everything a Linear's backward needs from it: `plain` (nullable) gets the un-transposed 16-bit
+// copy (dgrad's A operand), `colpart` (nullable, [ceil(R / 64), C]) the column sums of each 64-row band (their sum is the bias
+// gradient: a deterministic two-level reduction, no atomics).
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_lo_kernel(const float* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int R, int C, int Rpad) {
+__global__ __launch_bounds__(256) void transpose_lo_kernel(const float* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int R, int C, int Rpad,
+                                                           T* __restrict__ plain, int ld_plain, float* __restrict__ colpart) {
     __shared__ float tile[64][65];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int t = threadIdx.x;
@@ -101,10 +105,25 @@ __global__ __launch_bounds__(256) void transpose_lo_kernel(const float* __restri
                 if (c + 2 < C) v.z = in[(size_t)r * ld_in + c + 2];
                 if (c + 3 < C) v.w = in[(size_t)r * ld_in + c + 3];
             }
+            if (plain) {
+                if (c + 3 < C && ((ld_plain & 3) == 0)) *(uint2*)(plain + (size_t)r * ld_plain + c) = make_uint2(pack2_lo<T>(v.x, v.y), pack2_lo<T>(v.z, v.w));
+                else {
+                    if (c < C) plain[(size_t)r * ld_plain + c] = to_lo<T>(v.x);
+                    if (c + 1 < C) plain[(size_t)r * ld_plain + c + 1] = to_lo<T>(v.y);
+                    if (c + 2 < C) plain[(size_t)r * ld_plain + c + 2] = to_lo<T>(v.z);
+                    if (c + 3 < C) plain[(size_t)r * ld_plain + c + 3] = to_lo<T>(v.w);
+                }
+            }
         }
         tile[rr][cc] = v.x; tile[rr][cc + 1] = v.y; tile[rr][cc + 2] = v.z; tile[rr][cc + 3] = v.w;
     }
     __syncthreads();
+    if (colpart && r0 < R && t < 64 && c0 + t < C) {   // (bands past R exist only as zero padding of the transposed output)
+        float s = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < 64; ++rr) s += tile[rr][t];
+        colpart[(size_t)blockIdx.y * C + c0 + t] = s;
+    }
     for (int k = t; k < 64 * 16; k += 256) {           // 64 output rows (= input columns) x 16 groups of four input rows
         const int cc = k >> 4, rr = (k & 15) << 2;
         const int c = c0 + cc, r = r0 + rr;
@@ -132,23 +151,38 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
 }
 
 // op 0: out = a + b;  1: out = a * b;  2: out = a * vec[col] + vec2[col] (vec null: 1, vec2 null: 0);  3: out = a + s[row] * vec[col];
-// 4: out = a * s[row] (a may be null: out = s[row] * vec[col])
-__global__ void elementwise_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ vec,
-                                   const float* __restrict__ vec2, const float* __restrict__ s, float* __restrict__ out, int64_t n, int cols) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// 4: out = a * s[row] (a may be null: out = s[row] * vec[col]).  One thread per four consecutive elements of a row (cols % 4 == 0:
+// 16-byte accesses, one division per four values) or per element (V = 1).
+template <int V>
+__global__ __launch_bounds__(256) void elementwise_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ vec,
+                                                          const float* __restrict__ vec2, const float* __restrict__ s, float* __restrict__ out, int64_t n, int cols) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * V;
     for (; i < n; i += stride) {
-        const int col = (int)(i % cols);
-        const int64_t row = i / cols;
-        float v;
-        switch (op) {
-            case 0: v = a[i] + b[i]; break;
-            case 1: v = a[i] * b[i]; break;
-            case 2: v = (vec ? a[i] * vec[col] : a[i]) + (vec2 ? vec2[col] : 0.f); break;
-            case 3: v = a[i] + s[row] * vec[col]; break;
-            default: v = a ? a[i] * s[row] : s[row] * vec[col]; break;
+        float av[V], bv[V], ov[V];
+        if (V == 4) {
+            if (a) *(float4*)av = *(const float4*)(a + i);
+            if (b) *(float4*)bv = *(const float4*)(b + i);
+        } else {
+            if (a) av[0] = a[i];
+            if (b) bv[0] = b[i];
         }
-        out[i] = v;
+        int col = 0;
+        int64_t row = 0;
+        if (op >= 2) { row = i / cols; col = (int)(i - row * cols); }
+        const float sr = (op >= 3) ? s[row] : 0.f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            switch (op) {
+                case 0: ov[e] = av[e] + bv[e]; break;
+                case 1: ov[e] = av[e] * bv[e]; break;
+                case 2: ov[e] = (vec ? av[e] * vec[col + e] : av[e]) + (vec2 ? vec2[col + e] : 0.f); break;
+                case 3: ov[e] = av[e] + sr * vec[col + e]; break;
+                default: ov[e] = a ? av[e] * sr : sr * vec[col + e]; break;
+            }
+        }
+        if (V == 4) *(float4*)(out + i) = *(float4*)ov;
+        else out[i] = ov[0];
     }
 }
 
@@ -165,68 +199,155 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a
 }
 
 // ---- LayerNorm ------------------------------------------------------------------------------------------------------
-// y = (x - mean) * rstd * gamma + beta; stats[r] = (mean, rstd)   (two-pass variance, as torch.nn.LayerNorm)
+// y = (x - mean) * rstd * gamma + beta; stats[r] = (mean, rstd)   (two-pass variance, as torch.nn.LayerNorm).  A row is read
+// once, into registers: a thread owns columns 4 (tid + 256 j) ... + 3, j < J (H <= 1024 J, H % 4 == 0).
+template <int J>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float* __restrict__ y, float* __restrict__ stats, int R, int H) {
     __shared__ float red[4];
-    const int r = blockIdx.x;
-    if (r >= R) return;
-    const float* xr = x + (size_t)r * ld;
-    float s = 0.f;
-    for (int c = threadIdx.x; c < H; c += 256) s += xr[c];
-    const float mean = t_block_sum(s, red) / (float)H;
-    float q = 0.f;
-    for (int c = threadIdx.x; c < H; c += 256) { const float d = xr[c] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(t_block_sum(q, red) / (float)H + eps);
-    if (threadIdx.x == 0) { stats[2 * (size_t)r] = mean; stats[2 * (size_t)r + 1] = rstd; }
-    for (int c = threadIdx.x; c < H; c += 256) y[(size_t)r * H + c] = ln_affine(xr[c], mean, rstd, gamma[c], beta[c]);
+    const int tid = threadIdx.x;
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        float4 v[J];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int c = 4 * (tid + 256 * j);
+            v[j] = c < H ? *(const float4*)(x + (size_t)r * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        const float mean = t_block_sum(s, red) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (4 * (tid + 256 * j) < H) {
+                const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+                q += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(t_block_sum(q, red) / (float)H + eps);
+        if (tid == 0) { stats[2 * (size_t)r] = mean; stats[2 * (size_t)r + 1] = rstd; }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int c = 4 * (tid + 256 * j);
+            if (c < H) {
+                const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+                *(float4*)(y + (size_t)r * H + c) = make_float4(ln_affine(v[j].x, mean, rstd, g.x, b.x), ln_affine(v[j].y, mean, rstd, g.y, b.y),
+                                                                ln_affine(v[j].z, mean, rstd, g.z, b.z), ln_affine(v[j].w, mean, rstd, g.w, b.w));
+            }
+        }
+    }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd;
-// dyxhat = dy * xhat (its column sum is dgamma; dbeta is the column sum of dy)
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int ld, const float* __restrict__ stats,
-                                                     const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ dyxhat, int R, int H) {
-    __shared__ float red[4];
-    const int r = blockIdx.x;
-    if (r >= R) return;
-    const float mean = stats[2 * (size_t)r], rstd = stats[2 * (size_t)r + 1];
-    const float* xr = x + (size_t)r * ld;
-    const float* dyr = dy + (size_t)r * H;
-    float sg = 0.f, sgx = 0.f;
-    for (int c = threadIdx.x; c < H; c += 256) {
-        const float xh = (xr[c] - mean) * rstd, g = dyr[c] * gamma[c];
-        sg += g; sgx += g * xh;
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd, dy = dy1 (+ dy2: the gradient
+// arriving over the residual branch, added here instead of in a pass of its own).  The parameter gradients ride along:
+// workgroup b walks rows b, b + gridDim.x, ... and keeps, per thread, the running sums of dy * xhat (-> dgamma) and dy (-> dbeta)
+// of its columns; they leave as partials[b] = (dgamma part [H], dbeta part [H]) and one small column sum over the gridDim.x
+// partials finishes them — the same result for the same grid, no atomics, and no [R, H] product written or read.
+// A thread owns columns 4 (tid + 256 j) ... + 3, j < J (H <= 1024 J, H % 4 == 0); a row is read once, into registers.
+template <int J>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy1, const float* __restrict__ dy2, const float* __restrict__ x, int ld,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma, float* __restrict__ dx,
+                                                     float* __restrict__ partials, int R, int H) {
+    __shared__ float red[2][2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4 gam[J], ag[J], ab[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = 4 * (tid + 256 * j);
+        gam[j] = c < H ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ag[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float mg = t_block_sum(sg, red) / (float)H;
-    const float mgx = t_block_sum(sgx, red) / (float)H;
-    for (int c = threadIdx.x; c < H; c += 256) {
-        const float xh = (xr[c] - mean) * rstd, g = dyr[c] * gamma[c];
-        dx[(size_t)r * H + c] = rstd * (g - mg - xh * mgx);
-        dyxhat[(size_t)r * H + c] = dyr[c] * xh;
+    int par = 0;
+    for (int r = blockIdx.x; r < R; r += gridDim.x, par ^= 1) {
+        const float mean = stats[2 * (size_t)r], rstd = stats[2 * (size_t)r + 1];
+        float4 xh[J], d[J];
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int c = 4 * (tid + 256 * j);
+            xh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            d[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < H) {
+                const float4 xv = *(const float4*)(x + (size_t)r * ld + c);
+                d[j] = *(const float4*)(dy1 + (size_t)r * H + c);
+                if (dy2) {
+                    const float4 e = *(const float4*)(dy2 + (size_t)r * H + c);
+                    d[j].x += e.x; d[j].y += e.y; d[j].z += e.z; d[j].w += e.w;
+                }
+                xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                const float4 g = make_float4(d[j].x * gam[j].x, d[j].y * gam[j].y, d[j].z * gam[j].z, d[j].w * gam[j].w);
+                sg += (g.x + g.y) + (g.z + g.w);
+                sgx += (g.x * xh[j].x + g.y * xh[j].y) + (g.z * xh[j].z + g.w * xh[j].w);
+            }
+        }
+        sg = t_wave_sum(sg);
+        sgx = t_wave_sum(sgx);
+        if (lane == 0) { red[par][0][wave] = sg; red[par][1][wave] = sgx; }
+        __syncthreads();                               // (the other parity's slots are rewritten only after the next barrier)
+        const float mg = ((red[par][0][0] + red[par][0][1]) + (red[par][0][2] + red[par][0][3])) / (float)H;
+        const float mgx = ((red[par][1][0] + red[par][1][1]) + (red[par][1][2] + red[par][1][3])) / (float)H;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int c = 4 * (tid + 256 * j);
+            if (c < H) {
+                float4 o;
+                o.x = rstd * (d[j].x * gam[j].x - mg - xh[j].x * mgx);
+                o.y = rstd * (d[j].y * gam[j].y - mg - xh[j].y * mgx);
+                o.z = rstd * (d[j].z * gam[j].z - mg - xh[j].z * mgx);
+                o.w = rstd * (d[j].w * gam[j].w - mg - xh[j].w * mgx);
+                *(float4*)(dx + (size_t)r * H + c) = o;
+                ag[j].x += d[j].x * xh[j].x; ag[j].y += d[j].y * xh[j].y; ag[j].z += d[j].z * xh[j].z; ag[j].w += d[j].w * xh[j].w;
+                ab[j].x += d[j].x; ab[j].y += d[j].y; ab[j].z += d[j].z; ab[j].w += d[j].w;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = 4 * (tid + 256 * j);
+        if (c < H) {
+            *(float4*)(partials + ((size_t)blockIdx.x * 2) * H + c) = ag[j];
+            *(float4*)(partials + ((size_t)blockIdx.x * 2 + 1) * H + c) = ab[j];
+        }
     }
 }
 
 // ---- GELU -----------------------------------------------------------------------------------------------------------
 // kind 1: F.gelu(approximate="tanh") (ProjectorBlock), 2: erf form (RobertaIntermediate) — the forward functions of gemm.hip.h
-__global__ void gelu_fwd_kernel(const float* __restrict__ z, float* __restrict__ h, int64_t n, int kind) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) h[i] = kind == 1 ? gelu_tanh_f(z[i]) : gelu_erf_f(z[i]);
+__device__ __forceinline__ float gelu_fwd1(float x, int kind) { return kind == 1 ? gelu_tanh_f(x) : gelu_erf_f(x); }
+__device__ __forceinline__ float gelu_grad1(float x, int kind) {
+    if (kind == 1) {       // d/dx [0.5 x (1 + tanh u)], u = sqrt(2/pi) (x + 0.044715 x^3)
+        const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+        const float t = tanhf(u);
+        return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+    }
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);       // Phi(x) + x phi(x)
 }
-__global__ void gelu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dh, float* __restrict__ dz, int64_t n, int kind) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// V = 4: 16-byte accesses (n % 4 == 0, aligned), V = 1 otherwise
+template <int V>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ z, float* __restrict__ h, int64_t n, int kind) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * V;
     for (; i < n; i += stride) {
-        const float x = z[i];
-        float d;
-        if (kind == 1) {       // d/dx [0.5 x (1 + tanh u)], u = sqrt(2/pi) (x + 0.044715 x^3)
-            const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-            const float t = tanhf(u);
-            d = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
-        } else {               // Phi(x) + x phi(x)
-            d = 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+        if (V == 4) {
+            const float4 v = *(const float4*)(z + i);
+            *(float4*)(h + i) = make_float4(gelu_fwd1(v.x, kind), gelu_fwd1(v.y, kind), gelu_fwd1(v.z, kind), gelu_fwd1(v.w, kind));
+        } else {
+            h[i] = gelu_fwd1(z[i], kind);
         }
-        dz[i] = dh[i] * d;
+    }
+}
+template <int V>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dh, float* __restrict__ dz, int64_t n, int kind) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * V;
+    for (; i < n; i += stride) {
+        if (V == 4) {
+            const float4 v = *(const float4*)(z + i), g = *(const float4*)(dh + i);
+            *(float4*)(dz + i) = make_float4(g.x * gelu_grad1(v.x, kind), g.y * gelu_grad1(v.y, kind), g.z * gelu_grad1(v.z, kind), g.w * gelu_grad1(v.w, kind));
+        } else {
+            dz[i] = dh[i] * gelu_grad1(z[i], kind);
+        }
     }
 }
 
@@ -449,16 +570,33 @@ int zett_op_convert_lo(int32_t prec, const float* in, int32_t ld_in, void* out, 
     return 0;
 }
 
-int zett_op_transpose_lo(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream) {
+static int transpose_lo_launch(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded,
+                               void* plain, int32_t ld_plain, float* colpart, void* stream) {
     if (!in || !out || rows_padded < rows || ld_out < rows_padded) return fail(ZETT_E_INVALID, "bad transpose arguments");
-    if (prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "zett_op_transpose_lo takes ZETT_PREC_BF16 or ZETT_PREC_F16");
+    if (prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "the 16-bit transposes take ZETT_PREC_BF16 or ZETT_PREC_F16");
     if (rows <= 0 || cols <= 0) return 0;
+    if (plain && ld_plain < cols) return fail(ZETT_E_INVALID, "bad leading dimension of the plain copy");
     const dim3 grid((cols + 63) / 64, (unsigned)((rows_padded + 63) / 64));
-    if (((uintptr_t)in & 15) != 0 || ((uintptr_t)out & 7) != 0) return fail(ZETT_E_INVALID, "zett_op_transpose_lo needs a 16-byte aligned input and an 8-byte aligned output");
-    if (prec == ZETT_PREC_F16) hipLaunchKernelGGL(transpose_lo_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (f16_t*)out, ld_out, (int)rows, cols, (int)rows_padded);
-    else hipLaunchKernelGGL(transpose_lo_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (bf16_t*)out, ld_out, (int)rows, cols, (int)rows_padded);
+    if (((uintptr_t)in & 15) != 0 || ((uintptr_t)out & 7) != 0 || ((uintptr_t)plain & 7) != 0)
+        return fail(ZETT_E_INVALID, "the 16-bit transposes need a 16-byte aligned input and 8-byte aligned outputs");
+    if (prec == ZETT_PREC_F16)
+        hipLaunchKernelGGL(transpose_lo_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (f16_t*)out, ld_out, (int)rows, cols, (int)rows_padded,
+                           (f16_t*)plain, ld_plain, colpart);
+    else
+        hipLaunchKernelGGL(transpose_lo_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (bf16_t*)out, ld_out, (int)rows, cols, (int)rows_padded,
+                           (bf16_t*)plain, ld_plain, colpart);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int zett_op_transpose_lo(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream) {
+    return transpose_lo_launch(prec, in, ld_in, out, ld_out, rows, cols, rows_padded, nullptr, 0, nullptr, stream);
+}
+
+int zett_op_grad_operands_lo(int32_t prec, const float* dy, int32_t ld, int64_t rows, int32_t cols, int64_t rows_padded, void* dy_lo, int32_t ld_lo,
+                             void* dy_t, int32_t ld_t, float* colsum_part, void* stream) {
+    if (!dy_lo || !colsum_part) return fail(ZETT_E_INVALID, "null argument");
+    return transpose_lo_launch(prec, dy, ld, dy_t, ld_t, rows, cols, rows_padded, dy_lo, ld_lo, colsum_part, stream);
 }
 
 int zett_op_transpose_f32(const float* in, int32_t ld_in, float* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream) {
@@ -482,7 +620,9 @@ int zett_op_elementwise_f32(int32_t op, const float* a, const float* b, const fl
                             int64_t n, int32_t cols, void* stream) {
     if (!out || op < 0 || op > 4 || cols <= 0) return fail(ZETT_E_INVALID, "bad elementwise arguments");
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(elementwise_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, op, a, b, vec, vec2, s, out, n, cols);
+    const bool wide = cols % 4 == 0 && n % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0;
+    if (wide) hipLaunchKernelGGL(elementwise_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, op, a, b, vec, vec2, s, out, n, cols);
+    else hipLaunchKernelGGL(elementwise_kernel<1>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, op, a, b, vec, vec2, s, out, n, cols);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -498,17 +638,34 @@ int zett_op_rowdot_f32(const float* a, int32_t ld, const float* w, const float* 
 int zett_op_layernorm_fwd_f32(const float* x, int32_t ld, const float* gamma, const float* beta, float eps, float* y, float* stats,
                               int64_t rows, int32_t h, void* stream) {
     if (!x || !gamma || !beta || !y || !stats) return fail(ZETT_E_INVALID, "null argument");
+    if (h < 4 || h % 4 || h > 8192 || ld % 4) return fail(ZETT_E_INVALID, "LayerNorm: 4 <= h <= 8192, h and ld multiples of 4");
+    if ((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15) != 0) return fail(ZETT_E_INVALID, "LayerNorm needs 16-byte aligned rows");
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, ld, gamma, beta, eps, y, stats, (int)rows, h);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)std::min<int64_t>(rows, 16384)), block(256);
+    const int j = (h + 1023) / 1024;
+    if (j <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h);
+    else if (j <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h);
+    else if (j <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h);
+    else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int zett_op_layernorm_bwd_f32(const float* dy, const float* x, int32_t ld, const float* stats, const float* gamma, float* dx, float* dyxhat,
-                              int64_t rows, int32_t h, void* stream) {
-    if (!dy || !x || !stats || !gamma || !dx || !dyxhat) return fail(ZETT_E_INVALID, "null argument");
-    if (rows <= 0) return 0;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, x, ld, stats, gamma, dx, dyxhat, (int)rows, h);
+int zett_op_layernorm_bwd_f32(const float* dy, const float* dy2, const float* x, int32_t ld, const float* stats, const float* gamma, float* dx,
+                              float* partials, int32_t n_part, int64_t rows, int32_t h, void* stream) {
+    if (!dy || !x || !stats || !gamma || !dx || !partials) return fail(ZETT_E_INVALID, "null argument");
+    if (n_part < 1 || h < 4 || h % 4 || h > 8192 || ld % 4) return fail(ZETT_E_INVALID, "LayerNorm backward: 4 <= h <= 8192, h and ld multiples of 4, n_part >= 1");
+    if ((((uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)partials) & 15) != 0)
+        return fail(ZETT_E_INVALID, "LayerNorm backward needs 16-byte aligned rows");
+    if (rows < 0) rows = 0;                            // (no rows: the partials are still written, as zeros)
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(n_part), block(256);
+    const int j = (h + 1023) / 1024;
+    if (j <= 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, st, dy, dy2, x, ld, stats, gamma, dx, partials, (int)rows, h);
+    else if (j <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, st, dy, dy2, x, ld, stats, gamma, dx, partials, (int)rows, h);
+    else if (j <= 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, st, dy, dy2, x, ld, stats, gamma, dx, partials, (int)rows, h);
+    else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, 0, st, dy, dy2, x, ld, stats, gamma, dx, partials, (int)rows, h);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -516,7 +673,8 @@ int zett_op_layernorm_bwd_f32(const float* dy, const float* x, int32_t ld, const
 int zett_op_gelu_fwd_f32(const float* z, float* h, int64_t n, int32_t kind, void* stream) {
     if (!z || !h || (kind != 1 && kind != 2)) return fail(ZETT_E_INVALID, "bad gelu arguments");
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, h, n, kind);
+    if (n % 4 == 0 && (((uintptr_t)z | (uintptr_t)h) & 15) == 0) hipLaunchKernelGGL(gelu_fwd_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, z, h, n, kind);
+    else hipLaunchKernelGGL(gelu_fwd_kernel<1>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, h, n, kind);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -524,7 +682,9 @@ int zett_op_gelu_fwd_f32(const float* z, float* h, int64_t n, int32_t kind, void
 int zett_op_gelu_bwd_f32(const float* z, const float* dh, float* dz, int64_t n, int32_t kind, void* stream) {
     if (!z || !dh || !dz || (kind != 1 && kind != 2)) return fail(ZETT_E_INVALID, "bad gelu arguments");
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, dh, dz, n, kind);
+    if (n % 4 == 0 && (((uintptr_t)z | (uintptr_t)dh | (uintptr_t)dz) & 15) == 0)
+        hipLaunchKernelGGL(gelu_bwd_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, z, dh, dz, n, kind);
+    else hipLaunchKernelGGL(gelu_bwd_kernel<1>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, dh, dz, n, kind);
     HIP_TRY(hipGetLastError());
     return 0;
 }
