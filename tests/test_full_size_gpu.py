@@ -163,3 +163,66 @@ def test_heavy_tailed_checkpoint_stays_inside_tolerance(name, rows):
                 util.assert_bf16_close(got[idx].cpu().numpy(), ref, f"{name} heavy-tailed bf16 {what} (emulated bf16 operands: {rel_emu:.2e})",
                                        rel_max=max(lim, 1.1 * rel_emu))
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["mistral_gpt2_32k", "xlmr_gpt2"])
+def test_training_backward_against_the_inference_forward_full_size(name):
+    """N4 at BASELINE's sizes, through a size-independent property.  The differentiable forward (zett_amd/autograd.py, packed
+    schedule, exact fp32 MFMA) of the WHOLE vocabulary must reproduce the inference engine's fp32 outputs, and its backward must
+    predict what the inference engine measures: with L = <outputs, cotangents> and g = dL/d(parameters) from the backward,
+    moving every parameter by +-eps g changes L (evaluated by the inference path, an independent schedule with levers 1-4) by
+    2 eps |g|^2 up to third order (measured at the Mistral shape: ratio 0.99989)."""
+    from bench import device_weights
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+
+    cfg, rows, src_dtype, hist = synth.workload(name)
+    dev = torch.device("cuda:0")
+    model = ZettHypernet(ZettHypernetConfig(**cfg)).to(dev)
+    params = dict(model.named_parameters())
+    with torch.no_grad():
+        for pname, w in device_weights(cfg, dev, seed=0).items():
+            params[pname].copy_(w)
+    model.precision, model.train_precision, model.train_packed = "f32", "f32", True
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 0, dtype=src_dtype)).to(dev)
+    ids = torch.from_numpy(synth.make_surface_forms(cfg, rows, seed=0, hist=hist, n_special=2)).to(dev)
+    lang = torch.tensor(3) if cfg.get("hn_embed_lang_id") else None
+
+    def infer():
+        model.eval()
+        model.refresh_weights()
+        with torch.no_grad():
+            out = model(ids, source_embeddings=src, lang_index=lang)
+        torch.cuda.synchronize()
+        return out
+
+    base = infer()
+    g = torch.Generator(device=dev).manual_seed(5)
+    cot = [None if o is None else torch.randn(o.shape, device=dev, generator=g) for o in base]
+    loss_of = lambda out: sum(float((o.double() * c.double()).sum()) for o, c in zip(out, cot) if o is not None)
+
+    model.requires_grad_(True).train()
+    out = model(ids, source_embeddings=src, lang_index=lang)
+    for got, want, what in zip(out, base, ("pred_in", "pred_out", "bias")):
+        if want is None:
+            assert got is None
+            continue
+        rel = float((got.detach().double() - want.double()).norm() / want.double().norm())
+        assert rel < 2e-5, f"{name} {what}: differentiable forward vs inference engine (both fp32) rel-L2 {rel:.2e}"
+    sum((o * c).sum() for o, c in zip(out, cot) if o is not None).backward()
+    grads = {n: p.grad for n, p in params.items() if p.grad is not None}
+    assert len(grads) >= len(params) - 1                       # (only the unused word-embedding table may be without one)
+    del out
+    g2 = sum(float(v.double().pow(2).sum()) for v in grads.values())
+    theta = sum(float(params[n].detach().double().pow(2).sum()) for n in grads) ** 0.5
+    eps = 1e-5 * theta / g2 ** 0.5                             # a step of 1e-5 of the parameter norm along the gradient (1e-3: 47 % third-order
+                                                               # error at the Mistral shape, 1e-4: 1 %, 1e-5: 1e-4, 1e-6: 3e-5 - tools measured)
+    model.requires_grad_(False)
+    losses = []
+    for sign in (1.0, -2.0):                                   # theta + eps g, then theta - eps g
+        with torch.no_grad():
+            for n, v in grads.items():
+                params[n].add_(v, alpha=sign * eps)
+        losses.append(loss_of(infer()))
+    measured, predicted = losses[0] - losses[1], 2.0 * eps * g2
+    assert abs(measured - predicted) < 5e-3 * abs(predicted), f"{name}: dL measured {measured:.6e}, predicted by the backward {predicted:.6e}"

@@ -1,6 +1,2 @@
-set -u
-out=$GRAFT_REPO_ROOT/gpurun_out/r3h
-mkdir -p $out
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_autograd_gpu.py -x -q 2>&1 | tail -15
-for p in bf16 f32; do timeout 600 python tools/train_bench.py --rows 16384 --precision $p 2>&1 | tail -1; done
+timeout 900 python -m pytest tests/test_full_size_gpu.py -x -q -k training_backward 2>&1 | tail -5
