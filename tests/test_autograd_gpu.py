@@ -377,3 +377,26 @@ def test_a_training_step_lowers_the_loss():
     with torch.no_grad():
         out = model(ids, source_embeddings=src, lang_index=torch.tensor(1))
     assert not out[0].requires_grad
+
+
+def test_data_parallel_training_step_two_ranks():
+    """train.py's data-parallel step: two ranks, each with its row shard, torch DistributedDataParallel around the drop-in class
+    (its gradient hooks see the gradients zett_amd/autograd.py returns): the averaged gradients equal the single-process
+    gradients of all rows / 2.  On a 1-GPU box both ranks share cuda:0 over gloo; with two GPUs it runs over nccl (RCCL)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = torch.cuda.device_count() < 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if one:
+        env["ZETT_ONE_DEVICE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(repo, "tests", "ddp_worker.py")]
+    out = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[:3000] + " ... " + out.stderr[-1500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["world"] == 2 and d["compared"] >= 40 and d["worst_rel"] < 1e-4, d

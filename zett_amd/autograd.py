@@ -39,6 +39,9 @@ ACT_NONE, GELU_TANH, GELU_ERF = 0, 1, 2
 K_STEP = 32          # contraction widths of the fp32 MFMA GEMM are multiples of this
 
 
+NEVER_READ = frozenset({"model.embeddings.word_embeddings.weight"})     # inputs_embeds bypass the table (modeling_hypernet.py:225-229)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
@@ -716,7 +719,9 @@ def differentiable_forward(model, target_surface_forms: torch.Tensor, source_emb
     False: the reference's dense layout, every position computed — same outputs and gradients to fp32 round-off.
     precision: "f32" (exact fp32 MFMA) or "bf16" / "f16" (16-bit MFMA operands in every forward / dgrad / wgrad contraction,
     fp32 accumulation, fp32 parameters, activations and gradients)."""
-    names = [n for n in weight_shapes(model.dims)]
+    # (parameters of the checkpoint contract that the forward never reads stay outside the graph: a gradient hook that waits for
+    # every input of the Function — DistributedDataParallel's bucket logic — would wait for them for ever)
+    names = [n for n in weight_shapes(model.dims) if n not in NEVER_READ]
     params = dict(model.named_parameters())
     tensors = [params[n] for n in names]
     src = source_embeddings if source_embeddings.dtype in _SRC_DTYPES else source_embeddings.float()
