@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_autograd_gpu.py -x -q 2>&1 | tail -3
+mkdir -p gpurun_out/r3h
+timeout 1500 python tools/forward_fuzz.py --seeds 100 5000 --budget-s 1000 2>&1 | tail -3 | tee gpurun_out/r3h/forward_fuzz.json
