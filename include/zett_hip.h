@@ -276,11 +276,15 @@ int zett_op_gemm_lo(int32_t prec, const void* a, int32_t lda, const void* w, int
                     const float* residual, int32_t ld_res, float* out, int32_t ld_out, void* stream);
 int zett_op_convert_lo(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int32_t cols_padded, void* stream);
 int zett_op_transpose_lo(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream);
+/* The transposed operand of an activation that is already stored as a 16-bit operand of type prec (no conversion). */
+int zett_op_transpose_lo16(int32_t prec, const void* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream);
 /* Everything a Linear's backward needs from its output gradient dy [rows, cols], in one read: dy_lo = lo(dy) (dgrad's A operand),
  * dy_t [cols, rows_padded] = lo(dy)^T (wgrad's A operand, rows zero-padded), colsum_part [ceil(rows / 64), cols] = the column sums
- * of each 64-row band (their sum over the bands is the bias gradient). */
-int zett_op_grad_operands_lo(int32_t prec, const float* dy, int32_t ld, int64_t rows, int32_t cols, int64_t rows_padded, void* dy_lo, int32_t ld_lo,
-                             void* dy_t, int32_t ld_t, float* colsum_part, void* stream);
+ * of each 64-row band (their sum over the bands is the bias gradient).  act_z (nullable): the Linear's output went through a GELU
+ * (act_kind 1 tanh, 2 erf) and dy is the gradient of the GELU's OUTPUT: dy * gelu'(act_z) is formed on the fly and used for
+ * all three results (the activation's backward costs no pass of its own). */
+int zett_op_grad_operands_lo(int32_t prec, const float* dy, int32_t ld, const float* act_z, int32_t ld_z, int32_t act_kind, int64_t rows, int32_t cols,
+                             int64_t rows_padded, void* dy_lo, int32_t ld_lo, void* dy_t, int32_t ld_t, float* colsum_part, void* stream);
 /* out[c, r] = in[r, c] (r < rows), 0 for rows <= r < rows_padded */
 int zett_op_transpose_f32(const float* in, int32_t ld_in, float* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream);
 /* out[c] (+)= sum_r in[r, c] */
@@ -290,9 +294,10 @@ int zett_op_elementwise_f32(int32_t op, const float* a, const float* b, const fl
                             int64_t n, int32_t cols, void* stream);
 /* out[r] = a[r, :] . w + b[0] (b nullable) */
 int zett_op_rowdot_f32(const float* a, int32_t ld, const float* w, const float* b, float* out, int64_t rows, int32_t cols, void* stream);
-/* y = LayerNorm(x) (two-pass variance); stats[r] = (mean, rstd) */
+/* y = LayerNorm(x) (two-pass variance); stats[r] = (mean, rstd); y_lo (nullable, type prec): the same values as the 16-bit
+ * operand of the next contraction.  4 <= h <= 8192, h % 4 == 0. */
 int zett_op_layernorm_fwd_f32(const float* x, int32_t ld, const float* gamma, const float* beta, float eps, float* y, float* stats,
-                              int64_t rows, int32_t h, void* stream);
+                              int64_t rows, int32_t h, void* y_lo, int32_t prec, void* stream);
 /* dx for the gradient dy (+ dy2, nullable: the part arriving over the residual branch), and the parameter gradients as
  * n_part partial sums: partials [n_part, 2, h] — partials[:, 0].sum(0) = dgamma, partials[:, 1].sum(0) = dbeta (workgroup b
  * walks rows b, b + n_part, ...: deterministic for a given n_part).  4 <= h <= 8192, h % 4 == 0. */
@@ -300,6 +305,8 @@ int zett_op_layernorm_bwd_f32(const float* dy, const float* dy2, const float* x,
                               float* partials, int32_t n_part, int64_t rows, int32_t h, void* stream);
 int zett_op_gelu_fwd_f32(const float* z, float* h, int64_t n, int32_t kind, void* stream);
 int zett_op_gelu_bwd_f32(const float* z, const float* dh, float* dz, int64_t n, int32_t kind, void* stream);
+/* h_lo = lo(gelu(z)): the activation as the next contraction's 16-bit operand (its fp32 value is never stored) */
+int zett_op_gelu_fwd_lo(int32_t prec, const float* z, void* h_lo, int64_t n, int32_t kind, void* stream);
 /* softmax(q k^T / sqrt(d) + finfo.min * !mask) v per vocabulary row and head (eager semantics: a row whose keys are all
  * masked attends uniformly).  The positions of row n are rows [row_offset[n], row_offset[n+1]) of k / v (packed: only the
  * positions the row keeps) or [n*seq, (n+1)*seq) when row_offset is NULL (the reference's dense layout); at most seq <= 32

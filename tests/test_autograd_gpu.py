@@ -66,7 +66,7 @@ def test_layernorm_gelu_rowops_match_torch():
         dh = torch.randn(5000, device=DEV, generator=g)
         h = ops.gelu(z.detach(), kind)
         ref = torch.nn.functional.gelu(z.double(), approximate=approx)
-        assert float((h.double() - ref).abs().max()) < 1e-6
+        assert float((h.double() - ref.detach()).abs().max()) < 1e-6
         ref.backward(dh.double())
         assert float((ops.gelu_bwd(z.detach(), dh, kind).double() - z.grad.double()).abs().max()) < 2e-6
     a = torch.randn(50, 64, device=DEV, generator=g)
@@ -139,6 +139,22 @@ def test_grad_operands_one_read_matches_the_separate_kernels(precision):
     dx, dw, db = ops.linear_bwd(dy, x, w)
     tol = 2e-2 if precision == "bf16" else 3e-3
     assert _rel(dx, dy.double() @ w.double()) < tol and _rel(dw, dy.double().T @ x.double()) < tol and _rel(db, dy.double().sum(0)) < 1e-6
+    # the GELU's backward on the way: dy is the gradient of gelu(z), the three results are those of dy * gelu'(z)
+    for kind in (1, 2):
+        z = torch.randn(5000, 128, device=DEV, generator=g) * 2
+        eff = ops.gelu_bwd(z, dy, kind)
+        lo, t, cs = ops.grad_operands(dy, z, kind)
+        assert torch.equal(lo, ops.to_lo(eff)) and torch.equal(t, ops.transpose(eff)) and _rel(cs, eff.double().sum(0)) < 1e-6
+    # activations that are already 16-bit operands: the GELU written as an operand, LayerNorm's twin; both transposed as they are
+    z = torch.randn(777, 192, device=DEV, generator=g)
+    for kind in (1, 2):
+        h = ops.gelu(z, kind, operand=True)
+        assert h.dtype == ops.lo_dtype and torch.equal(h, ops.to_lo(ops.gelu(z, kind)))
+        assert torch.equal(ops.transpose(h), ops.transpose(ops.gelu(z, kind)))
+    y, st = ops.layernorm(z, torch.ones(192, device=DEV), torch.zeros(192, device=DEV), 1e-5)
+    assert torch.equal(y._zett_lo, ops.to_lo(y.clone())) and torch.equal(ops.transpose(y), ops.transpose(y.clone()))
+    w2 = torch.randn(64, 192, device=DEV, generator=g)
+    assert torch.equal(ops.gemm(y, w2), ops.gemm(y.clone(), w2))           # (the twin is the operand the conversion would have made)
 
 
 def test_attention_forward_backward_match_torch():

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3h
-timeout 1500 python tools/train_fuzz.py --seeds 0 5000 --budget-s 600 2>&1 | tail -2 | tee gpurun_out/r3h/train_fuzz.json
+timeout 900 python -m pytest tests/test_autograd_gpu.py -x -q 2>&1 | tail -8
+for p in bf16; do timeout 600 python tools/train_bench.py --rows 16384 --precision $p 2>&1 | tail -1; done

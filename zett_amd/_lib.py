@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "zett_op_gemm_f32", "zett_op_transpose_f32", "zett_op_colsum_f32", "zett_op_elementwise_f32", "zett_op_rowdot_f32",
     "zett_op_layernorm_fwd_f32", "zett_op_layernorm_bwd_f32", "zett_op_gelu_fwd_f32", "zett_op_gelu_bwd_f32",
     "zett_op_attention_fwd_f32", "zett_op_attention_bwd_f32", "zett_op_gather_fwd_f32", "zett_op_gather_bwd_f32",
-    "zett_op_gather_rows_f32", "zett_op_scatter_add_rows_f32", "zett_op_gemm_lo", "zett_op_convert_lo", "zett_op_transpose_lo", "zett_op_grad_operands_lo",
+    "zett_op_gather_rows_f32", "zett_op_scatter_add_rows_f32", "zett_op_gemm_lo", "zett_op_convert_lo", "zett_op_transpose_lo", "zett_op_grad_operands_lo", "zett_op_transpose_lo16", "zett_op_gelu_fwd_lo",
 )
 
 
@@ -113,11 +113,13 @@ def load():
         lib.zett_op_gemm_lo.argtypes = [I32, P, I32, P, I32, I64, I32, I32, P, I32, P, I32, P, I32, P]
         lib.zett_op_convert_lo.argtypes = [I32, P, I32, P, I32, I64, I32, I32, P]
         lib.zett_op_transpose_lo.argtypes = [I32, P, I32, P, I32, I64, I32, I64, P]
-        lib.zett_op_grad_operands_lo.argtypes = [I32, P, I32, I64, I32, I64, P, I32, P, I32, P, P]
+        lib.zett_op_grad_operands_lo.argtypes = [I32, P, I32, P, I32, I32, I64, I32, I64, P, I32, P, I32, P, P]
+        lib.zett_op_transpose_lo16.argtypes = [I32, P, I32, P, I32, I64, I32, I64, P]
+        lib.zett_op_gelu_fwd_lo.argtypes = [I32, P, P, I64, I32, P]
         lib.zett_op_colsum_f32.argtypes = [P, I32, I64, I32, P, I32, P]
         lib.zett_op_elementwise_f32.argtypes = [I32, P, P, P, P, P, P, I64, I32, P]
         lib.zett_op_rowdot_f32.argtypes = [P, I32, P, P, P, I64, I32, P]
-        lib.zett_op_layernorm_fwd_f32.argtypes = [P, I32, P, P, F, P, P, I64, I32, P]
+        lib.zett_op_layernorm_fwd_f32.argtypes = [P, I32, P, P, F, P, P, I64, I32, P, I32, P]
         lib.zett_op_layernorm_bwd_f32.argtypes = [P, P, P, I32, P, P, P, P, I32, I64, I32, P]
         lib.zett_op_gelu_fwd_f32.argtypes = [P, P, I64, I32, P]
         lib.zett_op_gelu_bwd_f32.argtypes = [P, P, P, I64, I32, P]

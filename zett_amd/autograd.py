@@ -69,6 +69,11 @@ class Ops:
     def new(self, *shape) -> torch.Tensor:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
+    def _twin(self, x):
+        """the 16-bit copy a producing kernel wrote next to an fp32 activation (LayerNorm forward), if it matches this arithmetic"""
+        t = getattr(x, "_zett_lo", None)
+        return t if t is not None and t.dtype == self.lo_dtype and t.shape[0] == x.shape[0] and t.shape[1] >= x.shape[1] and x.shape[1] % 64 == 0 else None
+
     # ---- dense contraction: y[M,N] = act(x[M,K] . w[N,K]^T + bias) + residual
     def to_lo(self, x):
         """fp32 [R, C] -> 16-bit [R, C'] (C' = C zero-padded to the 64-wide K step): an operand of zett_op_gemm_lo"""
@@ -82,7 +87,9 @@ class Ops:
     def gemm(self, x, w, bias=None, act=ACT_NONE, residual=None, out=None):
         assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
         if self.prec is not None:
-            xa = x if x.dtype == self.lo_dtype else self.to_lo(x)
+            xa = x if x.dtype == self.lo_dtype else self._twin(x)
+            if xa is None:
+                xa = self.to_lo(x)
             wa = w if w.dtype == self.lo_dtype else self.to_lo(w)
             assert xa.shape[1] == wa.shape[1]
             m, k, n = xa.shape[0], xa.shape[1], wa.shape[0]
@@ -130,14 +137,18 @@ class Ops:
 
     def transpose(self, x, pad_to=None):
         """[R, C] -> [C, R'] (R' = R zero-padded to the K step), in the operand type of the training GEMMs (fp32, or 16-bit:
-        the conversion rides on the transposition)"""
+        the conversion rides on the transposition; an activation that is already stored as a 16-bit operand is transposed as is)"""
         assert x.dim() == 2 and x.stride(1) == 1
         r, c = x.shape
         pad_to = pad_to or self.kstep
         rp = -(-r // pad_to) * pad_to
         if self.prec is not None:
             out = torch.empty((c, rp), dtype=self.lo_dtype, device=self.device)
-            _lib.check(self.lib.zett_op_transpose_lo(self.prec, _ptr(x), x.stride(0), _ptr(out), rp, r, c, rp, self._stream()), "zett_op_transpose_lo")
+            src = x if x.dtype == self.lo_dtype else self._twin(x)
+            if src is not None:
+                _lib.check(self.lib.zett_op_transpose_lo16(self.prec, _ptr(src), src.stride(0), _ptr(out), rp, r, c, rp, self._stream()), "zett_op_transpose_lo16")
+            else:
+                _lib.check(self.lib.zett_op_transpose_lo(self.prec, _ptr(x), x.stride(0), _ptr(out), rp, r, c, rp, self._stream()), "zett_op_transpose_lo")
             return out
         out = self.new(c, rp)
         _lib.check(self.lib.zett_op_transpose_f32(_ptr(x), x.stride(0), _ptr(out), rp, r, c, rp, self._stream()), "zett_op_transpose_f32")
@@ -200,11 +211,16 @@ class Ops:
         return out
 
     def layernorm(self, x, gamma, beta, eps):
+        """-> y, stats.  In 16-bit arithmetic y carries its 16-bit twin (y._zett_lo, written by the same kernel): the operand of
+        the contraction that reads y next, and of the weight gradient that transposes it in the backward."""
         assert x.dim() == 2 and x.stride(1) == 1
         r, h = x.shape
         y, stats = self.new(r, h), self.new(r, 2)
-        _lib.check(self.lib.zett_op_layernorm_fwd_f32(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), _ptr(y), _ptr(stats), r, h, self._stream()),
-                   "zett_op_layernorm_fwd_f32")
+        twin = torch.empty((r, h), dtype=self.lo_dtype, device=self.device) if self.prec is not None and h % 64 == 0 else None
+        _lib.check(self.lib.zett_op_layernorm_fwd_f32(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), _ptr(y), _ptr(stats), r, h, _ptr(twin),
+                                                      self.prec if twin is not None else 0, self._stream()), "zett_op_layernorm_fwd_f32")
+        if twin is not None:
+            y._zett_lo = twin
         return y, stats
 
     def layernorm_bwd(self, dy, x, stats, gamma, dy2=None):
@@ -219,7 +235,13 @@ class Ops:
         g = self._colsum_raw(part)
         return dx, g[:h], g[h:]
 
-    def gelu(self, z, kind):
+    def gelu(self, z, kind, operand=False):
+        """operand = True (the value only feeds a contraction): in 16-bit arithmetic the result is written as that operand and
+        its fp32 form is never stored"""
+        if operand and self.prec is not None and z.shape[-1] % 64 == 0 and z.is_contiguous():
+            h = torch.empty(z.shape, dtype=self.lo_dtype, device=self.device)
+            _lib.check(self.lib.zett_op_gelu_fwd_lo(self.prec, _ptr(z), _ptr(h), z.numel(), kind, self._stream()), "zett_op_gelu_fwd_lo")
+            return h
         h = self.new(*z.shape)
         _lib.check(self.lib.zett_op_gelu_fwd_f32(_ptr(z), _ptr(h), z.numel(), kind, self._stream()), "zett_op_gelu_fwd_f32")
         return h
@@ -280,26 +302,31 @@ class Ops:
         return dfb, self.colsum(prod), self.colsum(keep)
 
     # ---- Linear backward on the same GEMM: dgrad against W^T, wgrad of the transposed activations
-    def grad_operands(self, dy):
-        """16-bit arithmetic: one read of dy [M, N] -> (lo(dy) [M, N], lo(dy)^T [N, M'], column sums of dy [N])"""
+    def grad_operands(self, dy, act_z=None, act_kind=0):
+        """16-bit arithmetic: one read of dy [M, N] -> (lo(dy) [M, N], lo(dy)^T [N, M'], column sums of dy [N]); with act_z
+        (the pre-activation of the GELU whose output gradient dy is) the three are those of dy * gelu'(act_z)"""
         m, n = dy.shape
         mp = -(-m // self.kstep) * self.kstep
         bands = -(-m // 64)
         dy_lo = torch.empty((m, n), dtype=self.lo_dtype, device=self.device)
         dy_t = torch.empty((n, mp), dtype=self.lo_dtype, device=self.device)
         part = self.new(bands, n)
-        _lib.check(self.lib.zett_op_grad_operands_lo(self.prec, _ptr(dy), dy.stride(0), m, n, mp, _ptr(dy_lo), n, _ptr(dy_t), mp, _ptr(part), self._stream()),
-                   "zett_op_grad_operands_lo")
+        assert act_z is None or (act_z.shape == dy.shape and act_z.stride(1) == 1)
+        _lib.check(self.lib.zett_op_grad_operands_lo(self.prec, _ptr(dy), dy.stride(0), _ptr(act_z), 0 if act_z is None else act_z.stride(0), act_kind, m, n, mp,
+                                                     _ptr(dy_lo), n, _ptr(dy_t), mp, _ptr(part), self._stream()), "zett_op_grad_operands_lo")
         return dy_lo, dy_t, self.colsum(part)
 
-    def linear_bwd(self, dy, x, w):
-        """y = x w^T + b  ->  dx [M, K], dw [N, K], db [N]"""
+    def linear_bwd(self, dy, x, w, act_z=None, act_kind=0):
+        """y = x w^T + b  ->  dx [M, K], dw [N, K], db [N].  act_z / act_kind: y went through a GELU and dy is the gradient of the
+        GELU's output (the activation's backward is applied on the way: fused into the operand pass in 16-bit arithmetic)"""
         assert dy.is_contiguous() and dy.shape == (x.shape[0], w.shape[0])
         if w.shape[0] % self.kstep:
             raise NotImplementedError(f"the training GEMM contracts over multiples of {self.kstep}: a Linear with {w.shape[0]} outputs is not supported yet")
         if self.prec is not None and dy.shape[0] > 0:
-            dy_lo, dy_t, db = self.grad_operands(dy)
+            dy_lo, dy_t, db = self.grad_operands(dy, act_z, act_kind)
             return self.gemm(dy_lo, self.transpose(w)), self.wgrad(dy_t, self.transpose(x)), db
+        if act_z is not None:
+            dy = self.gelu_bwd(act_z, dy, act_kind)
         dx = self.gemm(dy, self.transpose(w))                           # A = dy [M, N], W-operand = w^T [K, N]
         dw = self.wgrad(self.transpose(dy), self.transpose(x))          # A = dy^T [N, M'], W-operand = x^T [K, M'] (M' = rows zero-padded to 32)
         return dx, dw, self.colsum(dy)
@@ -308,7 +335,7 @@ class Ops:
 def _projector_fwd(ops: Ops, P, prefix, x):
     """ProjectorBlock (modeling_hypernet.py:22-40): LN_1e-6(gelu_t(W2 gelu_t(W1 x + b1) + b2) + x)"""
     z1 = ops.gemm(x, P[prefix + "dense1.weight"], P[prefix + "dense1.bias"])
-    h1 = ops.gelu(z1, GELU_TANH)
+    h1 = ops.gelu(z1, GELU_TANH, operand=True)
     z2 = ops.gemm(h1, P[prefix + "dense2.weight"], P[prefix + "dense2.bias"])
     h2 = ops.gelu(z2, GELU_TANH)
     s = ops.add(h2, x)
@@ -318,10 +345,8 @@ def _projector_fwd(ops: Ops, P, prefix, x):
 
 def _projector_bwd(ops: Ops, P, G, prefix, saved, dy):
     ds, G[prefix + "ln.weight"], G[prefix + "ln.bias"] = ops.layernorm_bwd(dy, saved["s"], saved["st"], P[prefix + "ln.weight"])
-    dz2 = ops.gelu_bwd(saved["z2"], ds, GELU_TANH)
-    dh1, G[prefix + "dense2.weight"], G[prefix + "dense2.bias"] = ops.linear_bwd(dz2, saved["h1"], P[prefix + "dense2.weight"])
-    dz1 = ops.gelu_bwd(saved["z1"], dh1, GELU_TANH)
-    dx, G[prefix + "dense1.weight"], G[prefix + "dense1.bias"] = ops.linear_bwd(dz1, saved["x"], P[prefix + "dense1.weight"])
+    dh1, G[prefix + "dense2.weight"], G[prefix + "dense2.bias"] = ops.linear_bwd(ds, saved["h1"], P[prefix + "dense2.weight"], saved["z2"], GELU_TANH)
+    dx, G[prefix + "dense1.weight"], G[prefix + "dense1.bias"] = ops.linear_bwd(dh1, saved["x"], P[prefix + "dense1.weight"], saved["z1"], GELU_TANH)
     return ops.add(dx, ds)          # the residual branch
 
 
@@ -445,7 +470,7 @@ def forward_train(ops: Ops, dims: HypernetDims, ln_eps: float, P: Dict[str, torc
         s1 = ops.gemm(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"], residual=z)
         z1, st1 = ops.layernorm(s1, P[p + "attention.output.LayerNorm.weight"], P[p + "attention.output.LayerNorm.bias"], ln_eps)
         u = ops.gemm(z1, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"])
-        g = ops.gelu(u, GELU_ERF)
+        g = ops.gelu(u, GELU_ERF, operand=True)
         s2 = ops.gemm(g, P[p + "output.dense.weight"], P[p + "output.dense.bias"], residual=z1)
         z2, st2 = ops.layernorm(s2, P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], ln_eps)
         layers.append(dict(z=z, wqkv=wqkv, qkv=qkv, probs=probs, ctx=ctx, s1=s1, st1=st1, z1=z1, u=u, g=g, s2=s2, st2=st2))
@@ -476,8 +501,7 @@ def backward_train(ops: Ops, dims: HypernetDims, P: Dict[str, torch.Tensor], S, 
         A = S["layers"][l]
         ds2, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = ops.layernorm_bwd(dz, A["s2"], A["st2"], P[p + "output.LayerNorm.weight"], dy2=dz_res)
         dg, G[p + "output.dense.weight"], G[p + "output.dense.bias"] = ops.linear_bwd(ds2, A["g"], P[p + "output.dense.weight"])
-        du = ops.gelu_bwd(A["u"], dg, GELU_ERF)
-        dz1, G[p + "intermediate.dense.weight"], G[p + "intermediate.dense.bias"] = ops.linear_bwd(du, A["z1"], P[p + "intermediate.dense.weight"])
+        dz1, G[p + "intermediate.dense.weight"], G[p + "intermediate.dense.bias"] = ops.linear_bwd(dg, A["z1"], P[p + "intermediate.dense.weight"], A["u"], GELU_ERF)
         ds1, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
             ops.layernorm_bwd(dz1, A["s1"], A["st1"], P[p + "attention.output.LayerNorm.weight"], dy2=ds2)        # + the residual of the FFN
         dctx, G[p + "attention.output.dense.weight"], G[p + "attention.output.dense.bias"] = ops.linear_bwd(ds1, A["ctx"], P[p + "attention.output.dense.weight"])
@@ -600,7 +624,7 @@ def forward_packed(ops: Ops, dims: HypernetDims, ln_eps: float, P, ids: torch.Te
         s1 = ops.gemm(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"], residual=res)
         z1, st1 = ops.layernorm(s1, P[p + "attention.output.LayerNorm.weight"], P[p + "attention.output.LayerNorm.bias"], ln_eps)
         u = ops.gemm(z1, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"])
-        g = ops.gelu(u, GELU_ERF)
+        g = ops.gelu(u, GELU_ERF, operand=True)
         s2 = ops.gemm(g, P[p + "output.dense.weight"], P[p + "output.dense.bias"], residual=z1)
         z, st2 = ops.layernorm(s2, P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], ln_eps)
         A.update(probs=probs, ctx=ctx, s1=s1, st1=st1, z1=z1, u=u, g=g, s2=s2, st2=st2)
@@ -631,8 +655,7 @@ def backward_packed(ops: Ops, dims: HypernetDims, P, S, src, lang, d_in, d_out, 
         last = l == dims.layers - 1
         ds2, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = ops.layernorm_bwd(dz, A["s2"], A["st2"], P[p + "output.LayerNorm.weight"], dy2=dz_res)
         dg, G[p + "output.dense.weight"], G[p + "output.dense.bias"] = ops.linear_bwd(ds2, A["g"], P[p + "output.dense.weight"])
-        du = ops.gelu_bwd(A["u"], dg, GELU_ERF)
-        dz1, G[p + "intermediate.dense.weight"], G[p + "intermediate.dense.bias"] = ops.linear_bwd(du, A["z1"], P[p + "intermediate.dense.weight"])
+        dz1, G[p + "intermediate.dense.weight"], G[p + "intermediate.dense.bias"] = ops.linear_bwd(dg, A["z1"], P[p + "intermediate.dense.weight"], A["u"], GELU_ERF)
         ds1, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
             ops.layernorm_bwd(dz1, A["s1"], A["st1"], P[p + "attention.output.LayerNorm.weight"], dy2=ds2)        # + the residual of the FFN
         dctx, G[p + "attention.output.dense.weight"], G[p + "attention.output.dense.bias"] = ops.linear_bwd(ds1, A["ctx"], P[p + "attention.output.dense.weight"])

@@ -83,27 +83,71 @@ __global__ __launch_bounds__(256) void convert_lo4_kernel(const float* __restric
         }
     }
 }
-// 64 x 64 tiles through LDS: 16-byte loads along the input rows, 8-byte stores (four converted values) along the output rows.
+__device__ __forceinline__ float gelu_fwd1(float x, int kind) { return kind == 1 ? gelu_tanh_f(x) : gelu_erf_f(x); }
+__device__ __forceinline__ float gelu_grad1(float x, int kind) {
+    if (kind == 1) {       // d/dx [0.5 x (1 + tanh u)], u = sqrt(2/pi) (x + 0.044715 x^3)
+        const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+        const float t = tanhf(u);
+        return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+    }
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);       // Phi(x) + x phi(x)
+}
+
+// four consecutive values of a row as floats: fp32 (16-byte load) or 16-bit (8-byte load) storage; element-wise tail at the edges
+template <typename TIn>
+__device__ __forceinline__ float4 load4(const TIn* __restrict__ row, int c, int C, bool vec_ok);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float* __restrict__ row, int c, int C, bool vec_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 3 < C && vec_ok) return *(const float4*)(row + c);
+    if (c < C) v.x = row[c];
+    if (c + 1 < C) v.y = row[c + 1];
+    if (c + 2 < C) v.z = row[c + 2];
+    if (c + 3 < C) v.w = row[c + 3];
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ float4 load4_lo(const T* __restrict__ row, int c, int C, bool vec_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 3 < C && vec_ok) {
+        const uint2 u = *(const uint2*)(row + c);
+        unpack2_lo<T>(u.x, v.x, v.y);
+        unpack2_lo<T>(u.y, v.z, v.w);
+        return v;
+    }
+    if (c < C) v.x = lo_to_f32<T>(row[c]);
+    if (c + 1 < C) v.y = lo_to_f32<T>(row[c + 1]);
+    if (c + 2 < C) v.z = lo_to_f32<T>(row[c + 2]);
+    if (c + 3 < C) v.w = lo_to_f32<T>(row[c + 3]);
+    return v;
+}
+template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* __restrict__ row, int c, int C, bool vec_ok) { return load4_lo<bf16_t>(row, c, C, vec_ok); }
+template <> __device__ __forceinline__ float4 load4<f16_t>(const f16_t* __restrict__ row, int c, int C, bool vec_ok) { return load4_lo<f16_t>(row, c, C, vec_ok); }
+
+// 64 x 64 tiles through LDS: wide loads along the input rows (fp32 or, TIn = T, an operand that is already 16-bit), 8-byte stores
+// (four converted values) along the output rows.
 // One read of a gradient serves everything a Linear's backward needs from it: `plain` (nullable) gets the un-transposed 16-bit
 // copy (dgrad's A operand), `colpart` (nullable, [ceil(R / 64), C]) the column sums of each 64-row band (their sum is the bias
-// gradient: a deterministic two-level reduction, no atomics).
-template <typename T>
-__global__ __launch_bounds__(256) void transpose_lo_kernel(const float* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int R, int C, int Rpad,
-                                                           T* __restrict__ plain, int ld_plain, float* __restrict__ colpart) {
+// gradient: a deterministic two-level reduction, no atomics).  With `act_z` (nullable: the pre-activation of a GELU whose OUTPUT
+// gradient `in` is) the value used everywhere is in * gelu'(act_z): the activation's backward costs no pass of its own and its
+// fp32 result is never written.
+template <typename T, typename TIn>
+__global__ __launch_bounds__(256) void transpose_lo_kernel(const TIn* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int R, int C, int Rpad,
+                                                           T* __restrict__ plain, int ld_plain, float* __restrict__ colpart,
+                                                           const float* __restrict__ act_z, int ld_z, int act_kind) {
     __shared__ float tile[64][65];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int t = threadIdx.x;
-    for (int k = t; k < 64 * 16; k += 256) {           // 64 rows x 16 float4
+    const bool in_vec = (ld_in & 3) == 0, z_vec = (ld_z & 3) == 0;
+    for (int k = t; k < 64 * 16; k += 256) {           // 64 rows x 16 groups of four columns
         const int rr = k >> 4, cc = (k & 15) << 2;
         const int r = r0 + rr, c = c0 + cc;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < R) {
-            if (c + 3 < C && ((ld_in & 3) == 0)) v = *(const float4*)(in + (size_t)r * ld_in + c);
-            else {
-                if (c < C) v.x = in[(size_t)r * ld_in + c];
-                if (c + 1 < C) v.y = in[(size_t)r * ld_in + c + 1];
-                if (c + 2 < C) v.z = in[(size_t)r * ld_in + c + 2];
-                if (c + 3 < C) v.w = in[(size_t)r * ld_in + c + 3];
+            v = load4<TIn>(in + (size_t)r * ld_in, c, C, in_vec);
+            if (act_z) {
+                const float4 z = load4<float>(act_z + (size_t)r * ld_z, c, C, z_vec);
+                v.x *= gelu_grad1(z.x, act_kind); v.y *= gelu_grad1(z.y, act_kind); v.z *= gelu_grad1(z.z, act_kind); v.w *= gelu_grad1(z.w, act_kind);
             }
             if (plain) {
                 if (c + 3 < C && ((ld_plain & 3) == 0)) *(uint2*)(plain + (size_t)r * ld_plain + c) = make_uint2(pack2_lo<T>(v.x, v.y), pack2_lo<T>(v.z, v.w));
@@ -200,10 +244,11 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a
 
 // ---- LayerNorm ------------------------------------------------------------------------------------------------------
 // y = (x - mean) * rstd * gamma + beta; stats[r] = (mean, rstd)   (two-pass variance, as torch.nn.LayerNorm).  A row is read
-// once, into registers: a thread owns columns 4 (tid + 256 j) ... + 3, j < J (H <= 1024 J, H % 4 == 0).
-template <int J>
+// once, into registers: a thread owns columns 4 (tid + 256 j) ... + 3, j < J (H <= 1024 J, H % 4 == 0).  y_lo (nullable): the
+// same values as a 16-bit operand of the next contraction, written while they are in registers.
+template <int J, typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float eps, float* __restrict__ y, float* __restrict__ stats, int R, int H) {
+                                                     float eps, float* __restrict__ y, float* __restrict__ stats, int R, int H, T* __restrict__ y_lo) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     for (int r = blockIdx.x; r < R; r += gridDim.x) {
@@ -231,8 +276,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             const int c = 4 * (tid + 256 * j);
             if (c < H) {
                 const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
-                *(float4*)(y + (size_t)r * H + c) = make_float4(ln_affine(v[j].x, mean, rstd, g.x, b.x), ln_affine(v[j].y, mean, rstd, g.y, b.y),
-                                                                ln_affine(v[j].z, mean, rstd, g.z, b.z), ln_affine(v[j].w, mean, rstd, g.w, b.w));
+                const float4 o = make_float4(ln_affine(v[j].x, mean, rstd, g.x, b.x), ln_affine(v[j].y, mean, rstd, g.y, b.y),
+                                             ln_affine(v[j].z, mean, rstd, g.z, b.z), ln_affine(v[j].w, mean, rstd, g.w, b.w));
+                *(float4*)(y + (size_t)r * H + c) = o;
+                if (y_lo) *(uint2*)(y_lo + (size_t)r * H + c) = make_uint2(pack2_lo<T>(o.x, o.y), pack2_lo<T>(o.z, o.w));      // the next contraction's operand
             }
         }
     }
@@ -314,15 +361,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 // ---- GELU -----------------------------------------------------------------------------------------------------------
 // kind 1: F.gelu(approximate="tanh") (ProjectorBlock), 2: erf form (RobertaIntermediate) — the forward functions of gemm.hip.h
-__device__ __forceinline__ float gelu_fwd1(float x, int kind) { return kind == 1 ? gelu_tanh_f(x) : gelu_erf_f(x); }
-__device__ __forceinline__ float gelu_grad1(float x, int kind) {
-    if (kind == 1) {       // d/dx [0.5 x (1 + tanh u)], u = sqrt(2/pi) (x + 0.044715 x^3)
-        const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-        const float t = tanhf(u);
-        return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
-    }
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);       // Phi(x) + x phi(x)
-}
 // V = 4: 16-byte accesses (n % 4 == 0, aligned), V = 1 otherwise
 template <int V>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ z, float* __restrict__ h, int64_t n, int kind) {
@@ -347,6 +385,21 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
             *(float4*)(dz + i) = make_float4(g.x * gelu_grad1(v.x, kind), g.y * gelu_grad1(v.y, kind), g.z * gelu_grad1(v.z, kind), g.w * gelu_grad1(v.w, kind));
         } else {
             dz[i] = dh[i] * gelu_grad1(z[i], kind);
+        }
+    }
+}
+
+// the 16-bit form of the forward: the activation as the next contraction's operand (its fp32 value is never stored)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_lo_kernel(const float* __restrict__ z, T* __restrict__ h, int64_t n, int kind) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = *(const float4*)(z + i);
+            *(uint2*)(h + i) = make_uint2(pack2_lo<T>(gelu_fwd1(v.x, kind), gelu_fwd1(v.y, kind)), pack2_lo<T>(gelu_fwd1(v.z, kind), gelu_fwd1(v.w, kind)));
+        } else {
+            for (int64_t j = i; j < n; ++j) h[j] = to_lo<T>(gelu_fwd1(z[j], kind));
         }
     }
 }
@@ -520,6 +573,21 @@ static int gemm_lo(const T* a, int lda, const T* w, int ldw, int64_t m, int n, i
     return 0;
 }
 
+template <typename T, typename TIn>
+static void transpose_lo_go(const void* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* plain, int32_t ld_plain,
+                            float* colpart, const float* act_z, int32_t ld_z, int32_t act_kind, hipStream_t st) {
+    const dim3 grid((cols + 63) / 64, (unsigned)((rows_padded + 63) / 64));
+    hipLaunchKernelGGL((transpose_lo_kernel<T, TIn>), grid, dim3(256), 0, st, (const TIn*)in, ld_in, (T*)out, ld_out, (int)rows, cols, (int)rows_padded, (T*)plain, ld_plain,
+                       colpart, act_z, ld_z, act_kind);
+}
+
+template <int J>
+static void ln_fwd_go(int32_t prec, dim3 grid, hipStream_t st, const float* x, int32_t ld, const float* gamma, const float* beta, float eps, float* y, float* stats,
+                      int rows, int32_t h, void* y_lo) {
+    if (prec == ZETT_PREC_F16) hipLaunchKernelGGL((ln_fwd_kernel<J, f16_t>), grid, dim3(256), 0, st, x, ld, gamma, beta, eps, y, stats, rows, h, (f16_t*)y_lo);
+    else hipLaunchKernelGGL((ln_fwd_kernel<J, bf16_t>), grid, dim3(256), 0, st, x, ld, gamma, beta, eps, y, stats, rows, h, (bf16_t*)y_lo);
+}
+
 extern "C" {
 
 int zett_op_gemm_f32(const float* a, int32_t lda, const float* w, int32_t ldw, int64_t m, int32_t n, int32_t k, const float* bias, int32_t act,
@@ -570,33 +638,41 @@ int zett_op_convert_lo(int32_t prec, const float* in, int32_t ld_in, void* out, 
     return 0;
 }
 
-static int transpose_lo_launch(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded,
-                               void* plain, int32_t ld_plain, float* colpart, void* stream) {
+// in_lo: the input is already a 16-bit operand of type `prec` (plain transposition), otherwise fp32
+static int transpose_lo_launch(int32_t prec, bool in_lo, const void* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded,
+                               void* plain, int32_t ld_plain, float* colpart, const float* act_z, int32_t ld_z, int32_t act_kind, void* stream) {
     if (!in || !out || rows_padded < rows || ld_out < rows_padded) return fail(ZETT_E_INVALID, "bad transpose arguments");
     if (prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "the 16-bit transposes take ZETT_PREC_BF16 or ZETT_PREC_F16");
     if (rows <= 0 || cols <= 0) return 0;
     if (plain && ld_plain < cols) return fail(ZETT_E_INVALID, "bad leading dimension of the plain copy");
-    const dim3 grid((cols + 63) / 64, (unsigned)((rows_padded + 63) / 64));
-    if (((uintptr_t)in & 15) != 0 || ((uintptr_t)out & 7) != 0 || ((uintptr_t)plain & 7) != 0)
-        return fail(ZETT_E_INVALID, "the 16-bit transposes need a 16-byte aligned input and 8-byte aligned outputs");
-    if (prec == ZETT_PREC_F16)
-        hipLaunchKernelGGL(transpose_lo_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (f16_t*)out, ld_out, (int)rows, cols, (int)rows_padded,
-                           (f16_t*)plain, ld_plain, colpart);
-    else
-        hipLaunchKernelGGL(transpose_lo_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (bf16_t*)out, ld_out, (int)rows, cols, (int)rows_padded,
-                           (bf16_t*)plain, ld_plain, colpart);
+    if (act_z && (act_kind != 1 && act_kind != 2)) return fail(ZETT_E_INVALID, "activation kind must be 1 (tanh-GELU) or 2 (erf-GELU)");
+    if (act_z && ld_z < cols) return fail(ZETT_E_INVALID, "bad leading dimension of the pre-activation");
+    if (((uintptr_t)in & (in_lo ? 7 : 15)) != 0 || ((uintptr_t)out & 7) != 0 || ((uintptr_t)plain & 7) != 0 || ((uintptr_t)act_z & 15) != 0)
+        return fail(ZETT_E_INVALID, "the 16-bit transposes need 16-byte aligned fp32 inputs and 8-byte aligned 16-bit buffers");
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == ZETT_PREC_F16) {
+        if (in_lo) transpose_lo_go<f16_t, f16_t>(in, ld_in, out, ld_out, rows, cols, rows_padded, plain, ld_plain, colpart, act_z, ld_z, act_kind, st);
+        else transpose_lo_go<f16_t, float>(in, ld_in, out, ld_out, rows, cols, rows_padded, plain, ld_plain, colpart, act_z, ld_z, act_kind, st);
+    } else {
+        if (in_lo) transpose_lo_go<bf16_t, bf16_t>(in, ld_in, out, ld_out, rows, cols, rows_padded, plain, ld_plain, colpart, act_z, ld_z, act_kind, st);
+        else transpose_lo_go<bf16_t, float>(in, ld_in, out, ld_out, rows, cols, rows_padded, plain, ld_plain, colpart, act_z, ld_z, act_kind, st);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int zett_op_transpose_lo(int32_t prec, const float* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream) {
-    return transpose_lo_launch(prec, in, ld_in, out, ld_out, rows, cols, rows_padded, nullptr, 0, nullptr, stream);
+    return transpose_lo_launch(prec, false, in, ld_in, out, ld_out, rows, cols, rows_padded, nullptr, 0, nullptr, nullptr, 0, 0, stream);
 }
 
-int zett_op_grad_operands_lo(int32_t prec, const float* dy, int32_t ld, int64_t rows, int32_t cols, int64_t rows_padded, void* dy_lo, int32_t ld_lo,
-                             void* dy_t, int32_t ld_t, float* colsum_part, void* stream) {
+int zett_op_transpose_lo16(int32_t prec, const void* in, int32_t ld_in, void* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream) {
+    return transpose_lo_launch(prec, true, in, ld_in, out, ld_out, rows, cols, rows_padded, nullptr, 0, nullptr, nullptr, 0, 0, stream);
+}
+
+int zett_op_grad_operands_lo(int32_t prec, const float* dy, int32_t ld, const float* act_z, int32_t ld_z, int32_t act_kind, int64_t rows, int32_t cols,
+                             int64_t rows_padded, void* dy_lo, int32_t ld_lo, void* dy_t, int32_t ld_t, float* colsum_part, void* stream) {
     if (!dy_lo || !colsum_part) return fail(ZETT_E_INVALID, "null argument");
-    return transpose_lo_launch(prec, dy, ld, dy_t, ld_t, rows, cols, rows_padded, dy_lo, ld_lo, colsum_part, stream);
+    return transpose_lo_launch(prec, false, dy, ld, dy_t, ld_t, rows, cols, rows_padded, dy_lo, ld_lo, colsum_part, act_z, ld_z, act_kind, stream);
 }
 
 int zett_op_transpose_f32(const float* in, int32_t ld_in, float* out, int32_t ld_out, int64_t rows, int32_t cols, int64_t rows_padded, void* stream) {
@@ -636,18 +712,20 @@ int zett_op_rowdot_f32(const float* a, int32_t ld, const float* w, const float* 
 }
 
 int zett_op_layernorm_fwd_f32(const float* x, int32_t ld, const float* gamma, const float* beta, float eps, float* y, float* stats,
-                              int64_t rows, int32_t h, void* stream) {
+                              int64_t rows, int32_t h, void* y_lo, int32_t prec, void* stream) {
     if (!x || !gamma || !beta || !y || !stats) return fail(ZETT_E_INVALID, "null argument");
     if (h < 4 || h % 4 || h > 8192 || ld % 4) return fail(ZETT_E_INVALID, "LayerNorm: 4 <= h <= 8192, h and ld multiples of 4");
-    if ((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15) != 0) return fail(ZETT_E_INVALID, "LayerNorm needs 16-byte aligned rows");
+    if ((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15) != 0 || ((uintptr_t)y_lo & 7) != 0)
+        return fail(ZETT_E_INVALID, "LayerNorm needs 16-byte aligned rows");
+    if (y_lo && prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "the 16-bit copy takes ZETT_PREC_BF16 or ZETT_PREC_F16");
     if (rows <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)std::min<int64_t>(rows, 16384)), block(256);
+    const dim3 grid((unsigned)std::min<int64_t>(rows, 16384));
     const int j = (h + 1023) / 1024;
-    if (j <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h);
-    else if (j <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h);
-    else if (j <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h);
-    else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h);
+    if (j <= 1) ln_fwd_go<1>(prec, grid, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h, y_lo);
+    else if (j <= 2) ln_fwd_go<2>(prec, grid, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h, y_lo);
+    else if (j <= 4) ln_fwd_go<4>(prec, grid, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h, y_lo);
+    else ln_fwd_go<8>(prec, grid, st, x, ld, gamma, beta, eps, y, stats, (int)rows, h, y_lo);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -675,6 +753,18 @@ int zett_op_gelu_fwd_f32(const float* z, float* h, int64_t n, int32_t kind, void
     if (n <= 0) return 0;
     if (n % 4 == 0 && (((uintptr_t)z | (uintptr_t)h) & 15) == 0) hipLaunchKernelGGL(gelu_fwd_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, z, h, n, kind);
     else hipLaunchKernelGGL(gelu_fwd_kernel<1>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, h, n, kind);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_op_gelu_fwd_lo(int32_t prec, const float* z, void* h_lo, int64_t n, int32_t kind, void* stream) {
+    if (!z || !h_lo || (kind != 1 && kind != 2)) return fail(ZETT_E_INVALID, "bad gelu arguments");
+    if (prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "zett_op_gelu_fwd_lo takes ZETT_PREC_BF16 or ZETT_PREC_F16");
+    if ((((uintptr_t)z) & 15) != 0 || (((uintptr_t)h_lo) & 7) != 0) return fail(ZETT_E_INVALID, "zett_op_gelu_fwd_lo needs a 16-byte aligned input and an 8-byte aligned output");
+    if (n <= 0) return 0;
+    const int grid = grid_for((n + 3) / 4);
+    if (prec == ZETT_PREC_F16) hipLaunchKernelGGL(gelu_fwd_lo_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, (f16_t*)h_lo, n, kind);
+    else hipLaunchKernelGGL(gelu_fwd_lo_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, (bf16_t*)h_lo, n, kind);
     HIP_TRY(hipGetLastError());
     return 0;
 }
