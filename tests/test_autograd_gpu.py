@@ -228,6 +228,31 @@ def test_attention_forward_backward_match_torch():
     assert _rel(dst, torch.zeros(40, 96, device=DEV, dtype=torch.float64).index_add_(0, idx.long(), a.double())) < 1e-6
 
 
+@pytest.mark.parametrize("L,heads,d", [(1, 2, 64), (2, 3, 16), (3, 4, 128), (5, 1, 32), (8, 5, 128), (9, 2, 64), (16, 4, 128), (17, 2, 64), (32, 1, 128), (7, 2, 256), (16, 1, 192)])
+def test_attention_register_layouts(L, heads, d):
+    """every register layout of the attention kernels (positions rounded up to 2 / 4 / 8 / 16 / 32, one / two / four 64-column
+    slices of the head dim, head counts that do not fill the four waves of a workgroup): dense rows with random masks"""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(100 + L)
+    n, H = 13, heads * d
+    qkv = torch.randn(n * L, 3 * H, device=DEV, generator=g).requires_grad_(True)
+    mask = torch.rand(n, L, device=DEV, generator=g) < 0.7
+    mask[:, 0] = True
+    if L > 1:
+        mask[5] = False
+    dctx = torch.randn(n * L, H, device=DEV, generator=g)
+    qd = qkv.detach()
+    ctx, probs = ops.attention(qd[:, :H], qd[:, H:2 * H], qd[:, 2 * H:], mask.to(torch.uint8).view(-1), None, n, L, heads, H)
+    q, k, v = [t.view(n, L, heads, d).transpose(1, 2) for t in qkv.double().split(H, dim=1)]
+    bias = torch.where(mask, 0.0, torch.finfo(torch.float32).min).double()[:, None, None, :]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5 + bias, -1) @ v).transpose(1, 2).reshape(n * L, H)
+    assert _rel(ctx, ref) < 2e-6
+    ref.backward(dctx.double())
+    dqkv = torch.empty_like(qd)
+    ops.attention_bwd(dctx, qd[:, :H], qd[:, H:2 * H], qd[:, 2 * H:], probs, None, n, L, heads, H, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:])
+    assert _rel(dqkv, qkv.grad) < 5e-6
+
+
 def test_gather_forward_backward_match_torch():
     ops = _ops()
     g = torch.Generator(device=DEV).manual_seed(3)

@@ -412,89 +412,152 @@ __global__ __launch_bounds__(256) void gelu_fwd_lo_kernel(const float* __restric
 // probs [n_rows, heads, seq, seq] (row-major in the padded seq) is kept for the backward.  t1 - t0 <= seq <= ATT_MAX_L.
 constexpr int ATT_MAX_L = 32;
 
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ld,
-                                                      const uint8_t* __restrict__ mask, const int32_t* __restrict__ row_offset, int seq, int heads, int d,
-                                                      float scaling, int cls_only, float* __restrict__ ctx, int ld_ctx, float* __restrict__ probs) {
-    __shared__ float s[ATT_MAX_L][ATT_MAX_L];
-    const int n = blockIdx.x / heads, hd = blockIdx.x % heads, lane = threadIdx.x;
+// One WAVE per (vocabulary row, head), four heads per workgroup; no LDS, no barrier.  A lane owns head-dim columns lane + 64 e
+// (e < DV: head dims up to 64 DV); the row's keys and values live in registers (LMAX positions, loops over positions fully
+// unrolled with wave-uniform guards, so the arrays are never indexed dynamically), every load of the row is in flight before
+// the first reduction, and each query position is one pass: LMAX dot products (butterfly sums leave every lane with the
+// result), the softmax computed redundantly by all lanes, the weighted sum of the values.
+template <int LMAX, int DV>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ld,
+                                                       const uint8_t* __restrict__ mask, const int32_t* __restrict__ row_offset, int seq, int heads, int d,
+                                                       float scaling, int cls_only, float* __restrict__ ctx, int ld_ctx, float* __restrict__ probs) {
+    const int groups = (heads + 3) >> 2;
+    const int n = blockIdx.x / groups, hd = (blockIdx.x % groups) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (hd >= heads) return;
     const size_t base = row_offset ? (size_t)row_offset[n] : (size_t)n * seq;
     const int L = row_offset ? row_offset[n + 1] - row_offset[n] : seq;
     const int nq = cls_only ? 1 : L;
     const size_t qbase = cls_only ? (size_t)n : base;
-    for (int i = 0; i < nq; ++i)
-        for (int j = 0; j < L; ++j) {
-            float p = 0.f;
-            for (int c = lane; c < d; c += 64) p += q[(qbase + i) * ldq + hd * d + c] * k[(base + j) * ld + hd * d + c];
-            p = t_wave_sum(p);
-            if (lane == 0) s[i][j] = p * scaling + (mask[base + j] ? 0.f : -FLT_MAX);       // finfo(float32).min on masked keys
-        }
-    __syncthreads();
-    if (lane < nq) {
-        const int i = lane;
-        float mx = -INFINITY;
-        for (int j = 0; j < L; ++j) mx = fmaxf(mx, s[i][j]);
-        float sum = 0.f;
-        for (int j = 0; j < L; ++j) { const float e = expf(s[i][j] - mx); s[i][j] = e; sum += e; }
-        for (int j = 0; j < L; ++j) {
-            const float p = s[i][j] / sum;
-            s[i][j] = p;
-            probs[(((size_t)n * heads + hd) * seq + i) * seq + j] = p;
+    float kr[LMAX][DV], vr[LMAX][DV], bias[LMAX];
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        bias[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < DV; ++e) { kr[j][e] = 0.f; vr[j][e] = 0.f; }
+        if (j < L) {
+            bias[j] = mask[base + j] ? 0.f : -FLT_MAX;             // finfo(float32).min on masked keys
+#pragma unroll
+            for (int e = 0; e < DV; ++e) {
+                const int c = lane + 64 * e;
+                if (c < d) { kr[j][e] = k[(base + j) * ld + hd * d + c]; vr[j][e] = v[(base + j) * ld + hd * d + c]; }
+            }
         }
     }
-    __syncthreads();
-    for (int i = 0; i < nq; ++i)
-        for (int c = lane; c < d; c += 64) {
-            float a = 0.f;
-            for (int j = 0; j < L; ++j) a += s[i][j] * v[(base + j) * ld + hd * d + c];
-            ctx[(qbase + i) * ld_ctx + hd * d + c] = a;
+    for (int i = 0; i < nq; ++i) {
+        float qr[DV];
+#pragma unroll
+        for (int e = 0; e < DV; ++e) { const int c = lane + 64 * e; qr[e] = c < d ? q[(qbase + i) * ldq + hd * d + c] : 0.f; }
+        float sc[LMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j) {
+            sc[j] = 0.f;
+            if (j < L) {
+                float p = 0.f;
+#pragma unroll
+                for (int e = 0; e < DV; ++e) p += qr[e] * kr[j][e];
+                sc[j] = t_wave_sum(p) * scaling + bias[j];
+                mx = fmaxf(mx, sc[j]);
+            }
         }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j)
+            if (j < L) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+        float acc[DV];
+#pragma unroll
+        for (int e = 0; e < DV; ++e) acc[e] = 0.f;
+        float* prow = probs + (((size_t)n * heads + hd) * seq + i) * seq;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j)
+            if (j < L) {
+                const float p = sc[j] / sum;
+                if (lane == 0) prow[j] = p;
+#pragma unroll
+                for (int e = 0; e < DV; ++e) acc[e] += p * vr[j][e];
+            }
+#pragma unroll
+        for (int e = 0; e < DV; ++e) { const int c = lane + 64 * e; if (c < d) ctx[(qbase + i) * ld_ctx + hd * d + c] = acc[e]; }
+    }
 }
 
 // dv_j = sum_i p_ij dctx_i;  dp_ij = dctx_i . v_j;  ds_ij = p_ij (dp_ij - sum_j' p_ij' dp_ij');
-// dq_i = scaling sum_j ds_ij k_j;  dk_j = scaling sum_i ds_ij q_i
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ dctx, int ld_ctx, const float* __restrict__ q, int ldq, const float* __restrict__ k,
-                                                      const float* __restrict__ v, int ld, const float* __restrict__ probs, const int32_t* __restrict__ row_offset,
-                                                      int seq, int heads, int d, float scaling, int cls_only, float* __restrict__ dq, int ld_dq,
-                                                      float* __restrict__ dk, float* __restrict__ dv, int ld_d) {
-    __shared__ float p[ATT_MAX_L][ATT_MAX_L], ds[ATT_MAX_L][ATT_MAX_L];
-    const int n = blockIdx.x / heads, hd = blockIdx.x % heads, lane = threadIdx.x;
+// dq_i = scaling sum_j ds_ij k_j;  dk_j = scaling sum_i ds_ij q_i.   Same layout as the forward: keys, values and the running
+// dk / dv of the row in registers, one pass per query position.
+template <int LMAX, int DV>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ dctx, int ld_ctx, const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                       const float* __restrict__ v, int ld, const float* __restrict__ probs, const int32_t* __restrict__ row_offset,
+                                                       int seq, int heads, int d, float scaling, int cls_only, float* __restrict__ dq, int ld_dq,
+                                                       float* __restrict__ dk, float* __restrict__ dv, int ld_d) {
+    const int groups = (heads + 3) >> 2;
+    const int n = blockIdx.x / groups, hd = (blockIdx.x % groups) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (hd >= heads) return;
     const size_t base = row_offset ? (size_t)row_offset[n] : (size_t)n * seq;
     const int L = row_offset ? row_offset[n + 1] - row_offset[n] : seq;
     const int nq = cls_only ? 1 : L;
     const size_t qbase = cls_only ? (size_t)n : base;
-    for (int t = lane; t < nq * L; t += 64) p[t / L][t % L] = probs[(((size_t)n * heads + hd) * seq + t / L) * seq + t % L];
-    __syncthreads();
-    for (int i = 0; i < nq; ++i)
-        for (int j = 0; j < L; ++j) {
-            float a = 0.f;
-            for (int c = lane; c < d; c += 64) a += dctx[(qbase + i) * ld_ctx + hd * d + c] * v[(base + j) * ld + hd * d + c];
-            a = t_wave_sum(a);
-            if (lane == 0) ds[i][j] = a;           // dp for now
-        }
-    __syncthreads();
-    if (lane < nq) {
-        const int i = lane;
-        float dot = 0.f;
-        for (int j = 0; j < L; ++j) dot += p[i][j] * ds[i][j];
-        for (int j = 0; j < L; ++j) ds[i][j] = p[i][j] * (ds[i][j] - dot);
-    }
-    __syncthreads();
-    for (int c = lane; c < d; c += 64) {
-        for (int j = 0; j < L; ++j) {
-            float av = 0.f, ak = 0.f;
-            for (int i = 0; i < nq; ++i) {
-                av += p[i][j] * dctx[(qbase + i) * ld_ctx + hd * d + c];
-                ak += ds[i][j] * q[(qbase + i) * ldq + hd * d + c];
+    float kr[LMAX][DV], vr[LMAX][DV], dkr[LMAX][DV], dvr[LMAX][DV];
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+#pragma unroll
+        for (int e = 0; e < DV; ++e) { kr[j][e] = 0.f; vr[j][e] = 0.f; dkr[j][e] = 0.f; dvr[j][e] = 0.f; }
+        if (j < L) {
+#pragma unroll
+            for (int e = 0; e < DV; ++e) {
+                const int c = lane + 64 * e;
+                if (c < d) { kr[j][e] = k[(base + j) * ld + hd * d + c]; vr[j][e] = v[(base + j) * ld + hd * d + c]; }
             }
-            dv[(base + j) * ld_d + hd * d + c] = av;
-            dk[(base + j) * ld_d + hd * d + c] = ak * scaling;
-        }
-        for (int i = 0; i < nq; ++i) {
-            float aq = 0.f;
-            for (int j = 0; j < L; ++j) aq += ds[i][j] * k[(base + j) * ld + hd * d + c];
-            dq[(qbase + i) * ld_dq + hd * d + c] = aq * scaling;
         }
     }
+    for (int i = 0; i < nq; ++i) {
+        float qr[DV], gr[DV];
+#pragma unroll
+        for (int e = 0; e < DV; ++e) {
+            const int c = lane + 64 * e;
+            qr[e] = c < d ? q[(qbase + i) * ldq + hd * d + c] : 0.f;
+            gr[e] = c < d ? dctx[(qbase + i) * ld_ctx + hd * d + c] : 0.f;
+        }
+        const float* prow = probs + (((size_t)n * heads + hd) * seq + i) * seq;
+        float pr[LMAX], dp[LMAX];
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j) {
+            pr[j] = 0.f; dp[j] = 0.f;
+            if (j < L) {
+                pr[j] = prow[j];
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < DV; ++e) a += gr[e] * vr[j][e];
+                dp[j] = t_wave_sum(a);
+                dot += pr[j] * dp[j];
+            }
+        }
+        float aq[DV];
+#pragma unroll
+        for (int e = 0; e < DV; ++e) aq[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j)
+            if (j < L) {
+                const float dsv = pr[j] * (dp[j] - dot);
+#pragma unroll
+                for (int e = 0; e < DV; ++e) {
+                    aq[e] += dsv * kr[j][e];
+                    dkr[j][e] += dsv * qr[e];
+                    dvr[j][e] += pr[j] * gr[e];
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < DV; ++e) { const int c = lane + 64 * e; if (c < d) dq[(qbase + i) * ld_dq + hd * d + c] = aq[e] * scaling; }
+    }
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j)
+        if (j < L) {
+#pragma unroll
+            for (int e = 0; e < DV; ++e) {
+                const int c = lane + 64 * e;
+                if (c < d) { dk[(base + j) * ld_d + hd * d + c] = dkr[j][e] * scaling; dv[(base + j) * ld_d + hd * d + c] = dvr[j][e]; }
+            }
+        }
 }
 
 // ---- indexed rows: out[r] = (a ? a[r] : 0) + src[idx[r]];  dst[idx[r]] += src[r] -------------------------------------------
@@ -586,6 +649,24 @@ static void ln_fwd_go(int32_t prec, dim3 grid, hipStream_t st, const float* x, i
                       int rows, int32_t h, void* y_lo) {
     if (prec == ZETT_PREC_F16) hipLaunchKernelGGL((ln_fwd_kernel<J, f16_t>), grid, dim3(256), 0, st, x, ld, gamma, beta, eps, y, stats, rows, h, (f16_t*)y_lo);
     else hipLaunchKernelGGL((ln_fwd_kernel<J, bf16_t>), grid, dim3(256), 0, st, x, ld, gamma, beta, eps, y, stats, rows, h, (bf16_t*)y_lo);
+}
+
+// the register layout of the attention kernels: positions rounded up to 2 / 4 / 8 / 16 / 32, 64-column slices of the head dim
+template <int DV, typename... Args>
+static void attn_fwd_go(int lmax, dim3 grid, hipStream_t st, Args... a) {
+    if (lmax <= 2) hipLaunchKernelGGL((attn_fwd_kernel<2, DV>), grid, dim3(256), 0, st, a...);
+    else if (lmax <= 4) hipLaunchKernelGGL((attn_fwd_kernel<4, DV>), grid, dim3(256), 0, st, a...);
+    else if (lmax <= 8) hipLaunchKernelGGL((attn_fwd_kernel<8, DV>), grid, dim3(256), 0, st, a...);
+    else if (lmax <= 16) hipLaunchKernelGGL((attn_fwd_kernel<16, DV>), grid, dim3(256), 0, st, a...);
+    else hipLaunchKernelGGL((attn_fwd_kernel<32, DV>), grid, dim3(256), 0, st, a...);
+}
+template <int DV, typename... Args>
+static void attn_bwd_go(int lmax, dim3 grid, hipStream_t st, Args... a) {
+    if (lmax <= 2) hipLaunchKernelGGL((attn_bwd_kernel<2, DV>), grid, dim3(256), 0, st, a...);
+    else if (lmax <= 4) hipLaunchKernelGGL((attn_bwd_kernel<4, DV>), grid, dim3(256), 0, st, a...);
+    else if (lmax <= 8) hipLaunchKernelGGL((attn_bwd_kernel<8, DV>), grid, dim3(256), 0, st, a...);
+    else if (lmax <= 16) hipLaunchKernelGGL((attn_bwd_kernel<16, DV>), grid, dim3(256), 0, st, a...);
+    else if constexpr (DV < 4) hipLaunchKernelGGL((attn_bwd_kernel<32, DV>), grid, dim3(256), 0, st, a...);      // (DV = 4 would not fit its registers: refused by the caller)
 }
 
 extern "C" {
@@ -783,9 +864,14 @@ int zett_op_attention_fwd_f32(const float* q, int32_t ldq, const float* k, const
                               int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, int32_t cls_only, float* ctx, int32_t ld_ctx, float* probs, void* stream) {
     if (!q || !k || !v || !mask || !ctx || !probs) return fail(ZETT_E_INVALID, "null argument");
     if (seq < 1 || seq > ATT_MAX_L) return fail(ZETT_E_INVALID, "training attention handles 1 <= L <= %d positions, got %d", ATT_MAX_L, seq);
+    if (heads < 1 || head_dim < 1 || head_dim > 256) return fail(ZETT_E_INVALID, "training attention handles head dims up to 256, got %d", head_dim);
     if (n_rows <= 0) return 0;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(n_rows * heads)), dim3(64), 0, (hipStream_t)stream, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim,
-                       1.0f / sqrtf((float)head_dim), cls_only, ctx, ld_ctx, probs);
+    const dim3 grid((unsigned)(n_rows * ((heads + 3) / 4)));
+    const float scaling = 1.0f / sqrtf((float)head_dim);
+    hipStream_t st = (hipStream_t)stream;
+    if (head_dim <= 64) attn_fwd_go<1>(seq, grid, st, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim, scaling, cls_only, ctx, ld_ctx, probs);
+    else if (head_dim <= 128) attn_fwd_go<2>(seq, grid, st, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim, scaling, cls_only, ctx, ld_ctx, probs);
+    else attn_fwd_go<4>(seq, grid, st, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim, scaling, cls_only, ctx, ld_ctx, probs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -795,9 +881,15 @@ int zett_op_attention_bwd_f32(const float* dctx, int32_t ld_ctx, const float* q,
                               float* dk, float* dv, int32_t ld_d, void* stream) {
     if (!dctx || !q || !k || !v || !probs || !dq || !dk || !dv) return fail(ZETT_E_INVALID, "null argument");
     if (seq < 1 || seq > ATT_MAX_L) return fail(ZETT_E_INVALID, "training attention handles 1 <= L <= %d positions, got %d", ATT_MAX_L, seq);
+    if (heads < 1 || head_dim < 1 || head_dim > 256) return fail(ZETT_E_INVALID, "training attention handles head dims up to 256, got %d", head_dim);
+    if (head_dim > 128 && seq > 16) return fail(ZETT_E_INVALID, "training attention backward: head dims above 128 are handled for up to 16 positions, got %d", seq);
     if (n_rows <= 0) return 0;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(n_rows * heads)), dim3(64), 0, (hipStream_t)stream, dctx, ld_ctx, q, ldq, k, v, ld, probs, row_offset, seq,
-                       heads, head_dim, 1.0f / sqrtf((float)head_dim), cls_only, dq, ld_dq, dk, dv, ld_d);
+    const dim3 grid((unsigned)(n_rows * ((heads + 3) / 4)));
+    const float scaling = 1.0f / sqrtf((float)head_dim);
+    hipStream_t st = (hipStream_t)stream;
+    if (head_dim <= 64) attn_bwd_go<1>(seq, grid, st, dctx, ld_ctx, q, ldq, k, v, ld, probs, row_offset, seq, heads, head_dim, scaling, cls_only, dq, ld_dq, dk, dv, ld_d);
+    else if (head_dim <= 128) attn_bwd_go<2>(seq, grid, st, dctx, ld_ctx, q, ldq, k, v, ld, probs, row_offset, seq, heads, head_dim, scaling, cls_only, dq, ld_dq, dk, dv, ld_d);
+    else attn_bwd_go<4>(seq, grid, st, dctx, ld_ctx, q, ldq, k, v, ld, probs, row_offset, seq, heads, head_dim, scaling, cls_only, dq, ld_dq, dk, dv, ld_d);
     HIP_TRY(hipGetLastError());
     return 0;
 }
