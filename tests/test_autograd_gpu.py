@@ -441,3 +441,26 @@ def test_data_parallel_training_step_two_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["world"] == 2 and d["compared"] >= 40 and d["worst_rel"] < 1e-4, d
+
+
+def test_f16_training_overflow_is_an_error_not_a_nan():
+    """f16 operands without loss scaling: cotangents of 1e9 overflow the half range in the gradient operands; the step raises
+    (zett_amd._lib.RangeError) instead of returning NaN gradients, and the same step in bf16 is finite."""
+    from zett_amd import _lib
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg, w, src_np, ids_np = _case({}, seed=51, rows=64)
+    src, ids = torch.from_numpy(src_np).to(DEV), torch.from_numpy(ids_np).to(DEV)
+    for precision in ("f16", "bf16"):
+        model = ZettHypernet(ZettHypernetConfig(**cfg))
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+        model = model.to(DEV).requires_grad_(True).train()
+        model.train_precision = precision
+        out = model(ids, source_embeddings=src, lang_index=torch.tensor(1))
+        loss = sum((o * 1e9).sum() for o in out)
+        if precision == "f16":
+            with pytest.raises(_lib.RangeError, match="bf16"):
+                loss.backward()
+        else:
+            loss.backward()
+            assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)

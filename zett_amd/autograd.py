@@ -22,7 +22,8 @@ referenced id, the position-0-only last layer: exact for gradients too (a positi
 receives a zero gradient; a value computed once and used k times receives the sum of the k gradients), 3.3x fewer FLOPs on
 the headline workload.  The dense contractions run in exact fp32 MFMA (default) or on 16-bit MFMA operands (bf16 / f16:
 ``model.train_precision``; operands converted — and for dgrad / wgrad transposed in the same pass — per launch, fp32
-accumulation, everything else fp32).
+accumulation, everything else fp32).  bf16 is the 16-bit mode to train in: f16 operands are ~8x more accurate but have the
+half range and there is no loss scaling here — a step whose gradients overflow raises RangeError instead of returning NaNs.
 """
 from __future__ import annotations
 
@@ -732,6 +733,14 @@ class HypernetFunction(torch.autograd.Function):
             g = G.get(name)
             grads.append(None if g is None else g.reshape(p.shape))
         ctx.S = None
+        if ctx.ops.precision == "f16":
+            # half operands have 5 exponent bits and this path does no loss scaling: a gradient (or activation) beyond 65 504
+            # becomes inf in an operand and NaN in the result.  Said loudly (one parameter-sized reduction and a host read per
+            # step, f16 only) instead of handing NaNs to the optimizer; bf16 operands have the fp32 range.
+            worst = torch.stack([g.detach().abs().max() for g in grads if g is not None and g.numel()]).max()
+            if not bool(torch.isfinite(worst)):
+                raise _lib.RangeError("zett_amd: a gradient left the range of f16 MFMA operands (non-finite parameter gradients); scale the loss "
+                                      "down or use model.train_precision = 'bf16' (fp32 exponent range)")
         return (None, None, None, None, None, None, None, None, *grads)
 
 
