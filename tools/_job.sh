@@ -1,6 +1,7 @@
+set -u
 cd $GRAFT_REPO_ROOT
-export NORMAL=1 BURST=10 ROUNDS=5 ONLY=p4d,p4dpf
-for aux in 2 1 3; do
-echo "aux=$aux"
-EPI=8 timeout 300 tools/gemm_bench_lean_abl$aux 169283 768 768 118979 2048 2048 77450 4096 4096 2>&1 | cut -c60-260
-done
+mkdir -p gpurun_out/r3h
+timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/r3h/gpu_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r3h/gpu_tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" > gpurun_out/r3h/smoke.log 2>&1
+tail -3 gpurun_out/r3h/gpu_tests.log; tail -1 gpurun_out/r3h/smoke.log
+bash tools/profile_round.sh r3h
