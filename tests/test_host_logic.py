@@ -436,3 +436,44 @@ def test_no_product_kernel_uses_scratch(tmp_path):
     assert len(names) == len(scratch) and len(names) > 50
     bad = [(n, s) for n, s in zip(names, scratch) if s]
     assert not bad, bad
+
+
+def test_training_primitives_refuse_bad_arguments_before_touching_the_device():
+    """Error behaviour of the zett_op_* entry points at the boundary: arguments are validated before any launch, the return code is
+    ZETT_E_INVALID and zett_last_error says why (no GPU needed: nothing is launched)."""
+    import ctypes as C
+    from zett_amd import _lib
+    lib = _lib.load()
+    P = C.c_void_p
+    buf = (C.c_float * 4096)()
+    a = C.cast(buf, P)
+    null = P(0)
+
+    def refused(rc, *words):
+        assert rc == _lib.E_INVALID, rc
+        msg = lib.zett_last_error().decode()
+        assert all(w in msg for w in words), msg
+
+    refused(lib.zett_op_gemm_f32(a, 32, a, 32, 4, 4, 20, null, 0, null, 0, a, 4, null), "multiple of 32")
+    refused(lib.zett_op_gemm_f32(null, 32, a, 32, 4, 4, 32, null, 0, null, 0, a, 4, null), "null")
+    refused(lib.zett_op_gemm_lo(_lib.PREC_BF16, a, 64, a, 64, 4, 4, 96, null, 0, null, 0, a, 4, null), "multiple of 64")
+    refused(lib.zett_op_gemm_lo(_lib.PREC_F32, a, 64, a, 64, 4, 4, 64, null, 0, null, 0, a, 4, null), "ZETT_PREC")
+    refused(lib.zett_op_convert_lo(_lib.PREC_F16, a, 8, a, 4, 2, 8, 8, null), "conversion")          # ld_out < cols_padded
+    refused(lib.zett_op_transpose_lo(_lib.PREC_F16, a, 8, a, 2, 4, 8, 4, null), "transpose")          # ld_out < rows_padded
+    refused(lib.zett_op_transpose_lo16(7, a, 8, a, 64, 4, 8, 64, null), "ZETT_PREC")
+    refused(lib.zett_op_grad_operands_lo(_lib.PREC_BF16, a, 8, null, 0, 0, 4, 8, 64, null, 8, a, 64, a, null), "null")
+    refused(lib.zett_op_grad_operands_lo(_lib.PREC_BF16, a, 8, a, 8, 3, 4, 8, 64, a, 8, a, 64, a, null), "activation kind")
+    refused(lib.zett_op_elementwise_f32(9, a, a, null, null, null, a, 16, 4, null), "elementwise")
+    refused(lib.zett_op_layernorm_fwd_f32(a, 8, a, a, 1e-5, a, a, 2, 6, null, 0, null), "multiples of 4")
+    refused(lib.zett_op_layernorm_fwd_f32(a, 8200, a, a, 1e-5, a, a, 2, 8200, null, 0, null), "8192")
+    refused(lib.zett_op_layernorm_bwd_f32(a, null, a, 8, a, a, a, a, 0, 2, 8, null), "n_part")
+    refused(lib.zett_op_gelu_fwd_f32(a, a, 16, 5, null), "gelu")
+    refused(lib.zett_op_gelu_fwd_lo(_lib.PREC_F16, a, a, 16, 0, null), "gelu")
+    m = C.cast((C.c_uint8 * 64)(), P)
+    refused(lib.zett_op_attention_fwd_f32(a, 64, a, a, 64, m, null, 1, 33, 1, 64, 0, a, 64, a, null), "32")
+    refused(lib.zett_op_attention_fwd_f32(a, 64, a, a, 64, m, null, 1, 4, 1, 300, 0, a, 64, a, null), "256")
+    refused(lib.zett_op_attention_bwd_f32(a, 64, a, 64, a, a, 64, a, null, 1, 20, 1, 192, 0, a, 64, a, a, 64, null), "16 positions")
+    refused(lib.zett_op_gather_fwd_f32(a, 4, a, 9, 8, 10, a, null, null, a, null), "gather")
+    # and nothing to do is not an error
+    assert lib.zett_op_gemm_f32(a, 32, a, 32, 0, 4, 32, null, 0, null, 0, a, 4, null) == 0
+    assert lib.zett_op_gelu_fwd_f32(a, a, 0, 1, null) == 0
