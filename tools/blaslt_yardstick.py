@@ -3,6 +3,8 @@ shapes the benchmark workload launches, to compare with the in-tree kernel's per
 import os, torch, time
 ZERO = bool(os.environ.get("ZERO"))
 shapes = [(65536, 3072, 1024), (65536, 1024, 1024), (65536, 4096, 1024), (65536, 1024, 4096), (32768, 8192, 1024), (65536, 1024, 1536), (8192, 8192, 8192)]
+if os.environ.get("SHAPES"):      # SHAPES="M,N,K M,N,K ...": e.g. the launch shapes of the narrow workloads (XLM-R, TinyLlama) or of a 4 096-row shard
+    shapes = [tuple(int(x) for x in s.split(",")) for s in os.environ["SHAPES"].split()]
 for M, N, K in shapes:
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
