@@ -312,10 +312,13 @@ int zett_op_gelu_fwd_lo(int32_t prec, const float* z, void* h_lo, int64_t n, int
  * positions the row keeps) or [n*seq, (n+1)*seq) when row_offset is NULL (the reference's dense layout); at most seq <= 32
  * positions per row; mask[t] = position t is visible as a key.  cls_only: one query per row (position 0), q and ctx hold
  * one row per vocabulary row (the position-0-only last layer).  probs [n_rows, heads, seq, seq] is kept for the backward.
+ * ctx_lo (nullable, type prec, same leading dimension): the context is written as the 16-bit operand of the contraction behind it
+ * INSTEAD of fp32 (ctx may then be NULL).
  * Head dims up to 256 (the backward: above 128 for rows of up to 16 positions — the row's keys, values and their gradients
  * live in registers). */
 int zett_op_attention_fwd_f32(const float* q, int32_t ldq, const float* k, const float* v, int32_t ld, const uint8_t* mask, const int32_t* row_offset,
-                              int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, int32_t cls_only, float* ctx, int32_t ld_ctx, float* probs, void* stream);
+                              int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, int32_t cls_only, float* ctx, int32_t ld_ctx, float* probs,
+                              void* ctx_lo, int32_t prec, void* stream);
 int zett_op_attention_bwd_f32(const float* dctx, int32_t ld_ctx, const float* q, int32_t ldq, const float* k, const float* v, int32_t ld, const float* probs,
                               const int32_t* row_offset, int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, int32_t cls_only, float* dq, int32_t ld_dq,
                               float* dk, float* dv, int32_t ld_d, void* stream);

@@ -155,6 +155,14 @@ def test_grad_operands_one_read_matches_the_separate_kernels(precision):
     assert torch.equal(y._zett_lo, ops.to_lo(y.clone())) and torch.equal(ops.transpose(y), ops.transpose(y.clone()))
     w2 = torch.randn(64, 192, device=DEV, generator=g)
     assert torch.equal(ops.gemm(y, w2), ops.gemm(y.clone(), w2))           # (the twin is the operand the conversion would have made)
+    # the attention context written as a 16-bit operand only
+    n, L, heads, d = 11, 5, 2, 64
+    qkv = torch.randn(n * L, 3 * heads * d, device=DEV, generator=g)
+    mask = torch.ones(n * L, dtype=torch.uint8, device=DEV)
+    H = heads * d
+    c32, p32 = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, None, n, L, heads, H)
+    c16, p16 = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, None, n, L, heads, H, operand=True)
+    assert c16.dtype == ops.lo_dtype and torch.equal(c16, ops.to_lo(c32)) and torch.equal(p16, p32)
 
 
 def test_attention_forward_backward_match_torch():

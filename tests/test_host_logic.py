@@ -470,8 +470,9 @@ def test_training_primitives_refuse_bad_arguments_before_touching_the_device():
     refused(lib.zett_op_gelu_fwd_f32(a, a, 16, 5, null), "gelu")
     refused(lib.zett_op_gelu_fwd_lo(_lib.PREC_F16, a, a, 16, 0, null), "gelu")
     m = C.cast((C.c_uint8 * 64)(), P)
-    refused(lib.zett_op_attention_fwd_f32(a, 64, a, a, 64, m, null, 1, 33, 1, 64, 0, a, 64, a, null), "32")
-    refused(lib.zett_op_attention_fwd_f32(a, 64, a, a, 64, m, null, 1, 4, 1, 300, 0, a, 64, a, null), "256")
+    refused(lib.zett_op_attention_fwd_f32(a, 64, a, a, 64, m, null, 1, 33, 1, 64, 0, a, 64, a, null, 0, null), "32")
+    refused(lib.zett_op_attention_fwd_f32(a, 64, a, a, 64, m, null, 1, 4, 1, 300, 0, a, 64, a, null, 0, null), "256")
+    refused(lib.zett_op_attention_fwd_f32(a, 64, a, a, 64, m, null, 1, 4, 1, 64, 0, null, 64, a, a, _lib.PREC_F32, null), "16-bit context")
     refused(lib.zett_op_attention_bwd_f32(a, 64, a, 64, a, a, 64, a, null, 1, 20, 1, 192, 0, a, 64, a, a, 64, null), "16 positions")
     refused(lib.zett_op_gather_fwd_f32(a, 4, a, 9, 8, 10, a, null, null, a, null), "gather")
     # and nothing to do is not an error

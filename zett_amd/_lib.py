@@ -123,7 +123,7 @@ def load():
         lib.zett_op_layernorm_bwd_f32.argtypes = [P, P, P, I32, P, P, P, P, I32, I64, I32, P]
         lib.zett_op_gelu_fwd_f32.argtypes = [P, P, I64, I32, P]
         lib.zett_op_gelu_bwd_f32.argtypes = [P, P, P, I64, I32, P]
-        lib.zett_op_attention_fwd_f32.argtypes = [P, I32, P, P, I32, P, P, I64, I32, I32, I32, I32, P, I32, P, P]
+        lib.zett_op_attention_fwd_f32.argtypes = [P, I32, P, P, I32, P, P, I64, I32, I32, I32, I32, P, I32, P, P, I32, P]
         lib.zett_op_attention_bwd_f32.argtypes = [P, I32, P, I32, P, P, I32, P, P, I64, I32, I32, I32, I32, P, I32, P, P, I32, P]
         lib.zett_op_gather_rows_f32.argtypes = [P, P, I32, P, P, I64, I32, P]
         lib.zett_op_scatter_add_rows_f32.argtypes = [P, I32, P, P, I64, I32, P]

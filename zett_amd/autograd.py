@@ -253,14 +253,18 @@ class Ops:
         _lib.check(self.lib.zett_op_gelu_bwd_f32(_ptr(z), _ptr(dh), _ptr(dz), z.numel(), kind, self._stream()), "zett_op_gelu_bwd_f32")
         return dz
 
-    def attention(self, q, k, v, mask, row_offset, n_rows, seq, heads, hidden, cls_only=False):
+    def attention(self, q, k, v, mask, row_offset, n_rows, seq, heads, hidden, cls_only=False, operand=False):
         """q [Tq, *] (Tq = positions, or n_rows when cls_only), k / v [T, *] column views, mask uint8 [T] (key visible),
-        row_offset int32 [n_rows + 1] or None (dense: seq positions per row) -> ctx [Tq, H], probs [n_rows, heads, seq, seq]"""
+        row_offset int32 [n_rows + 1] or None (dense: seq positions per row) -> ctx [Tq, H], probs [n_rows, heads, seq, seq].
+        operand = True (the context only feeds the output projection): in 16-bit arithmetic ctx is written as that operand."""
         assert k.stride(0) == v.stride(0) and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
         d = hidden // heads
-        ctx, probs = self.new(q.shape[0], hidden), torch.zeros((n_rows, heads, seq, seq), dtype=torch.float32, device=self.device)
+        lo = operand and self.prec is not None and hidden % 64 == 0
+        ctx = torch.empty((q.shape[0], hidden), dtype=self.lo_dtype if lo else torch.float32, device=self.device)
+        probs = torch.zeros((n_rows, heads, seq, seq), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.zett_op_attention_fwd_f32(_ptr(q), q.stride(0), _ptr(k), _ptr(v), k.stride(0), _ptr(mask), _ptr(row_offset), n_rows, seq, heads, d,
-                                                      int(cls_only), _ptr(ctx), hidden, _ptr(probs), self._stream()), "zett_op_attention_fwd_f32")
+                                                      int(cls_only), _ptr(None if lo else ctx), hidden, _ptr(probs), _ptr(ctx if lo else None),
+                                                      self.prec if lo else 0, self._stream()), "zett_op_attention_fwd_f32")
         return ctx, probs
 
     def attention_bwd(self, dctx, q, k, v, probs, row_offset, n_rows, seq, heads, hidden, dq, dk, dv, cls_only=False):
@@ -467,7 +471,7 @@ def forward_train(ops: Ops, dims: HypernetDims, ln_eps: float, P: Dict[str, torc
         wqkv = torch.cat([P[a + "query.weight"], P[a + "key.weight"], P[a + "value.weight"]], 0)      # fused operand (parameter plumbing)
         bqkv = torch.cat([P[a + "query.bias"], P[a + "key.bias"], P[a + "value.bias"]], 0)
         qkv = ops.gemm(z, wqkv, bqkv)
-        ctx, probs = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask.view(-1), None, n, Lp, dims.heads, H)
+        ctx, probs = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask.view(-1), None, n, Lp, dims.heads, H, operand=True)
         s1 = ops.gemm(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"], residual=z)
         z1, st1 = ops.layernorm(s1, P[p + "attention.output.LayerNorm.weight"], P[p + "attention.output.LayerNorm.bias"], ln_eps)
         u = ops.gemm(z1, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"])
@@ -611,7 +615,7 @@ def forward_packed(ops: Ops, dims: HypernetDims, ln_eps: float, P, ids: torch.Te
         A = dict(z=z, wqkv=wqkv)
         if not last:
             qkv = ops.gemm(z, wqkv, bqkv)
-            ctx, probs = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], key, off, n, seq, dims.heads, H)
+            ctx, probs = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], key, off, n, seq, dims.heads, H, operand=True)
             res = z
             A.update(qkv=qkv)
         else:
@@ -619,7 +623,7 @@ def forward_packed(ops: Ops, dims: HypernetDims, ln_eps: float, P, ids: torch.Te
             kv = ops.gemm(z, wqkv[H:], bqkv[H:])
             zc = ops.gather_rows(z, plan["cls"])
             qc = ops.gemm(zc, wqkv[:H], bqkv[:H])
-            ctx, probs = ops.attention(qc, kv[:, :H], kv[:, H:], key, off, n, seq, dims.heads, H, cls_only=True)
+            ctx, probs = ops.attention(qc, kv[:, :H], kv[:, H:], key, off, n, seq, dims.heads, H, cls_only=True, operand=True)
             res = zc
             A.update(kv=kv, zc=zc, qc=qc)
         s1 = ops.gemm(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"], residual=res)

@@ -420,7 +420,8 @@ constexpr int ATT_MAX_L = 32;
 template <int LMAX, int DV>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ld,
                                                        const uint8_t* __restrict__ mask, const int32_t* __restrict__ row_offset, int seq, int heads, int d,
-                                                       float scaling, int cls_only, float* __restrict__ ctx, int ld_ctx, float* __restrict__ probs) {
+                                                       float scaling, int cls_only, float* __restrict__ ctx, int ld_ctx, float* __restrict__ probs,
+                                                       void* __restrict__ ctx_lo, int lo_kind) {
     const int groups = (heads + 3) >> 2;
     const int n = blockIdx.x / groups, hd = (blockIdx.x % groups) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (hd >= heads) return;
@@ -477,7 +478,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                 for (int e = 0; e < DV; ++e) acc[e] += p * vr[j][e];
             }
 #pragma unroll
-        for (int e = 0; e < DV; ++e) { const int c = lane + 64 * e; if (c < d) ctx[(qbase + i) * ld_ctx + hd * d + c] = acc[e]; }
+        for (int e = 0; e < DV; ++e) {
+            const int c = lane + 64 * e;
+            if (c < d) {
+                const size_t o = (qbase + i) * ld_ctx + hd * d + c;
+                // lo_kind != 0: the context only feeds a contraction (and its transposed twin in the backward): written as that 16-bit
+                // operand, its fp32 form is never stored
+                if (lo_kind == 0) ctx[o] = acc[e];
+                else if (lo_kind == 1) ((bf16_t*)ctx_lo)[o] = f32_to_bf16(acc[e]);
+                else ((f16_t*)ctx_lo)[o] = (f16_t)acc[e];
+            }
+        }
     }
 }
 
@@ -861,17 +872,20 @@ int zett_op_gelu_bwd_f32(const float* z, const float* dh, float* dz, int64_t n, 
 }
 
 int zett_op_attention_fwd_f32(const float* q, int32_t ldq, const float* k, const float* v, int32_t ld, const uint8_t* mask, const int32_t* row_offset,
-                              int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, int32_t cls_only, float* ctx, int32_t ld_ctx, float* probs, void* stream) {
-    if (!q || !k || !v || !mask || !ctx || !probs) return fail(ZETT_E_INVALID, "null argument");
+                              int64_t n_rows, int32_t seq, int32_t heads, int32_t head_dim, int32_t cls_only, float* ctx, int32_t ld_ctx, float* probs,
+                              void* ctx_lo, int32_t prec, void* stream) {
+    if (!q || !k || !v || !mask || (!ctx && !ctx_lo) || !probs) return fail(ZETT_E_INVALID, "null argument");
+    if (ctx_lo && prec != ZETT_PREC_BF16 && prec != ZETT_PREC_F16) return fail(ZETT_E_INVALID, "the 16-bit context takes ZETT_PREC_BF16 or ZETT_PREC_F16");
     if (seq < 1 || seq > ATT_MAX_L) return fail(ZETT_E_INVALID, "training attention handles 1 <= L <= %d positions, got %d", ATT_MAX_L, seq);
     if (heads < 1 || head_dim < 1 || head_dim > 256) return fail(ZETT_E_INVALID, "training attention handles head dims up to 256, got %d", head_dim);
     if (n_rows <= 0) return 0;
     const dim3 grid((unsigned)(n_rows * ((heads + 3) / 4)));
     const float scaling = 1.0f / sqrtf((float)head_dim);
+    const int lo_kind = !ctx_lo ? 0 : (prec == ZETT_PREC_BF16 ? 1 : 2);
     hipStream_t st = (hipStream_t)stream;
-    if (head_dim <= 64) attn_fwd_go<1>(seq, grid, st, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim, scaling, cls_only, ctx, ld_ctx, probs);
-    else if (head_dim <= 128) attn_fwd_go<2>(seq, grid, st, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim, scaling, cls_only, ctx, ld_ctx, probs);
-    else attn_fwd_go<4>(seq, grid, st, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim, scaling, cls_only, ctx, ld_ctx, probs);
+    if (head_dim <= 64) attn_fwd_go<1>(seq, grid, st, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim, scaling, cls_only, ctx, ld_ctx, probs, ctx_lo, lo_kind);
+    else if (head_dim <= 128) attn_fwd_go<2>(seq, grid, st, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim, scaling, cls_only, ctx, ld_ctx, probs, ctx_lo, lo_kind);
+    else attn_fwd_go<4>(seq, grid, st, q, ldq, k, v, ld, mask, row_offset, seq, heads, head_dim, scaling, cls_only, ctx, ld_ctx, probs, ctx_lo, lo_kind);
     HIP_TRY(hipGetLastError());
     return 0;
 }
