@@ -190,7 +190,9 @@ def main():
     ap.add_argument("--no-retokenize", action="store_true", help="A/B only: start every step from the id matrix instead of the surface forms")
     ap.add_argument("--chunks", type=int, default=2, help="N > 1: row blocks per step (zett_amd/sharding.py: the all-gather of a block overlaps the next block's forward)")
     ap.add_argument("--serial-allgather", action="store_true", help="N > 1: one block per step, i.e. forward, then all-gather (A/B)")
-    ap.add_argument("--gather-mode", default="allgather", choices=["allgather", "fanout"],
+    ap.add_argument("--force-gather", action="store_true", help="N = 1: join a ONE-rank RCCL group (backend nccl) and run every step through the row exchange "
+                    "(RowGather: all_gather_into_tensor on RCCL's stream, side-stream early start) exactly as N > 1 does — the nccl code path on a 1-GPU box")
+    ap.add_argument("--gather-mode", default="auto", choices=["auto", "allgather", "fanout"],
                     help="N > 1: transport of the row exchange (zett_amd/sharding.py RowGather): RCCL all-gather, or direct fan-out (every rank sends its shard to all peers at once, one xGMI link each)")
     ap.add_argument("--no-early-gather", action="store_true", help="N > 1, A/B: start the exchange of pred_in / bias behind the whole forward instead of behind their own completion point")
     args = ap.parse_args()
@@ -217,6 +219,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+    elif args.force_gather:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    exchange = world > 1 or args.force_gather          # steps end with the row exchange (RowGather)
+    from zett_amd.sharding import resolve_gather_mode
+    gather_mode = resolve_gather_mode(args.gather_mode, world)
 
     from zett_amd.hypernet import HipEngine
     from zett_amd.sharding import RowGather, plan_blocks
@@ -230,7 +240,7 @@ def main():
     weights = device_weights(cfg, device, seed=0)
     engine = HipEngine(dims, 1e-5, device, args.precision)
     engine.load_weights(weights)
-    if world == 1:
+    if not exchange:
         engine.set_option("time_gemm", 1)      # (brackets every GEMM with HIP events and synchronises at the end of a forward: kept out of the N > 1 overlap)
     if args.gemm_variant:
         engine.set_option("gemm_variant", args.gemm_variant)
@@ -247,7 +257,7 @@ def main():
     elif args.ln_fold != 1:
         engine.set_option("ln_fold", args.ln_fold)
     # the same weights in the OTHER 16-bit arithmetic, for the side measurement after the timed region (N = 1 only)
-    alt_precision = {"f16": "bf16", "bf16": "f16"}.get(args.precision) if (world == 1 and not args.no_alt_precision) else None
+    alt_precision = {"f16": "bf16", "bf16": "f16"}.get(args.precision) if (world == 1 and not exchange and not args.no_alt_precision) else None
     alt_engine = None
     if alt_precision:
         alt_engine = HipEngine(dims, 1e-5, device, alt_precision)
@@ -268,7 +278,7 @@ def main():
     # vocabulary is cut into `--chunks` row blocks, each sharded over the ranks, and the all-gather of a block runs
     # on RCCL's stream under the forward of the next one — inside ONE step, which is what a caller with a single
     # vocabulary gets from predict_sharded.  Nothing is carried across steps.
-    chunks = 1 if (world == 1 or args.serial_allgather) else args.chunks
+    chunks = 1 if (not exchange or args.serial_allgather) else args.chunks
     blocks = plan_blocks(rows, world, rank, chunks)
     assert all(b.hi > b.lo for b in blocks), "fewer rows than ranks"
     ids_blocks = [torch.from_numpy(ids_all[b.lo:b.hi]).to(device) for b in blocks]
@@ -312,7 +322,7 @@ def main():
         return ("16-bit out" if e & 1 else "fp32 out") + act
 
     def step():
-        gather = RowGather(blocks, mode=args.gather_mode) if world > 1 else None
+        gather = RowGather(blocks, mode=gather_mode) if exchange else None
         ready = None if args.no_early_gather else engine.stream_wait_output
         outs = None
         for k, b in enumerate(blocks):
@@ -357,7 +367,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -433,13 +443,13 @@ def main():
                                   for k, v in sorted(timed_classes.items(), key=lambda kv: -kv[1][1])]},
         # N > 1: the part of a step the compute stream spent waiting for the row exchange (HIP events around the waits in
         # RowGather.finish, this rank); the rest of the exchange ran under forwards
-        "exchange_exposed_ms_per_step": (sum(x for x in exposed if x is not None) / max(len(exposed), 1)) if world > 1 else None,
-        "exchange": None if world == 1 else {"mode": args.gather_mode, "early_start_of_pred_in_and_bias": not args.no_early_gather,
+        "exchange_exposed_ms_per_step": (sum(x for x in exposed if x is not None) / max(len(exposed), 1)) if exchange else None,
+        "exchange": None if not exchange else {"mode": gather_mode, "backend": dist.get_backend(), "one_rank_group": world == 1, "early_start_of_pred_in_and_bias": not args.no_early_gather,
                                              "bytes_received_per_rank_per_step": int(rows * (world - 1) / world * (dims.n_embd * (2 if dims.separate_out else 1) + 1) * 4)},
         "as_written_tflops": rows * f_ref * args.steps / dt / 1e12,
         "as_written_gflop_per_row": f_ref / 1e9,
     }
-    if world == 1:
+    if world == 1 and not exchange:
         # What a caller gets: the same steps with the per-launch HIP events (and the stream sync that reads them at the end of
         # every forward) switched off.  Measured after the timed region; `value` / `ms_per_step` stay the instrumented,
         # conservative figures the roofline is priced on.
@@ -480,7 +490,7 @@ def main():
                                            "bf16: rel-L2 ~0.97e-2 of the fp32 reference at this shape (tolerance 1e-2), f16: ~0.12e-2"}
         engine = main_engine
         alt_engine.close()
-    if world == 1 and args.precision != "f32" and not args.no_alt_precision and not args.rows:
+    if world == 1 and not exchange and args.precision != "f32" and not args.no_alt_precision and not args.rows:
         # Side measurement, outside the timed region and never `value`: the same workload in exact fp32 MFMA arithmetic — the
         # mode whose tolerance north_star names (max |err| <= 1e-4 relative to the row maximum against the fp32 reference).
         engine.close()
@@ -505,7 +515,7 @@ def main():
                               "gemm_tflops": f32_tf, "roofline_frac": f32_tf / PEAK_TFLOPS["f32"], "peak": PEAK_TFLOPS["f32"],
                               "note": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32, gemm8r tile); measured after the timed region"}
         f32_engine.close()
-    if rank == 0 and world == 1 and not args.no_live_traffic and not args.rows:
+    if rank == 0 and world == 1 and not exchange and not args.no_live_traffic and not args.rows:
         # roofline.traffic measured HERE: same build, same box, same workload, right after the timed region
         live, info = measure_traffic_live(args)
         if live is not None:
@@ -526,7 +536,7 @@ def main():
         result["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 

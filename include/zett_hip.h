@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define ZETT_ABI_VERSION 3      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range */
+#define ZETT_ABI_VERSION 4      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range;
+                                   4: ZETT_RETOK_WORDPIECE (zett_retok_model gained piece_continuing, max_input_chars_per_word) */
 
 enum zett_status {
     ZETT_OK = 0,
@@ -209,9 +210,9 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value);
 
 /* ---- retokenizer ------------------------------------------------------------
  * Replaces: zett.utils.get_surface_form_matrix (zett/utils.py:651-689) and the
- * tokenizers-library Model.tokenize it calls per token (zett/utils.py:681). */
+ * tokenizers-library Model.tokenize it calls per token (zett/utils.py:681): BPE, Unigram and WordPiece models. */
 
-enum zett_retok_kind { ZETT_RETOK_BPE = 0, ZETT_RETOK_UNIGRAM = 1 };
+enum zett_retok_kind { ZETT_RETOK_BPE = 0, ZETT_RETOK_UNIGRAM = 1, ZETT_RETOK_WORDPIECE = 2 };
 
 /* Host-side description of the hn tokenizer's bare model.  Pieces are given as RAW
  * BYTES (byte-level token strings already mapped through the reference's
@@ -237,6 +238,14 @@ typedef struct zett_retok_model {
     const uint8_t* special_bytes;  /* host: hn tokenizer all_special_tokens, raw bytes */
     const int32_t* special_offsets;/* host: n_special + 1                          */
     const int32_t* special_ids;    /* host                                          */
+    /* WordPiece (tokenizers WordPiece::tokenize; zett/tokenizer_converters.py:370-373 carries such hn tokenizers through).
+     * A lookup at the start of a word matches a vocabulary entry as listed; a lookup further in matches
+     * continuing_subword_prefix + substring.  The caller lists every entry once as it is (piece_continuing 0) and every
+     * entry that starts with the prefix once more with the prefix stripped (piece_continuing 1) — with the empty prefix
+     * that convert_to_byte_level leaves, each entry twice.  unk_id = id of unk_token, -1 when it is not in the vocabulary
+     * (a word that needs it then fails the call with ZETT_E_STATE, as the library raises). */
+    const uint8_t* piece_continuing;   /* host: n_pieces flags (may be NULL: no continuing pieces); WordPiece only */
+    int32_t max_input_chars_per_word;  /* WordPiece: longer words are [UNK] (library default 100)                  */
 } zett_retok_model;
 
 int zett_retok_create(const zett_retok_model* model, int device, zett_retok** out);

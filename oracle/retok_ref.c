@@ -4,8 +4,9 @@
  *
  * Restates get_surface_form_matrix (reference zett/utils.py:651-689) and the
  * third-party algorithm it calls per token (zett/utils.py:681): HF `tokenizers`
- * 0.22.2 `BPE::tokenize` (merge_word + Word::merge_all) and `Unigram::tokenize`
- * (encode_optimized Viterbi + piece->id with byte fallback).  Works in RAW BYTE
+ * 0.22.2 `BPE::tokenize` (merge_word + Word::merge_all), `Unigram::tokenize`
+ * (encode_optimized Viterbi + piece->id with byte fallback) and `WordPiece::tokenize`
+ * (greedy longest match, continuing pieces looked up with their prefix).  Works in RAW BYTE
  * space: every byte-level character is one byte (CHARS_TO_BYTES, zett/utils.py:351-609).
  *
  * Deliberately simple data structures (sorted arrays + bsearch, O(n^2) loops): it has
@@ -28,7 +29,7 @@ typedef struct {
 } merge_t;
 
 typedef struct {
-    int kind;                 /* 0 BPE, 1 Unigram */
+    int kind;                 /* 0 BPE, 1 Unigram, 2 WordPiece */
     int n_pieces;
     piece_t* pieces;          /* sorted by bytes; duplicates collapsed to the last one */
     uint8_t* blob;
@@ -42,6 +43,13 @@ typedef struct {
     piece_t* specials;
     uint8_t* sblob;
     int single_id[256];       /* id of the one-byte piece, -1 = absent */
+    /* WordPiece: vocabulary entries that start with continuing_subword_prefix, prefix stripped (what a lookup at
+       start > 0 can match); `pieces` holds every entry as listed (what a lookup at start == 0 can match) */
+    int n_cont;
+    piece_t* cont;
+    uint8_t* cblob;
+    int max_cont_len;
+    int max_chars;            /* max_input_chars_per_word */
 } model_t;
 
 /* UTF-8 bytes of the printable character that stands for raw byte b (GPT-2 table):
@@ -176,10 +184,31 @@ void* retok_ref_new(int kind, int n_pieces, const uint8_t* piece_bytes, const in
     return m;
 }
 
+void retok_ref_set_wordpiece(void* h, int n_cont, const uint8_t* cont_bytes, const int32_t* cont_offsets,
+                             const int32_t* cont_ids, int max_chars) {
+    model_t* m = (model_t*)h;
+    int i, total = n_cont ? cont_offsets[n_cont] : 0;
+    m->max_chars = max_chars;
+    m->cblob = (uint8_t*)malloc((size_t)total + 1);
+    if (total) memcpy(m->cblob, cont_bytes, (size_t)total);
+    m->cont = (piece_t*)malloc(sizeof(piece_t) * (size_t)(n_cont + 1));
+    for (i = 0; i < n_cont; ++i) {
+        piece_t* p = &m->cont[i];
+        p->p = m->cblob + cont_offsets[i];
+        p->len = cont_offsets[i + 1] - cont_offsets[i];
+        p->id = cont_ids[i];
+        p->score = 0.0;
+        p->order = i;
+        if (p->len > m->max_cont_len) m->max_cont_len = p->len;
+    }
+    qsort(m->cont, (size_t)n_cont, sizeof(piece_t), cmp_piece);
+    m->n_cont = dedup_pieces(m->cont, n_cont);
+}
+
 void retok_ref_free(void* h) {
     model_t* m = (model_t*)h;
     if (!m) return;
-    free(m->blob); free(m->pieces); free(m->merges); free(m->sblob); free(m->specials); free(m);
+    free(m->blob); free(m->pieces); free(m->merges); free(m->sblob); free(m->specials); free(m->cont); free(m->cblob); free(m);
 }
 
 /* ids of "<0xXX>" for every UTF-8 byte of the printable chars of raw[0..len); 0 if any is absent */
@@ -324,6 +353,29 @@ static int unigram_tokenize(const model_t* m, const uint8_t* raw, int len, int* 
     return n_out;
 }
 
+/* ---- WordPiece ----------------------------------------------------------------------
+ * tokenizers `WordPiece::tokenize`: more than max_input_chars_per_word characters -> [unk]; otherwise, from each
+ * start, the LONGEST substring that is in the vocabulary (with the continuing prefix when start > 0); no match at some
+ * start -> the whole word is [unk].  A byte-level character is one raw byte, so characters = bytes here. */
+static int wordpiece_tokenize(const model_t* m, const uint8_t* raw, int len, int* out /* cap 2*len+2 */) {
+    int start = 0, n = 0;
+    if (len == 0) return 0;
+    if (len > m->max_chars) { if (m->unk_id < 0) return -1; out[0] = m->unk_id; return 1; }
+    while (start < len) {
+        int end = len;
+        const piece_t* hit = NULL;
+        while (start < end) {
+            hit = start == 0 ? find_piece(m->pieces, m->n_pieces, raw, end) : find_piece(m->cont, m->n_cont, raw + start, end - start);
+            if (hit) break;
+            --end;
+        }
+        if (!hit) { if (m->unk_id < 0) return -1; out[0] = m->unk_id; return 1; }
+        out[n++] = hit->id;
+        start = end;
+    }
+    return n;
+}
+
 /* get_surface_form_matrix (zett/utils.py:651-689): `out` is pre-filled with pad_id by the caller */
 int retok_ref_surface_forms(void* h, const uint8_t* raw, const int32_t* offsets, int64_t n_tokens, int maxlen,
                             int pad_id, int32_t* out, int64_t* n_truncated) {
@@ -339,7 +391,7 @@ int retok_ref_surface_forms(void* h, const uint8_t* raw, const int32_t* offsets,
         int n, i;
         if (sp) { row[0] = sp->id; continue; }          /* :671-673 */
         ids = (int*)malloc(sizeof(int) * (size_t)(2 * len + 4));
-        n = m->kind == 0 ? bpe_tokenize(m, p, len, ids) : unigram_tokenize(m, p, len, ids);
+        n = m->kind == 0 ? bpe_tokenize(m, p, len, ids) : m->kind == 1 ? unigram_tokenize(m, p, len, ids) : wordpiece_tokenize(m, p, len, ids);
         if (n < 0) { free(ids); return -1; }
         if (n > maxlen) { n = maxlen; ++trunc; }        /* :683-685 */
         for (i = 0; i < n; ++i) row[i] = ids[i];

@@ -8,8 +8,9 @@ Restates, in plain Python (and in C, retok_ref.c, for the larger fixtures):
   (zett/utils.py:351-609 ``CHARS_TO_BYTES``; it is the GPT-2 ``bytes_to_unicode`` map);
 * ``get_surface_form_matrix`` (zett/utils.py:651-689);
 * what ``tokenizer_to_use._tokenizer.model.tokenize(token)`` does (zett/utils.py:681):
-  the HF ``tokenizers`` library's ``BPE::tokenize`` / ``Unigram::tokenize`` on the bare
-  model.  That library (pinned by the image at 0.22.2; reference requirements pull
+  the HF ``tokenizers`` library's ``BPE::tokenize`` / ``Unigram::tokenize`` /
+  ``WordPiece::tokenize`` on the bare model (zett/tokenizer_converters.py:370-373 carries
+  WordPiece hn tokenizers through convert_to_byte_level).  That library (pinned by the image at 0.22.2; reference requirements pull
   0.20.x) is a third-party Rust dependency and is NOT under /root/reference; its
   published algorithm is restated here and pinned by differential tests against the
   installed wheel (tests/test_retok_oracle.py) and by the golden fixtures
@@ -32,7 +33,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-BPE, UNIGRAM = 0, 1
+BPE, UNIGRAM, WORDPIECE = 0, 1, 2
 K_UNK_PENALTY = 10.0      # tokenizers: unigram/model.rs kUnkPenalty
 
 
@@ -75,6 +76,11 @@ class RetokModel:
     specials: List[bytes] = field(default_factory=list)     # hn all_special_tokens (raw bytes)
     special_ids: List[int] = field(default_factory=list)
     min_score: float = 0.0                 # Unigram: min over ALL vocabulary scores (tokenizers Unigram::from)
+    # WordPiece: vocabulary entries that start with continuing_subword_prefix, prefix stripped — what a lookup at start > 0
+    # can match (`pieces` holds every entry as listed: what a lookup at start == 0 can match)
+    cont_pieces: List[bytes] = field(default_factory=list)
+    cont_ids: List[int] = field(default_factory=list)
+    max_chars: int = 100                   # max_input_chars_per_word
 
 
 def _piece_bytes(piece: str) -> Optional[bytes]:
@@ -88,7 +94,7 @@ def model_from_tokenizer_json(data: dict, special_tokens: Sequence[str] = (), sp
     """Build the raw-byte model from a ``tokenizer.json`` dict (its "model" section)."""
     m = data["model"] if "model" in data else data
     kind = m.get("type")
-    if m.get("continuing_subword_prefix") or m.get("end_of_word_suffix"):
+    if kind != "WordPiece" and (m.get("continuing_subword_prefix") or m.get("end_of_word_suffix")):
         raise NotImplementedError("continuing_subword_prefix / end_of_word_suffix")
     if m.get("dropout"):
         raise NotImplementedError("BPE dropout")
@@ -134,6 +140,24 @@ def model_from_tokenizer_json(data: dict, special_tokens: Sequence[str] = (), sp
                           byte_fallback=bool(m.get("byte_fallback", False)), byte_fallback_ids=bf_ids,
                           specials=[b for b, _ in specials], special_ids=[i for _, i in specials],
                           min_score=min(float(s) for _, s in vocab_list) if vocab_list else 0.0)
+    if kind == "WordPiece":
+        vocab = m["vocab"]
+        prefix = m.get("continuing_subword_prefix") or ""
+        pieces, ids, cont, cont_ids = [], [], [], []
+        for tok, i in vocab.items():
+            b = _piece_bytes(tok)
+            if b is not None and len(b) > 0:
+                pieces.append(b)
+                ids.append(int(i))
+            if tok.startswith(prefix):               # (prefix + substring) is looked up: the substring alone must be byte-level
+                b = _piece_bytes(tok[len(prefix):])
+                if b is not None and len(b) > 0:
+                    cont.append(b)
+                    cont_ids.append(int(i))
+        unk = m.get("unk_token")
+        return RetokModel(kind=WORDPIECE, pieces=pieces, piece_ids=ids, unk_id=int(vocab[unk]) if unk in vocab else -1,
+                          specials=[b for b, _ in specials], special_ids=[i for _, i in specials],
+                          cont_pieces=cont, cont_ids=cont_ids, max_chars=int(m.get("max_input_chars_per_word", 100)))
     raise NotImplementedError(f"hn tokenizer model type {kind!r}")
 
 
@@ -290,7 +314,41 @@ def unigram_tokenize(model: RetokModel, raw: bytes) -> List[int]:
     return out
 
 
+def wordpiece_tokenize(model: RetokModel, raw: bytes) -> List[int]:
+    """tokenizers ``WordPiece::tokenize``: a word of more than max_input_chars_per_word characters is [unk]; otherwise
+    greedy longest match from each start (continuing pieces carry the prefix); a start without any match makes the WHOLE
+    word [unk].  One byte-level character is one raw byte, so characters = bytes."""
+    if not raw:
+        return []
+
+    def unk():
+        if model.unk_id < 0:
+            raise RuntimeError("WordPiece error: Missing [UNK] token from the vocabulary")
+        return [model.unk_id]
+
+    if len(raw) > model.max_chars:
+        return unk()
+    first = dict(zip(model.pieces, model.piece_ids))
+    cont = dict(zip(model.cont_pieces, model.cont_ids))
+    out, start = [], 0
+    while start < len(raw):
+        end = len(raw)
+        hit = None
+        while start < end:
+            hit = (first if start == 0 else cont).get(raw[start:end])
+            if hit is not None:
+                break
+            end -= 1
+        if hit is None:
+            return unk()
+        out.append(hit)
+        start = end
+    return out
+
+
 def tokenize(model: RetokModel, raw: bytes) -> List[int]:
+    if model.kind == WORDPIECE:
+        return wordpiece_tokenize(model, raw)
     return bpe_tokenize(model, raw) if model.kind == BPE else unigram_tokenize(model, raw)
 
 
@@ -332,6 +390,8 @@ def _load_c():
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.retok_ref_free.argtypes = [C.c_void_p]
+        lib.retok_ref_set_wordpiece.restype = None
+        lib.retok_ref_set_wordpiece.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.retok_ref_surface_forms.restype = C.c_int
         lib.retok_ref_surface_forms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                                 C.c_void_p, C.POINTER(C.c_int64)]
@@ -378,6 +438,10 @@ def surface_form_matrix_c(model: RetokModel, tokens: Sequence[str], maxlen: int,
                           a["byte_fallback"], _ptr(a["byte_fallback_ids"]), a["ignore_merges"], a["min_score"],
                           a["n_special"], _ptr(a["special_bytes"]), _ptr(a["special_offsets"]), _ptr(a["special_ids"]))
     try:
+        if model.kind == WORDPIECE:
+            cb, co = _blob(model.cont_pieces)
+            ci = np.asarray(model.cont_ids, dtype=np.int32).reshape(-1)
+            lib.retok_ref_set_wordpiece(h, len(model.cont_pieces), _ptr(cb), _ptr(co), _ptr(ci), int(model.max_chars))
         out = np.full((len(tokens) + padding, maxlen), pad_id, dtype=np.int32)
         ntr = C.c_int64(0)
         rc = lib.retok_ref_surface_forms(h, _ptr(data), _ptr(offs), len(tokens), maxlen, pad_id, _ptr(out), C.byref(ntr))

@@ -97,6 +97,19 @@ def train_mistral_like(lines, vocab_size):
     return tok
 
 
+def train_bert_wordpiece(lines, vocab_size):
+    """WordPiece + BertNormalizer + BertPreTokenizer + "##" continuing prefix (BERT style)."""
+    from tokenizers import Tokenizer, decoders, models, normalizers, pre_tokenizers, trainers
+    tok = Tokenizer(models.WordPiece(unk_token="[UNK]"))
+    tok.normalizer = normalizers.BertNormalizer(lowercase=False)
+    tok.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tok.decoder = decoders.WordPiece(prefix="##")
+    trainer = trainers.WordPieceTrainer(vocab_size=vocab_size, special_tokens=["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"],
+                                        continuing_subword_prefix="##", show_progress=False)
+    tok.train_from_iterator(lines, trainer)
+    return tok
+
+
 def wrap(tok, **special):
     from transformers import PreTrainedTokenizerFast
     return PreTrainedTokenizerFast(tokenizer_object=tok, **special)
@@ -173,5 +186,26 @@ def gen_retok():
     dump_case("retok_mistral_like", mis, toks_m, 7, gsfm)
 
 
+def gen_wordpiece():
+    """(5) WordPiece hn tokenizer (zett/utils.py:681 is model-agnostic; zett/tokenizer_converters.py:370-373 carries WordPiece
+    through convert_to_byte_level, which empties the continuing prefix): BERT-style tokenizer converted by the reference,
+    matrix computed by the reference's get_surface_form_matrix.  Separate entry point: the fixtures of gen_retok() stay as
+    they were generated."""
+    convert_to_byte_level, gsfm, c2b, b2c = _import_reference()
+    lines_a, lines_b = corpus(1), corpus(2)
+    kw = dict(unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]", mask_token="[MASK]")
+    wp_src = wrap(train_bert_wordpiece(lines_a, 2000), **kw)
+    wp = convert_to_byte_level(wrap(train_bert_wordpiece(lines_a, 2000), **kw))[0]
+    tgt = wrap(train_bytelevel_bpe(lines_b, 2500, ["<|endoftext|>"]), eos_token="<|endoftext|>")
+    tgt = convert_to_byte_level(tgt, make_whitespace_consistent=True, match_special_tokens_to=wp_src)[0]
+    toks = tgt.convert_ids_to_tokens(range(len(tgt)))
+    extra = ["", "Ġ", "ĠĠĠĠĠĠĠĠĠĠĠĠĠĠĠĠĠĠĠĠ", "a" * 40, "b" * 101, "Ġ" + "c" * 100, "ĊĊĊ", "Ġthe", "ÿÿ", "ĠĠhelloĠworldĠĠ", "Ġimport", "ĠimportĠos"]
+    dump_case("retok_wordpiece", wp, toks + extra, 7, gsfm)
+    dump_case("retok_wordpiece_L15", wp, (toks + extra)[-700:], 15, gsfm)
+
+
 if __name__ == "__main__":
-    gen_retok()
+    if len(sys.argv) > 1 and sys.argv[1] == "wordpiece":
+        gen_wordpiece()
+    else:
+        gen_retok()

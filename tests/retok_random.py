@@ -1,4 +1,4 @@
-"""Random hn-tokenizer models for the retokenizer tests (BPE / Unigram in tokenizers.json form)."""
+"""Random hn-tokenizer models for the retokenizer tests (BPE / Unigram / WordPiece in tokenizers.json form)."""
 import random
 
 from oracle.retok_ref import BYTES_TO_CHARS
@@ -59,6 +59,26 @@ def random_unigram(rng: random.Random, n_pieces=60):
     return model
 
 
+def random_wordpiece(rng: random.Random, n_pieces=70):
+    """WordPiece in tokenizers.json form: a random continuing prefix ("" as convert_to_byte_level leaves it, "##" as BERT
+    ships it, or a prefix that is itself made of alphabet characters), some pieces with it, sometimes no [UNK] in the
+    vocabulary, a small max_input_chars_per_word now and then."""
+    prefix = rng.choice(["", "", "##", "a", "ab"])
+    vocab = {}
+    if rng.random() < 0.8:
+        vocab["[UNK]"] = 0
+    for b in ALPHABET:
+        if rng.random() < 0.7:
+            vocab.setdefault(chars(bytes([b])), len(vocab))
+        if rng.random() < 0.6:
+            vocab.setdefault(prefix + chars(bytes([b])), len(vocab))
+    for _ in range(n_pieces):
+        piece = bytes(rng.choice(ALPHABET) for _ in range(rng.randint(2, 5)))
+        vocab.setdefault((prefix if rng.random() < 0.5 else "") + chars(piece), len(vocab))
+    return {"type": "WordPiece", "unk_token": "[UNK]", "continuing_subword_prefix": prefix,
+            "max_input_chars_per_word": rng.choice([100, 100, 100, 6, 9]), "vocab": vocab}
+
+
 def random_tokens(rng: random.Random, n=200, maxlen=12):
     out = []
     for _ in range(n):
@@ -75,4 +95,7 @@ def build_tokenizers_model(model: dict):
         kw = dict(unk_token=model["unk_token"], fuse_unk=model["fuse_unk"], byte_fallback=model["byte_fallback"],
                   ignore_merges=model["ignore_merges"])
         return models.BPE(dict(model["vocab"]), [tuple(m) for m in model["merges"]], **kw)
+    if model["type"] == "WordPiece":
+        return models.WordPiece(dict(model["vocab"]), unk_token=model["unk_token"], max_input_chars_per_word=model["max_input_chars_per_word"],
+                                continuing_subword_prefix=model["continuing_subword_prefix"])
     return models.Unigram([tuple(v) for v in model["vocab"]], unk_id=model["unk_id"], byte_fallback=model["byte_fallback"])

@@ -472,3 +472,75 @@ def test_f16_training_overflow_is_an_error_not_a_nan():
         else:
             loss.backward()
             assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+
+
+def test_inference_after_an_optimizer_step_uses_the_new_weights():
+    """train.py's eval_step pattern: train a step, then predict under no_grad / eval().  The inference engine holds a copy of
+    the weights; it must notice the in-place update (parameter version counters) without refresh_weights()."""
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg, w, src_np, ids_np = _case({}, seed=43, rows=48)
+    model = ZettHypernet(ZettHypernetConfig(**cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model = model.to(DEV).requires_grad_(True).train()
+    model.precision = "f32"
+    src, ids = torch.from_numpy(src_np).to(DEV), torch.from_numpy(ids_np).to(DEV)
+    lang = torch.tensor(1)
+    with torch.no_grad():
+        before = model(ids, source_embeddings=src, lang_index=lang)
+        again = model(ids, source_embeddings=src, lang_index=lang)
+    assert torch.equal(before[0], again[0])                   # (unchanged weights: the cached engine, same bits)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    out = model(ids, source_embeddings=src, lang_index=lang)
+    (out[0] ** 2).mean().backward()
+    opt.step()
+    with torch.no_grad():
+        after = model(ids, source_embeddings=src, lang_index=lang)
+    fresh = ZettHypernet(ZettHypernetConfig(**cfg))
+    fresh.load_state_dict(model.state_dict())
+    fresh = fresh.to(DEV)
+    fresh.precision = "f32"
+    with torch.no_grad():
+        want = fresh(ids, source_embeddings=src, lang_index=lang)
+    assert not torch.equal(before[0], after[0])
+    for a, b in zip(after, want):
+        assert torch.equal(a, b)
+    # p.data = ... (a new storage, version counter untouched) is seen too
+    with torch.no_grad():
+        p = model.get_parameter("bias_projection.bias") if cfg.get("hn_predict_bias", True) else None
+    if p is not None:
+        p.data = p.data + 1.0
+        with torch.no_grad():
+            shifted = model(ids, source_embeddings=src, lang_index=lang)
+        assert float((shifted[2] - after[2]).mean()) == pytest.approx(1.0, abs=1e-4)
+
+
+def test_training_forward_validates_its_indices_like_the_inference_path():
+    """A bad id / language index / over-long surface form raises IndexError before any kernel reads (or, in the backward,
+    atomically writes) through it — the reference's F.embedding IndexError, the inference path's ZETT_E_INDEX."""
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg, w, src_np, ids_np = _case({}, seed=44, rows=16)
+    model = ZettHypernet(ZettHypernetConfig(**cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model = model.to(DEV).requires_grad_(True).train()
+    src, ids = torch.from_numpy(src_np).to(DEV), torch.from_numpy(ids_np).to(DEV)
+    top = model.dims.original_vocab_size + model.dims.n_extra
+    for packed in (True, False):
+        model.train_packed = packed
+        bad = ids.clone(); bad[3, 1] = top
+        with pytest.raises(IndexError, match="outside"):
+            model(bad, source_embeddings=src, lang_index=torch.tensor(1))
+        bad = ids.clone(); bad[0, 0] = -1
+        with pytest.raises(IndexError):
+            model(bad, source_embeddings=src, lang_index=torch.tensor(1))
+        with pytest.raises(IndexError, match="lang_index"):
+            model(ids, source_embeddings=src, lang_index=torch.tensor(model.dims.n_langs))
+        with pytest.raises(IndexError, match="rows"):
+            model(ids, source_embeddings=src[: model.dims.original_vocab_size - 1], lang_index=torch.tensor(1))
+        long = torch.full((2, model.dims.max_positions), 5, dtype=ids.dtype, device=DEV)
+        with pytest.raises(IndexError, match="position_embeddings"):
+            model(long, source_embeddings=src, lang_index=torch.tensor(1))
+    ok = ids.clone(); ok[3, 1] = top - 1                          # the last fallback row is a valid id
+    out = model(ok, source_embeddings=src, lang_index=torch.tensor(1))
+    assert bool(torch.isfinite(out[0]).all())

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.zett_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.zett_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_cli_dtype_selects_one_precision_policy():
@@ -52,6 +52,10 @@ def test_struct_layouts_match_header():
     # zett_retok_model: int,int,4 ptr,double,int,ptr,3 int,ptr,int,int,3 ptr  (natural alignment)
     assert _lib.ZettRetokModel.piece_scores.offset == 32
     assert _lib.ZettRetokModel.unigram_min_score.offset == 40
+    # ABI 4: the WordPiece fields at the end (pointer, int32; the struct is padded to 8)
+    assert _lib.ZettRetokModel.piece_continuing.offset == _lib.ZettRetokModel.special_ids.offset + 8
+    assert _lib.ZettRetokModel.max_input_chars_per_word.offset == _lib.ZettRetokModel.piece_continuing.offset + 8
+    assert ctypes.sizeof(_lib.ZettRetokModel) == _lib.ZettRetokModel.max_input_chars_per_word.offset + 8
 
 
 def test_no_cpu_fallback():
@@ -344,6 +348,10 @@ ok = ok and all(torch.equal(a, b) for a, b in zip(got, want))
 pri = -np.abs(np.random.default_rng(3).standard_normal(1003))
 got = predict_vocabulary(Fake(), sfm, None, None, Args(output="", batch_size=128, sample_batches=True, n_samples=40, min_k=5), target_priors=pri)
 ok = ok and all(torch.allclose(a, b, rtol=1e-6, atol=0) for a, b in zip(got, want))
+# the range word of the sharded run is OR-ed over the ranks bit by bit (RCCL has no BOR, MAX of the words loses bits)
+from zett_amd.transfer import reduce_flag_word
+ok = ok and reduce_flag_word(1 if rank == 0 else 2, "cpu") == 3 and reduce_flag_word(0, "cpu") == 0
+ok = ok and reduce_flag_word(8 if rank == 1 else 0, "cpu") == 8 and reduce_flag_word(5, "cpu") == 5
 flag = torch.tensor([1 if ok else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 rows = torch.tensor([per_rank_rows]); dist.all_reduce(rows)
 if rank == 0:

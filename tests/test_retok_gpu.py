@@ -86,6 +86,62 @@ def test_random_models_match_oracle(seed):
         assert got_tr == want_tr
 
 
+@pytest.mark.parametrize("seed", range(20))
+def test_random_wordpiece_models_match_oracle(seed):
+    """WordPiece hn tokenizers (zett/utils.py:681 is model-agnostic, zett/tokenizer_converters.py:370-373): random models with
+    the prefixes "", "##", "a", "ab", small max_input_chars_per_word, [UNK] present or not (then only words that do not
+    need it), against the C oracle (itself equal to the tokenizers wheel: tests/test_retok_oracle.py)."""
+    from zett_amd.surface_forms import HnTokenizerSpec, get_surface_form_matrix
+    rng = random.Random(3000 + seed)
+    model_json = rr.random_wordpiece(rng, 90)
+    has_unk = "[UNK]" in model_json["vocab"]
+    specials, special_ids = (["[UNK]"], [model_json["vocab"]["[UNK]"]]) if has_unk else ([], [])
+    tokens = rr.random_tokens(rng, 400, maxlen=14) + rr.random_tokens(rng, 20, maxlen=120) + specials
+    oracle_model = retok_ref.model_from_tokenizer_json(model_json, specials, special_ids)
+    if not has_unk:        # keep the words the library can tokenize; one that needs [UNK] must fail the call
+        bad = []
+        for t in tokens:
+            try:
+                retok_ref.tokenize(oracle_model, retok_ref.token_to_bytes(t))
+            except RuntimeError:
+                bad.append(t)
+        tokens = [t for t in tokens if t not in set(bad)]
+        spec = HnTokenizerSpec.from_model_json(model_json, specials, special_ids, 77)
+        if bad:
+            with pytest.raises(Exception, match="UNK"):
+                get_surface_form_matrix(tokens + bad[:1], 9, spec)
+    want, want_tr = retok_ref.surface_form_matrix_c(oracle_model, tokens, 9, 77)
+    spec = HnTokenizerSpec.from_model_json(model_json, specials, special_ids, 77)
+    got, got_tr = get_surface_form_matrix(tokens, 9, spec)
+    np.testing.assert_array_equal(got, want)
+    assert got_tr == want_tr
+
+
+def test_wordpiece_tokenizer_object_entry_point():
+    """The transformers-tokenizer entry point with a WordPiece model, "##" prefix kept (not converted): the library's own
+    Model.tokenize is the expectation, token by token."""
+    from tokenizers import Tokenizer
+    from transformers import PreTrainedTokenizerFast
+
+    from zett_amd.surface_forms import get_surface_form_matrix
+    vocab = {"[PAD]": 0, "[UNK]": 1, "a": 2, "b": 3, "ab": 4, "##a": 5, "##b": 6, "##ab": 7, "##": 8, "#": 9, "abab": 10, "c": 11}
+    tok = Tokenizer.from_str(json.dumps({"version": "1.0", "truncation": None, "padding": None, "added_tokens": [], "normalizer": None,
+                                         "pre_tokenizer": None, "post_processor": None, "decoder": None,
+                                         "model": {"type": "WordPiece", "unk_token": "[UNK]", "continuing_subword_prefix": "##",
+                                                   "max_input_chars_per_word": 8, "vocab": vocab}}))
+    hf = PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="[UNK]", pad_token="[PAD]")
+    tokens = ["ab", "aab", "abab", "ababab", "ba", "##", "##a", "a#", "cab", "abc", "ababababa", "abababab", "", "[UNK]", "[PAD]", "bbbb"]
+    want = np.zeros((len(tokens), 5), dtype=np.int32)
+    for r, t in enumerate(tokens):
+        if t in ("[UNK]", "[PAD]"):
+            want[r, 0] = vocab[t]
+            continue
+        ids = [x.id for x in tok.model.tokenize(t)][:5]
+        want[r, :len(ids)] = ids
+    got, _ = get_surface_form_matrix(tokens, 5, hf)
+    np.testing.assert_array_equal(got, want)
+
+
 def test_unigram_without_unk_raises():
     from zett_amd.surface_forms import HnTokenizerSpec, get_surface_form_matrix
     model = {"type": "Unigram", "unk_id": None, "byte_fallback": False, "vocab": [["a", -1.0], ["b", -1.0]]}

@@ -27,6 +27,33 @@ def test_oracle_equals_tokenizers_library(seed):
             assert list(row[:len(w)]) == w[:16] and all(x == -7 for x in row[len(w):])
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_wordpiece_oracle_equals_tokenizers_library(seed):
+    """WordPiece (zett/utils.py:681 is model-agnostic; zett/tokenizer_converters.py:370-373 carries WordPiece through):
+    greedy longest match, continuing prefix, the whole word [UNK] on a miss, an error when [UNK] is not in the vocabulary."""
+    rng = random.Random(1000 + seed)
+    model_json = rr.random_wordpiece(rng)
+    lib_model = rr.build_tokenizers_model(model_json)
+    model = retok_ref.model_from_tokenizer_json(model_json)
+    tokens = rr.random_tokens(rng, 120)
+    want, ok_tokens = [], []
+    for tok in tokens:
+        try:
+            want.append([t.id for t in lib_model.tokenize(tok)])
+            ok_tokens.append(tok)
+        except Exception:                       # "[UNK] missing": the oracle must fail on the same word
+            with pytest.raises(RuntimeError):
+                retok_ref.tokenize(model, retok_ref.token_to_bytes(tok))
+    got_py = [retok_ref.tokenize(model, retok_ref.token_to_bytes(tok)) for tok in ok_tokens]
+    assert got_py == want
+    mat, _ = retok_ref.surface_form_matrix_c(model, ok_tokens, 16, -7)
+    for row, w in zip(mat, want):
+        assert list(row[:len(w)]) == w[:16] and all(x == -7 for x in row[len(w):])
+    if len(ok_tokens) != len(tokens):
+        with pytest.raises(RuntimeError):
+            retok_ref.surface_form_matrix_c(model, tokens, 16, -7)
+
+
 def test_known_answers():
     """Tie-breaks / drops probed on tokenizers 0.22.2."""
     m = retok_ref.model_from_tokenizer_json({"type": "Unigram", "unk_id": 0, "byte_fallback": False, "vocab": [

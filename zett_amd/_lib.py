@@ -16,7 +16,7 @@ E_INVALID, E_HIP, E_STATE, E_INDEX, E_NOT_IMPLEMENTED, E_KEY, E_RANGE = -1, -2, 
 RANGE_SOURCE, RANGE_ACTIVATION, RANGE_OUTPUT, RANGE_WEIGHT = 1, 2, 4, 8      # zett_range_bits
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
-RETOK_BPE, RETOK_UNIGRAM = 0, 1
+RETOK_BPE, RETOK_UNIGRAM, RETOK_WORDPIECE = 0, 1, 2
 OUT_IN, OUT_BIAS = 0, 1              # zett_output
 
 ABI_SYMBOLS = (
@@ -40,7 +40,7 @@ class ZettConfig(C.Structure):
         ("ln_eps_encoder", C.c_float), ("ln_eps_projector", C.c_float)]
 
 
-ABI_VERSION = 3      # ZETT_ABI_VERSION of include/zett_hip.h
+ABI_VERSION = 4      # ZETT_ABI_VERSION of include/zett_hip.h
 
 
 class ZettStats(C.Structure):
@@ -64,6 +64,7 @@ class ZettRetokModel(C.Structure):
         ("byte_fallback_ids", C.c_void_p), ("ignore_merges", C.c_int32),
         ("n_special", C.c_int32), ("special_bytes", C.c_void_p), ("special_offsets", C.c_void_p),
         ("special_ids", C.c_void_p),
+        ("piece_continuing", C.c_void_p), ("max_input_chars_per_word", C.c_int32),
     ]
 
 

@@ -748,6 +748,29 @@ class HypernetFunction(torch.autograd.Function):
         return (None, None, None, None, None, None, None, None, *grads)
 
 
+def _check_indices(dims: HypernetDims, ids: torch.Tensor, src: torch.Tensor, lang: int) -> None:
+    """The index errors of the reference's F.embedding calls (modeling_hypernet.py:179-188, 192-211) and of the inference
+    path (ZETT_E_INDEX), raised BEFORE a kernel reads — and, in the backward, atomically writes — through a bad id.  One
+    min/max reduction over the id matrix and one host read per training step."""
+    if ids.dim() != 2:
+        raise ValueError("target_surface_forms must be [n_tokens, surface_maxlen]")
+    lam = 1 if dims.embed_lang else 0
+    if ids.shape[1] + lam > dims.max_positions:
+        raise IndexError(f"sequence {ids.shape[1]} (+{lam} language token) exceeds position_embeddings ({dims.max_positions} rows)")
+    v0, top = dims.original_vocab_size, dims.original_vocab_size + dims.n_extra
+    if src.dim() != 2 or src.shape[1] != dims.n_in_embd:
+        raise ValueError(f"source_embeddings must be [V, {dims.n_in_embd}], got {tuple(src.shape)}")
+    if src.shape[0] < v0:
+        raise IndexError(f"source_embeddings has {src.shape[0]} rows, config.original_vocab_size is {v0}")
+    if ids.numel():
+        lo, hi = (int(v) for v in torch.stack([ids.min(), ids.max()]).tolist())
+        if lo < 0 or hi >= top:
+            raise IndexError(f"target_surface_forms holds an id outside [0, {top}) (original_vocab_size {v0} + {dims.n_extra} fallback rows): "
+                             f"min {lo}, max {hi}")
+    if dims.embed_lang and not 0 <= lang < dims.n_langs:
+        raise IndexError(f"lang_index {lang} outside [0, {dims.n_langs})")
+
+
 def differentiable_forward(model, target_surface_forms: torch.Tensor, source_embeddings: torch.Tensor, lang_index: int, packed: bool = True,
                            precision: str = "f32"):
     """The forward of `model` (a zett_amd.hypernet.ZettHypernet) with gradients to its parameters.  packed = True (default):
@@ -757,6 +780,7 @@ def differentiable_forward(model, target_surface_forms: torch.Tensor, source_emb
     fp32 accumulation, fp32 parameters, activations and gradients)."""
     # (parameters of the checkpoint contract that the forward never reads stay outside the graph: a gradient hook that waits for
     # every input of the Function — DistributedDataParallel's bucket logic — would wait for them for ever)
+    _check_indices(model.dims, target_surface_forms, source_embeddings, int(lang_index))
     names = [n for n in weight_shapes(model.dims) if n not in NEVER_READ]
     params = dict(model.named_parameters())
     tensors = [params[n] for n in names]

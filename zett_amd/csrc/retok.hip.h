@@ -18,6 +18,10 @@
 //       Unigram  tokenizers `Unigram::tokenize`: Viterbi over an FNV-hashed piece table
 //                (strictly-greater updates, start positions ascending => earliest start
 //                wins ties), unknown runs fused, optional byte fallback;
+//       WordPiece tokenizers `WordPiece::tokenize` (zett/tokenizer_converters.py:370-373 carries
+//                WordPiece hn tokenizers through): greedy longest match from every start,
+//                continuing pieces in their own key space of the same hash table, the whole
+//                word [UNK] on a miss or beyond max_input_chars_per_word;
 //     then truncation to maxlen with the n_truncated count (zett/utils.py:683-685).
 //
 // Results are integers: bit-exact against the oracle and the reference by construction.
@@ -41,7 +45,7 @@ struct PieceEntry {
     int32_t off;
     int32_t len;      // 0 = empty slot
     int32_t id;
-    int32_t pad_;
+    int32_t where;    // WordPiece: 0 = matches at the start of a word, 1 = continuing piece (prefix stripped); else 0
     double score;
 };
 
@@ -57,12 +61,13 @@ struct RetokTables {
     const int32_t* single_id;     // [256] id of the one-byte piece or -1
     const int32_t* bf_ids;        // [256] id of "<0xXX>" or -1
     const int16_t* cp_to_byte;    // [324] code point -> byte or -1
-    int kind, unk_id, fuse_unk, byte_fallback, ignore_merges, max_piece_len;
+    int kind, unk_id, fuse_unk, byte_fallback, ignore_merges, max_piece_len, max_word_chars;
     double unk_score;             // min_score - kUnkPenalty
 };
 
 constexpr uint64_t FNV_OFFSET = 14695981039346656037ull;
 constexpr uint64_t FNV_PRIME = 1099511628211ull;
+constexpr uint64_t FNV_OFFSET_CONT = FNV_OFFSET ^ 0x5bd1e9955bd1e995ull;      // key space of WordPiece continuing pieces
 
 __host__ __device__ inline uint64_t fnv_step(uint64_t h, uint8_t b) { return (h ^ b) * FNV_PRIME; }
 __host__ __device__ inline uint32_t piece_slot(uint64_t h, uint32_t mask) { return (uint32_t)(h ^ (h >> 32)) & mask; }
@@ -77,6 +82,22 @@ __device__ inline const PieceEntry* piece_find(const PieceEntry* tab, uint32_t m
         const PieceEntry* e = tab + slot;
         if (e->len == 0) return nullptr;
         if (e->hash == h && e->len == len) {
+            const uint8_t* p = blob + e->off;
+            int i = 0;
+            while (i < len && p[i] == s[i]) ++i;
+            if (i == len) return e;
+        }
+    }
+}
+
+// WordPiece: the same table holds word-initial pieces (where 0, hashed from FNV_OFFSET) and continuing pieces (where 1,
+// hashed from FNV_OFFSET_CONT): `where` is part of the key
+__device__ inline const PieceEntry* piece_find_where(const PieceEntry* tab, uint32_t mask, const uint8_t* blob, uint64_t h,
+                                                     const uint8_t* s, int len, int where) {
+    for (uint32_t slot = piece_slot(h, mask);; slot = (slot + 1) & mask) {
+        const PieceEntry* e = tab + slot;
+        if (e->len == 0) return nullptr;
+        if (e->hash == h && e->len == len && e->where == where) {
             const uint8_t* p = blob + e->off;
             int i = 0;
             while (i < len && p[i] == s[i]) ++i;
@@ -345,9 +366,42 @@ __device__ bool unigram_token(const RetokTables& t, const RetokLds& L, const uin
     return true;
 }
 
+// tokenizers `WordPiece::tokenize`.  Returns false on "the word is [UNK] but [UNK] is not in the vocabulary".  From each
+// start the library tries the longest substring first and shortens it a character at a time; walking the ends upwards
+// with a running hash and keeping the LAST hit finds the same piece.  One byte-level character is one raw byte.
+__device__ bool wordpiece_token(const RetokTables& t, const uint8_t* raw, int len, RowWriter& w, int32_t pad_id) {
+    if (len > t.max_word_chars) {
+        if (t.unk_id < 0) return false;
+        w.push(t.unk_id);
+        return true;
+    }
+    const int n0 = w.n;
+    for (int s = 0; s < len;) {
+        const int where = s == 0 ? 0 : 1;
+        uint64_t h = where ? FNV_OFFSET_CONT : FNV_OFFSET;
+        const int emax = (s + t.max_piece_len < len) ? s + t.max_piece_len : len;
+        int best_e = -1, best_id = -1;
+        for (int e = s + 1; e <= emax; ++e) {
+            h = fnv_step(h, raw[e - 1]);
+            const PieceEntry* p = piece_find_where(t.pieces, t.piece_mask, t.piece_blob, h, raw + s, e - s, where);
+            if (p) { best_e = e; best_id = p->id; }
+        }
+        if (best_e < 0) {                                   // is_bad: the pieces found so far are dropped, the word is [UNK]
+            if (t.unk_id < 0) return false;
+            for (int i = n0; i < w.n && i < w.maxlen; ++i) w.row[i] = pad_id;
+            w.n = n0;
+            w.push(t.unk_id);
+            return true;
+        }
+        w.push(best_id);
+        s = best_e;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const uint8_t* __restrict__ raw,
                                                           const int32_t* __restrict__ raw_off, int64_t n_tokens,
-                                                          int maxlen, int32_t* __restrict__ out, int32_t* __restrict__ scratch,
+                                                          int maxlen, int32_t pad_id, int32_t* __restrict__ out, int32_t* __restrict__ scratch,
                                                           unsigned long long* __restrict__ n_truncated,
                                                           int32_t* __restrict__ err_unk) {
     __shared__ RetokLds L;
@@ -366,9 +420,11 @@ __global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const u
     }
     if (len == 0) return;
     int32_t* scr = scratch + ((int64_t)o0 * SCR_PER_BYTE + tok * SCR_FIXED);
-    if (t.kind == ZETT_RETOK_BPE) {
-        bpe_token(t, L, s, len, scr, w);
-    } else if (!unigram_token(t, L, s, len, scr, w)) {
+    bool ok = true;
+    if (t.kind == ZETT_RETOK_BPE) bpe_token(t, L, s, len, scr, w);
+    else if (t.kind == ZETT_RETOK_UNIGRAM) ok = unigram_token(t, L, s, len, scr, w);
+    else ok = wordpiece_token(t, s, len, w, pad_id);
+    if (!ok) {
         atomicMax(err_unk, (int32_t)(tok < 0x7ffffffe ? tok + 1 : 0x7fffffff));
         return;
     }
@@ -404,14 +460,16 @@ struct HostPieceTable {
 };
 
 inline void build_piece_table(const uint8_t* bytes, const int32_t* offsets, const int32_t* ids, const double* scores, int n,
-                              HostPieceTable& out, int32_t* single_id /* nullable */) {
+                              HostPieceTable& out, int32_t* single_id /* nullable */, const uint8_t* where = nullptr /* WordPiece: 1 = continuing piece */) {
     // duplicates: the LAST listed piece wins (tokenizers inserts into a HashMap in listing order)
     std::unordered_map<std::string, int> last;
     last.reserve((size_t)n * 2);
     for (int i = 0; i < n; ++i) {
         const int len = offsets[i + 1] - offsets[i];
         if (len <= 0) continue;
-        last[std::string((const char*)bytes + offsets[i], (size_t)len)] = i;
+        std::string key((const char*)bytes + offsets[i], (size_t)len);
+        if (where) key.push_back(where[i] ? '\1' : '\0');        // the key space is part of the key
+        last[key] = i;
     }
     if (last.empty()) return;
     const uint32_t cap = pow2_capacity(last.size());
@@ -419,16 +477,17 @@ inline void build_piece_table(const uint8_t* bytes, const int32_t* offsets, cons
     out.slots.assign(cap, PieceEntry{0, 0, 0, 0, 0, 0.0});
     for (auto& kv : last) {
         const int i = kv.second;
-        const int len = (int)kv.first.size();
-        uint64_t h = FNV_OFFSET;
+        const int len = (int)kv.first.size() - (where ? 1 : 0);
+        const int wh = where ? (where[i] ? 1 : 0) : 0;
+        uint64_t h = wh ? FNV_OFFSET_CONT : FNV_OFFSET;
         for (int k = 0; k < len; ++k) h = fnv_step(h, (uint8_t)kv.first[k]);
-        PieceEntry e{h, (int32_t)out.blob.size(), len, ids[i], 0, scores ? scores[i] : 0.0};
-        out.blob.insert(out.blob.end(), kv.first.begin(), kv.first.end());
+        PieceEntry e{h, (int32_t)out.blob.size(), len, ids[i], wh, scores ? scores[i] : 0.0};
+        out.blob.insert(out.blob.end(), kv.first.begin(), kv.first.begin() + len);
         uint32_t slot = piece_slot(h, out.mask);
         while (out.slots[slot].len != 0) slot = (slot + 1) & out.mask;
         out.slots[slot] = e;
         if (len > out.max_len) out.max_len = len;
-        if (single_id && len == 1) single_id[(uint8_t)kv.first[0]] = ids[i];
+        if (single_id && len == 1 && !wh) single_id[(uint8_t)kv.first[0]] = ids[i];
     }
 }
 
@@ -451,7 +510,8 @@ extern "C" {
 int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
     using namespace zett;
     if (!m || !out) return fail(ZETT_E_INVALID, "null argument");
-    if (m->kind != ZETT_RETOK_BPE && m->kind != ZETT_RETOK_UNIGRAM) return fail(ZETT_E_NOT_IMPLEMENTED, "hn tokenizer model kind %d", m->kind);
+    if (m->kind != ZETT_RETOK_BPE && m->kind != ZETT_RETOK_UNIGRAM && m->kind != ZETT_RETOK_WORDPIECE) return fail(ZETT_E_NOT_IMPLEMENTED, "hn tokenizer model kind %d", m->kind);
+    if (m->kind == ZETT_RETOK_WORDPIECE && m->max_input_chars_per_word < 0) return fail(ZETT_E_INVALID, "max_input_chars_per_word must be >= 0");
     if (m->n_pieces < 0 || m->n_merges < 0 || m->n_special < 0) return fail(ZETT_E_INVALID, "negative count");
     if (m->n_pieces && (!m->piece_bytes || !m->piece_offsets || !m->piece_ids)) return fail(ZETT_E_INVALID, "piece arrays missing");
     if (m->kind == ZETT_RETOK_UNIGRAM && m->n_pieces && !m->piece_scores) return fail(ZETT_E_INVALID, "Unigram needs piece_scores");
@@ -464,7 +524,8 @@ int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
     std::vector<int32_t> single(256, -1), bf(256, -1);
     if (m->byte_fallback && m->byte_fallback_ids) bf.assign(m->byte_fallback_ids, m->byte_fallback_ids + 256);
     HostPieceTable pt, st;
-    build_piece_table(m->piece_bytes, m->piece_offsets, m->piece_ids, m->piece_scores, m->n_pieces, pt, single.data());
+    build_piece_table(m->piece_bytes, m->piece_offsets, m->piece_ids, m->piece_scores, m->n_pieces, pt, single.data(),
+                      m->kind == ZETT_RETOK_WORDPIECE ? m->piece_continuing : nullptr);
     build_piece_table(m->special_bytes, m->special_offsets, m->special_ids, nullptr, m->n_special, st, nullptr);
     std::vector<MergeEntry> mt;
     uint32_t mmask = 0xffffffffu;
@@ -508,7 +569,7 @@ int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
     if ((rc = upload(r, bf, &di))) { zett_retok_destroy(r); return rc; } t.bf_ids = di;
     if ((rc = upload(r, cp, &dc))) { zett_retok_destroy(r); return rc; } t.cp_to_byte = dc;
     t.kind = m->kind; t.unk_id = m->unk_id; t.fuse_unk = m->fuse_unk; t.byte_fallback = m->byte_fallback;
-    t.ignore_merges = m->ignore_merges; t.max_piece_len = pt.max_len;
+    t.ignore_merges = m->ignore_merges; t.max_piece_len = pt.max_len; t.max_word_chars = m->max_input_chars_per_word;
     t.unk_score = m->unigram_min_score - 10.0;   // tokenizers kUnkPenalty
     HIP_TRY(hipHostMalloc((void**)&r->host_pinned, 64, hipHostMallocDefault));
     *out = r;
@@ -570,7 +631,7 @@ int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* of
     hipLaunchKernelGGL(token_raw_offsets_kernel, dim3((unsigned)((n_tokens + 1 + 255) / 256)), dim3(256), 0, st, offsets, n_tokens,
                        n_text, r->raw_pos.as<uint32_t>(), blk_scan, n_blocks, r->raw_off.as<int32_t>());
     hipLaunchKernelGGL(retok_tokens_kernel, dim3((unsigned)((n_tokens + 63) / 64)), dim3(64), 0, st, r->t, r->raw.as<uint8_t>(),
-                       r->raw_off.as<int32_t>(), n_tokens, maxlen, out, r->scratch.as<int32_t>(), ntr, err_unk);
+                       r->raw_off.as<int32_t>(), n_tokens, maxlen, pad_id, out, r->scratch.as<int32_t>(), ntr, err_unk);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hp, err_pos, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -584,6 +645,8 @@ int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* of
     }
     if (hp[1] != 0) {
         if (bad_token) *bad_token = hp[1] - 1;
+        if (r->t.kind == ZETT_RETOK_WORDPIECE)
+            return fail(ZETT_E_STATE, "WordPiece error: Missing [UNK] token from the vocabulary (token %d)", hp[1] - 1);
         return fail(ZETT_E_STATE, "Encountered an unknown token but `unk_id` is missing (token %d)", hp[1] - 1);
     }
     unsigned long long trunc;

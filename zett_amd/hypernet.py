@@ -89,6 +89,7 @@ class HipEngine:
         index = device.index if device.index is not None else torch.cuda.current_device()
         _lib.check(self.lib.zett_create(C.byref(cfg), index, _PRECISIONS[precision], C.byref(handle)), "zett_create")
         self.handle = handle
+        self.weights_stamp = None
 
     def load_weights(self, tensors: Dict[str, torch.Tensor]) -> None:
         for name, t in tensors.items():
@@ -270,7 +271,8 @@ class ZettHypernet(PreTrainedModel):
         return out
 
     def refresh_weights(self) -> None:
-        """Re-upload parameters after they were modified in place."""
+        """Re-upload parameters now.  Not needed for correctness any more: engine() notices in-place modification through
+        the parameters' version counters and rebuilds; kept for callers that want the upload to happen at a chosen point."""
         self._drop_engines()
 
     def engine(self, device: torch.device, precision: Optional[str] = None) -> HipEngine:
@@ -278,12 +280,24 @@ class ZettHypernet(PreTrainedModel):
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         key = (str(device), precision)
+        # An engine holds the weight copy uploaded when it was built.  Parameters modified in place since then (optimizer.step(),
+        # p.data.copy_(...), p.add_(...): all bump the tensor's version counter; p.data = t replaces the storage) make it stale:
+        # rebuilt here, so that eval / no_grad prediction after a training step never runs on pre-training weights
+        # (train.py's eval_step pattern).  Costs one pass over ~50 Python attributes per forward.
+        stamp = self._weights_stamp()
         eng = self._engines.get(key)
+        if eng is not None and eng.weights_stamp != stamp:
+            eng.close()
+            eng = None
         if eng is None:
             eng = HipEngine(self.dims, self._ln_eps_encoder, device, precision)
             eng.load_weights({n: p.data for n, p in self.named_parameters()})
+            eng.weights_stamp = stamp
             self._engines[key] = eng
         return eng
+
+    def _weights_stamp(self):
+        return tuple((p._version, p.data_ptr()) for p in self.parameters())
 
     # ---- the forward ----------------------------------------------------------------------
     def forward(self, target_surface_forms, target_priors=None, source_embeddings=None, lang_index=None,
@@ -343,9 +357,22 @@ class ZettHypernet(PreTrainedModel):
                 warnings.warn("zett_amd: the f16 forward left the half range (" + ", ".join(where) + "); repeating the call with bf16 "
                               "operands (fp32 exponent range, rel-L2 ~1e-2 instead of ~1e-3 of the fp32 reference). The model stays on bf16.")
             self.precision = "bf16"
+        # bf16 / f32: nothing to fall back to, so the call stays ASYNCHRONOUS (no stream sync, no device-to-host read: the
+        # caller's next batch preparation and index_add overlap the forward, as batched_inference relies on).  A caller that
+        # wants to know whether the outputs are finite asks once, when it chooses: model.check_outputs().
         eng = self.engine(device)
-        out = eng.forward(surface_forms, source_embeddings, lang)
-        if self.range_guard and eng.range_flags() & _lib.RANGE_OUTPUT:
+        self._last_engine = eng
+        return eng.forward(surface_forms, source_embeddings, lang)
+
+    def check_outputs(self) -> int:
+        """Range word of the most recent bf16 / f32 forward (waits for the stream): 0, or _lib.RANGE_* bits; warns when the
+        predicted embeddings are not finite (non-finite weights or source embeddings: the reference would return them too)."""
+        import warnings
+        eng = getattr(self, "_last_engine", None)
+        if eng is None or eng.handle is None:
+            return 0
+        flags = eng.range_flags()
+        if flags & _lib.RANGE_OUTPUT:
             warnings.warn(f"zett_amd: non-finite predicted embeddings in {self.precision} arithmetic (non-finite weights or source embeddings?); "
                           "returned as computed, as the reference would")
-        return out
+        return flags

@@ -74,6 +74,19 @@ def padded_rows(blocks: Sequence[Block], world: int) -> int:
 GATHER_MODES = ("allgather", "fanout")
 
 
+def resolve_gather_mode(mode: str, world: int) -> str:
+    """"auto" -> the transport the budget picks: on xGMI a ring all-gather is bound by ONE of a GPU's seven
+    links (world - 1 steps x shard / 153 GB/s), the direct fan-out uses all of them at once (shard / 153 GB/s).  From four
+    ranks on the ring's exposed tail (~3 ms per output at 8 GPUs on the headline vocabulary, against 0.45 ms) is a third of a
+    shard's compute, so the fan-out is the default there; at two ranks both move one shard over one link and RCCL's
+    all-gather is one call instead of a grouped send/recv pair."""
+    if mode == "auto":
+        return "fanout" if int(world) >= 4 else "allgather"
+    if mode not in GATHER_MODES:
+        raise ValueError(f"gather mode must be one of {GATHER_MODES + ('auto',)}")
+    return mode
+
+
 class RowGather:
     """Asynchronous reassembly of row blocks into full matrices on every rank.
 
@@ -96,13 +109,11 @@ class RowGather:
     exchange is issued on a side stream behind that point instead of behind the whole forward; pred_out follows in stream
     order.  This is what hides half of the exchange when a rank has ONE block (8 GPUs on the headline vocabulary)."""
 
-    def __init__(self, blocks: Sequence[Block], group=None, mode: str = "allgather"):
-        if mode not in GATHER_MODES:
-            raise ValueError(f"gather mode must be one of {GATHER_MODES}")
+    def __init__(self, blocks: Sequence[Block], group=None, mode: str = "auto"):
         self.blocks = list(blocks)
         self.group = group
-        self.mode = mode
         self.world = dist.get_world_size(group)
+        self.mode = resolve_gather_mode(mode, self.world)
         self.rank = dist.get_rank(group)
         self.total = padded_rows(self.blocks, self.world)
         self.full: Optional[List[Optional[torch.Tensor]]] = None
@@ -187,11 +198,11 @@ def all_gather_rows(local: torch.Tensor, n_rows: int, per: int, group=None) -> t
 
 
 def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group=None, chunks: int = 2,
-                    ready: Optional[Callable] = None, mode: str = "allgather"):
+                    ready: Optional[Callable] = None, mode: str = "auto"):
     """Run `predict(rows) -> (pred_in, pred_out | None, bias)` on this rank's rows and return the full result on every
     rank.  The vocabulary is processed in `chunks` row blocks whose exchange overlaps the next block's forward (module
     docstring); chunks = 1 is the plain shard-then-gather.  `ready` (RowGather: early start of pred_in / bias) and `mode`
-    ("allgather" | "fanout") are handed to the RowGather.
+    ("auto" | "allgather" | "fanout": resolve_gather_mode) are handed to the RowGather.
 
     `predict` is typically ``lambda rows: engine.forward(rows, source_embeddings, lang)`` with
     ``ready=engine.stream_wait_output``.  Without an initialised process group this is just ``predict(target_surface_forms)``.

@@ -6,7 +6,7 @@ expresses every (byte-level) target token as at most ``maxlen`` ids of the sourc
 model's ("hn") tokenizer, pad-filled, exactly as the reference does — but the per-token
 Python loop around ``tokenizer_to_use._tokenizer.model.tokenize`` is replaced by two
 HIP kernels behind ``zett_retokenize`` (byte-table gather + scan, then BPE merge /
-Unigram Viterbi per token; zett_amd/csrc/retok.hip.h).  This module only flattens the
+Unigram Viterbi / WordPiece longest match per token; zett_amd/csrc/retok.hip.h).  This module only flattens the
 hn tokenizer's bare model (vocabulary, merges / scores, flags, special tokens) into
 the arrays the C ABI takes.  There is no CPU path.
 """
@@ -76,6 +76,8 @@ class HnTokenizerSpec:
     # '▁' inside '<|begin▁of▁sentence|>'): matched on the host BEFORE the byte lookup, as the reference does
     # (zett/utils.py:671-673 tests `token in all_special_tokens` on the character string)
     host_specials: Tuple[Tuple[str, int], ...] = ()
+    piece_continuing: Optional[np.ndarray] = None      # uint8 per piece, WordPiece only (include/zett_hip.h)
+    max_input_chars_per_word: int = 100
 
     @staticmethod
     def _pack(items: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
@@ -89,8 +91,8 @@ class HnTokenizerSpec:
     def from_model_json(cls, model: dict, special_tokens: Sequence[str], special_ids: Sequence[int],
                         pad_token_id: int) -> "HnTokenizerSpec":
         kind_name = model.get("type") or ("BPE" if "merges" in model else None)
-        if model.get("continuing_subword_prefix") or model.get("end_of_word_suffix"):
-            raise NotImplementedError("hn tokenizers with a continuing_subword_prefix / end_of_word_suffix")
+        if kind_name != "WordPiece" and (model.get("continuing_subword_prefix") or model.get("end_of_word_suffix")):
+            raise NotImplementedError("BPE hn tokenizers with a continuing_subword_prefix / end_of_word_suffix")
         if model.get("dropout"):
             raise NotImplementedError("BPE dropout")
         pieces: List[bytes] = []
@@ -99,7 +101,28 @@ class HnTokenizerSpec:
         merges = np.zeros((0, 3), dtype=np.int32)
         bf_ids = None
         min_score = 0.0
-        if kind_name == "BPE":
+        continuing: Optional[List[int]] = None
+        if kind_name == "WordPiece":
+            # tokenizers WordPiece::tokenize (zett/utils.py:681 calls whatever model the hn tokenizer has;
+            # zett/tokenizer_converters.py:370-373 carries WordPiece through, with the continuing prefix emptied): a lookup at
+            # the start of a word matches an entry as listed, a lookup further in matches prefix + substring — every entry is
+            # listed as it is, and every entry that starts with the prefix once more with the prefix stripped (flag 1)
+            vocab = model["vocab"]
+            prefix = model.get("continuing_subword_prefix") or ""
+            continuing = []
+            for piece, i in vocab.items():
+                raw = _raw(piece)
+                if raw:
+                    pieces.append(raw); ids.append(int(i)); continuing.append(0)
+                if piece.startswith(prefix):
+                    raw = _raw(piece[len(prefix):])
+                    if raw:
+                        pieces.append(raw); ids.append(int(i)); continuing.append(1)
+            unk = model.get("unk_token")
+            unk_id = int(vocab[unk]) if unk in vocab else -1
+            fuse_unk = False
+            kind = _lib.RETOK_WORDPIECE
+        elif kind_name == "BPE":
             vocab: Dict[str, int] = model["vocab"]
             for piece, i in vocab.items():
                 raw = _raw(piece)
@@ -136,8 +159,8 @@ class HnTokenizerSpec:
                 bf_ids = np.asarray([lookup.get("<0x%02X>" % b, -1) for b in range(256)], dtype=np.int32)
             kind = _lib.RETOK_UNIGRAM
         else:
-            raise NotImplementedError(f"hn tokenizer model type {kind_name!r} (the reference's shipped hn "
-                                      "tokenizers are BPE or Unigram)")
+            raise NotImplementedError(f"hn tokenizer model type {kind_name!r} (tokenizers has BPE, Unigram, WordPiece and "
+                                      "WordLevel; convert_to_byte_level itself refuses anything but the first three)")
         sp = [(r, int(i)) for r, i in ((_raw(s), i) for s, i in zip(special_tokens, special_ids)) if r]
         pb, po = cls._pack(pieces)
         sb, so = cls._pack([r for r, _ in sp])
@@ -148,7 +171,9 @@ class HnTokenizerSpec:
                    ignore_merges=bool(model.get("ignore_merges", False)), special_bytes=sb, special_offsets=so,
                    special_ids=np.asarray([i for _, i in sp], dtype=np.int32), pad_token_id=int(pad_token_id),
                    special_tokens=tuple(special_tokens),
-                   host_specials=tuple((s, int(i)) for s, i in zip(special_tokens, special_ids) if not _raw(s)))
+                   host_specials=tuple((s, int(i)) for s, i in zip(special_tokens, special_ids) if not _raw(s)),
+                   piece_continuing=None if continuing is None else np.asarray(continuing, dtype=np.uint8),
+                   max_input_chars_per_word=int(model.get("max_input_chars_per_word", 100)))
 
     @classmethod
     def from_tokenizer(cls, tokenizer) -> "HnTokenizerSpec":
@@ -186,7 +211,8 @@ class DeviceRetokenizer:
             unk_id=spec.unk_id, fuse_unk=int(spec.fuse_unk), byte_fallback=int(spec.byte_fallback),
             byte_fallback_ids=ptr(spec.byte_fallback_ids), ignore_merges=int(spec.ignore_merges),
             n_special=len(spec.special_ids), special_bytes=ptr(spec.special_bytes),
-            special_offsets=ptr(spec.special_offsets), special_ids=ptr(spec.special_ids))
+            special_offsets=ptr(spec.special_offsets), special_ids=ptr(spec.special_ids),
+            piece_continuing=ptr(spec.piece_continuing), max_input_chars_per_word=int(spec.max_input_chars_per_word))
         handle = C.c_void_p()
         index = device.index if device.index is not None else torch.cuda.current_device()
         _lib.check(self.lib.zett_retok_create(C.byref(m), index, C.byref(handle)), "zett_retok_create")

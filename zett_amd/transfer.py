@@ -167,7 +167,14 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
         state = {"rng_state": rng.bit_generator.state}
 
         def run_with(precision):
-            eng = hypernet.engine(device, precision)
+            import torch.distributed as dist
+            from zett_amd import _lib
+            try:
+                eng = hypernet.engine(device, precision)
+            except _lib.RangeError as err:               # zett_finalize: a weight (or gamma-folded weight) does not fit the half type.
+                import warnings                          # Every rank holds the same weights, so every rank lands here together.
+                warnings.warn(f"zett_amd: {err}")
+                return None, _lib.RANGE_WEIGHT
             eng.set_option("range_accumulate", 1)
             eng.range_flags()                           # (clears whatever an earlier call left)
 
@@ -181,11 +188,9 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
                 gen.bit_generator.state = state["rng_state"]        # the same batch order on a repeat
                 out = batched_inference(predict_rows, target_surface_form_matrix, hypernet.config.n_embd, args.batch_size,
                                         args.sample_batches, target_priors, args.min_k, args.n_samples, gen)
-            flags = torch.tensor([eng.range_flags()], dtype=torch.int32, device=device)
-            import torch.distributed as dist
-            dist.all_reduce(flags, op=dist.ReduceOp.BOR if hasattr(dist.ReduceOp, "BOR") else dist.ReduceOp.MAX)
+            flags = reduce_flag_word(eng.range_flags(), device)
             eng.set_option("range_accumulate", 0)
-            return out, int(flags.item())
+            return out, flags
 
         import warnings
         out, flags = run_with(hypernet.precision)
@@ -193,6 +198,8 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
             warnings.warn("zett_amd: the f16 forward left the half range on some rank; repeating the prediction with bf16 operands on every rank")
             hypernet.precision = "bf16"
             out, flags = run_with("bf16")
+        if out is None:          # (a weight outside the half range with the guard off, or the caller forced f16)
+            raise _lib_range_error("a GEMM weight does not fit the f16 operand type and the range guard is off: pass --dtype bfloat16")
         if flags:
             warnings.warn(f"zett_amd: non-finite predicted embeddings in {hypernet.precision} arithmetic; returned as computed")
         return out
@@ -202,6 +209,20 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
     n_embd = hypernet.config.n_embd
     return batched_inference(predict, target_surface_form_matrix, n_embd, args.batch_size, args.sample_batches,
                              target_priors, args.min_k, args.n_samples, rng)
+
+
+def _lib_range_error(msg: str):
+    from zett_amd import _lib
+    return _lib.RangeError(msg)
+
+
+def reduce_flag_word(word: int, device, group=None, bits: int = 8) -> int:
+    """Bitwise OR of a small flag word over the ranks.  RCCL has no BOR ("Cannot use ReduceOp.BOR with NCCL"), and MAX of the
+    words would lose bits (max(1, 2) = 2): one int32 per bit, reduced with MAX — works on nccl and gloo alike."""
+    import torch.distributed as dist
+    vec = torch.tensor([(int(word) >> b) & 1 for b in range(bits)], dtype=torch.int32, device=device)
+    dist.all_reduce(vec, op=dist.ReduceOp.MAX, group=group)
+    return sum(int(v) << b for b, v in enumerate(vec.tolist()))
 
 
 def _world_size() -> int:
