@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B only: the encoder's LayerNorms as launches instead of folded into the GEMMs around them (zett_set_option ln_fold 0)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 PMC passes that measure roofline.traffic after the timed region (N = 1, default workload sizes); "
                     "the figure then comes from profiles/pmc_traffic.json if that still matches the HIP sources, else null")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="A/B only: any zett_set_option key (repeatable), applied last")
     ap.add_argument("--no-retokenize", action="store_true", help="A/B only: start every step from the id matrix instead of the surface forms")
     ap.add_argument("--chunks", type=int, default=2, help="N > 1: row blocks per step (zett_amd/sharding.py: the all-gather of a block overlaps the next block's forward)")
     ap.add_argument("--serial-allgather", action="store_true", help="N > 1: one block per step, i.e. forward, then all-gather (A/B)")
@@ -256,6 +257,9 @@ def main():
         engine.set_option("ln_fold", 0)
     elif args.ln_fold != 1:
         engine.set_option("ln_fold", args.ln_fold)
+    for kv in args.option:
+        key, _, val = kv.partition("=")
+        engine.set_option(key, int(val))
     # the same weights in the OTHER 16-bit arithmetic, for the side measurement after the timed region (N = 1 only)
     alt_precision = {"f16": "bf16", "bf16": "f16"}.get(args.precision) if (world == 1 and not exchange and not args.no_alt_precision) else None
     alt_engine = None
@@ -267,6 +271,9 @@ def main():
             alt_engine.set_option("pair_dedupe", 0)
         if args.no_ln_fold:
             alt_engine.set_option("ln_fold", 0)
+        for kv in args.option:
+            key, _, val = kv.partition("=")
+            alt_engine.set_option(key, int(val))
     if rank != 0 or args.no_cpu_baseline or world > 1:
         weights_keep = None
     else:
@@ -283,18 +290,21 @@ def main():
     assert all(b.hi > b.lo for b in blocks), "fewer rows than ranks"
     ids_blocks = [torch.from_numpy(ids_all[b.lo:b.hi]).to(device) for b in blocks]
     # The step starts from SURFACE FORMS: the byte-level strings of this rank's target tokens and the tables of a
-    # synthetic hn tokenizer (Unigram, one 3-byte piece per source id) are resident on the device; every step
-    # retokenizes them on the GPU (zett_retokenize: byte table, Viterbi) into the [rows, L] id matrix the forward
-    # consumes.  The strings are built so that this matrix is exactly the workload's (checked below, untimed).
+    # synthetic hn tokenizer of the SOURCE model's kind (synth.HN_MODEL_KIND: BPE with byte fallback and ~31.9 k merges for
+    # Mistral / TinyLlama, BPE with ignore_merges and 128 k merges for Llama-3, Unigram for XLM-R) are resident on the
+    # device; every step retokenizes them on the GPU (zett_retokenize: byte table, then merge queue / Viterbi) into the
+    # [rows, L] id matrix the forward consumes.  The strings are built so that this matrix is exactly the workload's
+    # (checked below, untimed).
     retok = None
     texts = []
     seq_len = int(ids_all.shape[1])
     if not args.no_retokenize:
         from zett_amd.surface_forms import DeviceRetokenizer, HnTokenizerSpec
-        spec = HnTokenizerSpec.from_model_json(synth.make_hn_unigram_model(cfg), ["<unk>", "<s>", "</s>"], [0, 1, 2], dims.pad_token_id)
+        hn_model, piece_of_id = synth.make_hn_model(args.workload, cfg)
+        spec = HnTokenizerSpec.from_model_json(hn_model, ["<unk>", "<s>", "</s>"], [0, 1, 2], dims.pad_token_id)
         retok = DeviceRetokenizer(spec, device)
         for b, ids_b in zip(blocks, ids_blocks):
-            d_text, d_off, n_tok = retok.encode(synth.tokens_for_surface_forms(cfg, ids_all[b.lo:b.hi]))
+            d_text, d_off, n_tok = retok.encode(synth.tokens_for_surface_forms(cfg, ids_all[b.lo:b.hi], piece_of_id))
             sfm0, n_trunc0 = retok.run(d_text, d_off, n_tok, seq_len)
             if n_trunc0 != 0 or not torch.equal(sfm0, ids_b):
                 raise SystemExit("the retokenized surface forms differ from the workload's id matrix")
@@ -420,6 +430,9 @@ def main():
                    "precision": f"{args.precision} MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision != "f32" else "fp32 MFMA",
                    "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"],
                    "distinct_id_position_pairs_rank0": st["distinct_positions"],
+                   "hn_tokenizer": (None if retok is None else
+                                    f"synthetic {hn_model['type']}" + (f", {len(hn_model['merges'])} merges" if hn_model["type"] == "BPE" else f", {len(hn_model['vocab'])} pieces")
+                                    + (", byte fallback" if hn_model.get("byte_fallback") else "") + (", ignore_merges" if hn_model.get("ignore_merges") else "")),
                    "step": ("surface forms (byte strings resident on the device) -> GPU retokenization -> hypernet forward" if retok is not None
                             else "id matrix -> hypernet forward [A/B: --no-retokenize]") + ("" if world == 1 else " -> all-gather")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -195,7 +195,8 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
 /* Options: "max_chunk_tokens" (packed positions per encoder chunk, >= 1024; default: 12 GiB of per-position
  * workspace, at least 131072 positions: 131072 at H = 4096, ~640 k at H = 768), "time_gemm" (0/1: bracket every
  * GEMM launch with HIP events on the launch stream and report the sum in
- * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "pair_dedupe" (0/1, default 1: layer 0's
+ * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "attention_fast" (0/1, default 1, A/B only: rows of at most 8 packed positions
+ * take the attention kernel's register-resident path), "pair_dedupe" (0/1, default 1: layer 0's
  * Q/K/V once per distinct (source id, position) pair; same bits either way), "ln_fold" (0/1/2, default 1: in the 16-bit
  * modes the LayerNorms inside the encoder AND the ProjectorBlock LayerNorm in front of each output head's final Linear are
  * folded into the GEMMs around them instead of launched; 2 = the encoder's only (A/B); same values to the rounding of the

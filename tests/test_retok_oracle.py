@@ -72,19 +72,42 @@ def test_known_answers():
     assert retok_ref.tokenize(noign, b"abc") == [4, 2]
 
 
-@pytest.mark.parametrize("name", ["tiny", "mistral_gpt2_32k", "xlmr_gpt2"])
+@pytest.mark.parametrize("name", ["tiny", "mistral_gpt2_32k", "xlmr_gpt2", "tinyllama_neox", "llama3_256k"])
 def test_bench_surface_forms_retokenize_to_the_workload_ids(name):
-    """bench.py starts every step from byte strings: the synthetic hn tokenizer and the target-token strings of
-    zett_amd.synth must retokenize (oracle: the tokenizers-library algorithm) to exactly the id matrix the
-    forward is benchmarked on, with nothing truncated."""
+    """bench.py starts every step from byte strings: the synthetic hn tokenizer of the workload (Unigram for XLM-R, BPE with
+    byte fallback and ~31.9 k merges for Mistral / TinyLlama, BPE with ignore_merges and 128 k merges for Llama-3:
+    zett_amd.synth.HN_MODEL_KIND) and the target-token strings must retokenize (oracle: the tokenizers-library algorithm) to
+    exactly the id matrix the forward is benchmarked on, with nothing truncated."""
     from zett_amd import synth
     cfg, _, _, hist = synth.workload(name)
     ids = synth.make_surface_forms(cfg, 3000, seed=0, hist=hist)
-    model = synth.make_hn_unigram_model(cfg)
-    tokens = synth.tokens_for_surface_forms(cfg, ids)
+    model, piece_of_id = synth.make_hn_model(name, cfg)
+    tokens = synth.tokens_for_surface_forms(cfg, ids, piece_of_id)
     om = retok_ref.model_from_tokenizer_json({"model": model}, ["<unk>", "<s>", "</s>"], [0, 1, 2])
     got, n_trunc = retok_ref.surface_form_matrix_c(om, tokens, ids.shape[1], cfg["pad_token_id"])
     assert n_trunc == 0 and (got == ids).all()
+    if model["type"] == "BPE":
+        assert len(model["merges"]) >= 31900
+        if model["byte_fallback"]:                         # the byte-fallback branch is on the benchmarked path
+            fb = {model["vocab"]["<0x%02X>" % ord(c)] for c in "_#|{}[]"}
+            assert any(int(i) in fb for i in ids.ravel())
+
+
+def test_synthetic_bpe_hn_model_against_the_tokenizers_wheel():
+    """The benchmark's BPE hn model, tokenized by the library the reference calls (zett/utils.py:681), yields the workload's
+    ids: the oracle is not the only witness of the construction."""
+    import tokenizers
+
+    from zett_amd import synth
+    for name in ("mistral_gpt2_32k", "llama3_256k"):
+        cfg, _, _, hist = synth.workload(name)
+        ids = synth.make_surface_forms(cfg, 400, seed=3, hist=hist)
+        model, piece_of_id = synth.make_hn_model(name, cfg)
+        tokens = synth.tokens_for_surface_forms(cfg, ids, piece_of_id)
+        bpe = tokenizers.models.BPE(vocab=model["vocab"], merges=[tuple(m) for m in model["merges"]], unk_token="<unk>",
+                                    fuse_unk=model["fuse_unk"], byte_fallback=model["byte_fallback"], ignore_merges=model["ignore_merges"])
+        for row, tok in zip(ids, tokens):
+            assert [t.id for t in bpe.tokenize(tok)] == [int(i) for i in row if i != cfg["pad_token_id"]]
 
 
 def test_byt5_branch_is_a_byte_bpe_without_merges():

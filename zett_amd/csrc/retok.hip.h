@@ -76,8 +76,9 @@ __host__ __device__ inline uint32_t merge_slot(int32_t a, int32_t b, uint32_t ma
     return (uint32_t)(k >> 32) & mask;
 }
 
-__device__ inline const PieceEntry* piece_find(const PieceEntry* tab, uint32_t mask, const uint8_t* blob, uint64_t h,
-                                               const uint8_t* s, int len) {
+// BP: pointer to the token's bytes — global memory, or the wave's staged text in LDS (stage 2 below)
+template <typename BP>
+__device__ inline const PieceEntry* piece_find(const PieceEntry* tab, uint32_t mask, const uint8_t* blob, uint64_t h, BP s, int len) {
     for (uint32_t slot = piece_slot(h, mask);; slot = (slot + 1) & mask) {
         const PieceEntry* e = tab + slot;
         if (e->len == 0) return nullptr;
@@ -92,8 +93,8 @@ __device__ inline const PieceEntry* piece_find(const PieceEntry* tab, uint32_t m
 
 // WordPiece: the same table holds word-initial pieces (where 0, hashed from FNV_OFFSET) and continuing pieces (where 1,
 // hashed from FNV_OFFSET_CONT): `where` is part of the key
-__device__ inline const PieceEntry* piece_find_where(const PieceEntry* tab, uint32_t mask, const uint8_t* blob, uint64_t h,
-                                                     const uint8_t* s, int len, int where) {
+template <typename BP>
+__device__ inline const PieceEntry* piece_find_where(const PieceEntry* tab, uint32_t mask, const uint8_t* blob, uint64_t h, BP s, int len, int where) {
     for (uint32_t slot = piece_slot(h, mask);; slot = (slot + 1) & mask) {
         const PieceEntry* e = tab + slot;
         if (e->len == 0) return nullptr;
@@ -207,12 +208,27 @@ __global__ void fill_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------
-// stage 2: one lane per token
+// stage 2: a wave per 64 tokens, one lane per token; the tokens' bytes and their working state live in LDS
 // ---------------------------------------------------------------------------------------
+// The 64 tokens of a wave are one contiguous range of `raw`: the wave stages it in LDS with coalesced 16-byte loads.
+// Every lane then sizes the working state of its token (BPE: symbol list, links and merge queue; Unigram: the Viterbi
+// lattice), a wavefront scan over the 64 sizes carves one LDS arena into per-token regions, and the segmentation runs
+// on LDS state — the hash tables of the model (2-4 MB: pieces, merges) are probed through L2.  A token whose bytes or
+// state do not fit (a wave with > 4 KiB of text, a lane beyond the 24 KiB arena) takes the same code on global memory:
+// its region of the `scratch` buffer, sized for the worst case by the host.
 struct RetokLds {
     int32_t single_id[256];
     int32_t bf_ids[256];
 };
+
+constexpr int RT_TEXT_BYTES = 4096;        // staged text per wave
+constexpr int RT_ARENA_WORDS = 6144;       // 24 KiB of per-token state per wave
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) int32_t lds_i32;
+typedef __attribute__((address_space(3))) double lds_f64;
+struct GlobalMem { typedef const uint8_t* bytes; typedef int32_t* words; typedef double* doubles; };
+struct LdsMem { typedef const lds_u8* bytes; typedef lds_i32* words; typedef lds_f64* doubles; };
 
 // UTF-8 bytes of the printable character standing for raw byte b
 __device__ inline int byte_char_utf8(int b, uint8_t out[2]) {
@@ -246,45 +262,51 @@ struct RowWriter {
     __device__ void push(int32_t id) { if (n < maxlen) row[n] = id; ++n; }
 };
 
-// scratch layout per token: region of SCR_PER_BYTE * len + SCR_FIXED int32 words
+// worst-case words of a token's region of the global scratch buffer (the fallback of the LDS arena)
 constexpr int SCR_PER_BYTE = 24;
 constexpr int SCR_FIXED = 16;
 
-__device__ void bpe_token(const RetokTables& t, const RetokLds& L, const uint8_t* raw, int len, int32_t* scr, RowWriter& w) {
-    if (t.ignore_merges) {
-        uint64_t h = FNV_OFFSET;
-        for (int i = 0; i < len; ++i) h = fnv_step(h, raw[i]);
-        const PieceEntry* e = piece_find(t.pieces, t.piece_mask, t.piece_blob, h, raw, len);
-        if (e) { w.push(e->id); return; }
-    }
-    const int cap = 2 * len + 1;
-    int32_t* c = scr;                 // symbol ids, -1 = removed
-    int32_t* prev = c + cap;
-    int32_t* next = prev + cap;
-    int32_t* q = next + cap;          // queue triples (rank, pos, new_id), capacity 3*cap
+// tokenizers `BPE::merge_word`: the symbols the merges start from (byte fallback / unk / drop).  WRITE = false only counts.
+template <bool WRITE, typename M>
+__device__ inline int bpe_symbols(const RetokTables& t, const RetokLds& L, typename M::bytes raw, int len, typename M::words c) {
     int n = 0;
     bool unk_pending = false;
-    for (int i = 0; i < len; ++i) {   // merge_word
+    for (int i = 0; i < len; ++i) {
         const int b = raw[i];
         const int32_t id = L.single_id[b];
         if (id >= 0) {
-            if (unk_pending) { c[n++] = t.unk_id; unk_pending = false; }
-            c[n++] = id;
+            if (unk_pending) { if (WRITE) c[n] = t.unk_id; ++n; unk_pending = false; }
+            if (WRITE) c[n] = id;
+            ++n;
             continue;
         }
         if (t.byte_fallback) {
             int32_t fb[2]; int nfb = 0;
             if (fallback_pair(L, b, fb, &nfb)) {            // a pending unk is not flushed first (library behaviour)
-                for (int k = 0; k < nfb; ++k) c[n++] = fb[k];
+                for (int k = 0; k < nfb; ++k) { if (WRITE) c[n] = fb[k]; ++n; }
                 continue;
             }
         }
         if (t.unk_id >= 0) {
-            if (unk_pending && !t.fuse_unk) c[n++] = t.unk_id;
+            if (unk_pending && !t.fuse_unk) { if (WRITE) c[n] = t.unk_id; ++n; }
             unk_pending = true;
         }
     }
-    if (unk_pending) c[n++] = t.unk_id;
+    if (unk_pending) { if (WRITE) c[n] = t.unk_id; ++n; }
+    return n;
+}
+
+// state of a BPE token with n start symbols, in words: c[n] prev[n] next[n] + a queue of (rank, position, new id)
+// triples with room for 2n entries — at most n - 1 pairs at the start, one more per merge, at most n - 1 merges
+__device__ inline int bpe_state_words(int n) { return 9 * n + 1; }
+
+template <typename M>
+__device__ inline void bpe_merge(const RetokTables& t, const RetokLds& L, typename M::bytes raw, int len, int n, typename M::words scr, RowWriter& w) {
+    typename M::words c = scr;        // symbol ids, -1 = removed
+    typename M::words prev = c + n;
+    typename M::words next = prev + n;
+    typename M::words q = next + n;   // queue triples (rank, pos, new_id)
+    bpe_symbols<true, M>(t, L, raw, len, c);
     for (int i = 0; i < n; ++i) { prev[i] = i - 1; next[i] = (i + 1 < n) ? i + 1 : -1; }
     int nq = 0;
     for (int i = 0; i + 1 < n; ++i) {
@@ -319,12 +341,16 @@ __device__ void bpe_token(const RetokTables& t, const RetokLds& L, const uint8_t
         if (c[i] >= 0) w.push(c[i]);
 }
 
+// Viterbi lattice of a Unigram token of len bytes: best[len + 1] (double) + bstart / bid / fwd [len + 1]
+__device__ inline int unigram_state_words(int len) { return 5 * (len + 1) + 1; }
+
 // returns false on "unknown token but unk_id is missing"
-__device__ bool unigram_token(const RetokTables& t, const RetokLds& L, const uint8_t* raw, int len, int32_t* scr, RowWriter& w) {
-    double* best = (double*)scr;                   // [len+1]   (scr is 8-byte aligned)
-    int32_t* bstart = (int32_t*)(best + len + 1);  // [len+1]
-    int32_t* bid = bstart + len + 1;               // [len+1]  piece id, -2 = unknown
-    int32_t* fwd = bid + len + 1;                  // [len+1]  forward links of the best path
+template <typename M>
+__device__ inline bool unigram_token(const RetokTables& t, const RetokLds& L, typename M::bytes raw, int len, typename M::words scr, RowWriter& w) {
+    typename M::doubles best = (typename M::doubles)scr;      // [len+1]   (regions start on 8-byte boundaries)
+    typename M::words bstart = scr + 2 * (len + 1);           // [len+1]
+    typename M::words bid = bstart + len + 1;                 // [len+1]  piece id, -2 = unknown
+    typename M::words fwd = bid + len + 1;                    // [len+1]  forward links of the best path
     for (int i = 0; i <= len; ++i) { best[i] = 0.0; bstart[i] = -1; bid[i] = -1; }
     for (int s = 0; s < len; ++s) {
         const double base = best[s];
@@ -369,7 +395,8 @@ __device__ bool unigram_token(const RetokTables& t, const RetokLds& L, const uin
 // tokenizers `WordPiece::tokenize`.  Returns false on "the word is [UNK] but [UNK] is not in the vocabulary".  From each
 // start the library tries the longest substring first and shortens it a character at a time; walking the ends upwards
 // with a running hash and keeping the LAST hit finds the same piece.  One byte-level character is one raw byte.
-__device__ bool wordpiece_token(const RetokTables& t, const uint8_t* raw, int len, RowWriter& w, int32_t pad_id) {
+template <typename M>
+__device__ inline bool wordpiece_token(const RetokTables& t, typename M::bytes raw, int len, RowWriter& w, int32_t pad_id) {
     if (len > t.max_word_chars) {
         if (t.unk_id < 0) return false;
         w.push(t.unk_id);
@@ -399,36 +426,93 @@ __device__ bool wordpiece_token(const RetokTables& t, const uint8_t* raw, int le
     return true;
 }
 
+// special-token lookup (zett/utils.py:671-673) and, with ignore_merges, the whole-token lookup of BPE::tokenize: -1 = no hit
+template <typename M>
+__device__ inline int whole_token_id(const PieceEntry* tab, uint32_t mask, const uint8_t* blob, typename M::bytes s, int len) {
+    uint64_t h = FNV_OFFSET;
+    for (int i = 0; i < len; ++i) h = fnv_step(h, s[i]);
+    const PieceEntry* e = piece_find(tab, mask, blob, h, s, len);
+    return e ? e->id : -1;
+}
+
+// one token: `n_sym` = its BPE start symbols (0 for the other kinds), `scr` = its state region
+template <typename M>
+__device__ inline bool segment_token(const RetokTables& t, const RetokLds& L, typename M::bytes s, int len, int n_sym, typename M::words scr,
+                                     RowWriter& w, int32_t pad_id) {
+    if (t.kind == ZETT_RETOK_BPE) { bpe_merge<M>(t, L, s, len, n_sym, scr, w); return true; }
+    if (t.kind == ZETT_RETOK_UNIGRAM) return unigram_token<M>(t, L, s, len, scr, w);
+    return wordpiece_token<M>(t, s, len, w, pad_id);
+}
+
 __global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const uint8_t* __restrict__ raw,
                                                           const int32_t* __restrict__ raw_off, int64_t n_tokens,
                                                           int maxlen, int32_t pad_id, int32_t* __restrict__ out, int32_t* __restrict__ scratch,
                                                           unsigned long long* __restrict__ n_truncated,
                                                           int32_t* __restrict__ err_unk) {
     __shared__ RetokLds L;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) { L.single_id[i] = t.single_id[i]; L.bf_ids[i] = t.bf_ids[i]; }
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[RT_TEXT_BYTES + 16];
+    __shared__ __attribute__((aligned(8))) int32_t s_arena[RT_ARENA_WORDS];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) { L.single_id[i] = t.single_id[i]; L.bf_ids[i] = t.bf_ids[i]; }
+    const int64_t tok0 = (int64_t)blockIdx.x * 64;
+    const int64_t tok = tok0 + lane;
+    const bool live = tok < n_tokens;
+    const int o0 = live ? raw_off[tok] : 0;
+    const int len = live ? raw_off[tok + 1] - o0 : 0;
+    // the wave's text: bytes [w_lo, w_hi) of `raw`, staged from the 16-byte boundary below w_lo (the buffer has 16 bytes of slack)
+    const int w_lo = raw_off[tok0];
+    const int w_hi = raw_off[tok0 + 64 < n_tokens ? tok0 + 64 : n_tokens];
+    const int mis = w_lo & 15;
+    const bool text_lds = (w_hi - w_lo) + mis <= RT_TEXT_BYTES;
+    if (text_lds)
+        for (int i = lane * 16; i < (w_hi - w_lo) + mis; i += 64 * 16) *(uint4*)(s_text + i) = *(const uint4*)(raw + (w_lo - mis) + i);
     __syncthreads();
-    const int64_t tok = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tok >= n_tokens) return;
-    const int o0 = raw_off[tok], len = raw_off[tok + 1] - o0;
-    const uint8_t* s = raw + o0;
+    const lds_u8* sl = (const lds_u8*)s_text + mis + (o0 - w_lo);
+    const uint8_t* sg = raw + o0;
     RowWriter w{out + tok * maxlen, maxlen, 0};
-    if (len > 0 && t.special_mask != 0xffffffffu) {          // zett/utils.py:671-673
-        uint64_t h = FNV_OFFSET;
-        for (int i = 0; i < len; ++i) h = fnv_step(h, s[i]);
-        const PieceEntry* e = piece_find(t.specials, t.special_mask, t.special_blob, h, s, len);
-        if (e) { w.row[0] = e->id; return; }
+    bool todo = live && len > 0;
+    if (todo && t.special_mask != 0xffffffffu) {              // zett/utils.py:671-673
+        const int id = text_lds ? whole_token_id<LdsMem>(t.specials, t.special_mask, t.special_blob, sl, len)
+                                : whole_token_id<GlobalMem>(t.specials, t.special_mask, t.special_blob, sg, len);
+        if (id >= 0) { w.row[0] = id; todo = false; }
     }
-    if (len == 0) return;
-    int32_t* scr = scratch + ((int64_t)o0 * SCR_PER_BYTE + tok * SCR_FIXED);
-    bool ok = true;
-    if (t.kind == ZETT_RETOK_BPE) bpe_token(t, L, s, len, scr, w);
-    else if (t.kind == ZETT_RETOK_UNIGRAM) ok = unigram_token(t, L, s, len, scr, w);
-    else ok = wordpiece_token(t, s, len, w, pad_id);
-    if (!ok) {
-        atomicMax(err_unk, (int32_t)(tok < 0x7ffffffe ? tok + 1 : 0x7fffffff));
-        return;
+    if (todo && t.kind == ZETT_RETOK_BPE && t.ignore_merges) {
+        const int id = text_lds ? whole_token_id<LdsMem>(t.pieces, t.piece_mask, t.piece_blob, sl, len)
+                                : whole_token_id<GlobalMem>(t.pieces, t.piece_mask, t.piece_blob, sg, len);
+        if (id >= 0) { w.push(id); todo = false; }
     }
-    if (w.n > maxlen) atomicAdd(n_truncated, 1ull);          // zett/utils.py:683-685
+    // state of the token, and its place in the wave's arena: an exclusive wavefront scan over the 64 sizes
+    int n_sym = 0, need = 0;
+    if (todo) {
+        if (t.kind == ZETT_RETOK_BPE) {
+            n_sym = text_lds ? bpe_symbols<false, LdsMem>(t, L, sl, len, (lds_i32*)nullptr) : bpe_symbols<false, GlobalMem>(t, L, sg, len, (int32_t*)nullptr);
+            need = bpe_state_words(n_sym);
+        } else if (t.kind == ZETT_RETOK_UNIGRAM) {
+            need = unigram_state_words(len);
+        }
+        need = (need + 1) & ~1;                                // regions start on 8-byte boundaries
+    }
+    int inc = need;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += v;
+    }
+    const int a0 = inc - need;
+    if (todo) {
+        bool ok;
+        if (text_lds && a0 + need <= RT_ARENA_WORDS) {
+            ok = segment_token<LdsMem>(t, L, sl, len, n_sym, (lds_i32*)s_arena + a0, w, pad_id);
+        } else {
+            int32_t* scr = scratch + ((int64_t)o0 * SCR_PER_BYTE + tok * SCR_FIXED);
+            ok = segment_token<GlobalMem>(t, L, sg, len, n_sym, scr, w, pad_id);
+        }
+        if (!ok) {
+            atomicMax(err_unk, (int32_t)(tok < 0x7ffffffe ? tok + 1 : 0x7fffffff));
+            return;
+        }
+        if (w.n > maxlen) atomicAdd(n_truncated, 1ull);      // zett/utils.py:683-685
+    }
 }
 
 }  // namespace zett

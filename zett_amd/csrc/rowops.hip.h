@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gemm.hip.h"
 
 namespace zett {
@@ -481,6 +483,49 @@ template <typename T> __device__ __forceinline__ void store8_16bit(T* p, const f
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&o)[8]) { store8_16bit<bf16_t>(p, o); }
 template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&o)[8]) { store8_16bit<f16_t>(p, o); }
 
+// ---- fast path of the attention kernel (16-bit operands, rows of at most ATT_FAST_KEYS packed positions: every row of the
+// BASELINE workloads, hn_surface_maxlen 7 + language token) ----------------------------------------------------------------
+// (r4) The generic loop below walks (query, key) pairs one after the other: a K and a V load, a shuffle reduction through the
+// LDS crossbar and two expf chains per pair, each waiting for the one before — ~0.3 ns per pair and wave whatever the width,
+// which on the narrow hypernets is 2-3 TB/s (XLM-R shape: 0.33 ms per launch for 1.04 GB).  Here the row's keys and values
+// are fetched ONCE, all at the start (packed 16-bit, 8 registers per position), and a query handles all keys side by side:
+// independent v_dot2 chains, head sums by DPP (no LDS), one v_exp_f32 per key, no running-maximum correction.
+constexpr int ATT_FAST_KEYS = 8;
+
+template <typename T> __device__ __forceinline__ float dot8_lo(const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ float dot8_lo<f16_t>(const uint4& a, const uint4& b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    float s = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.x), __builtin_bit_cast(h2, b.x), 0.f, false);
+    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.y), __builtin_bit_cast(h2, b.y), s, false);
+    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.z), __builtin_bit_cast(h2, b.z), s, false);
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.w), __builtin_bit_cast(h2, b.w), s, false);
+}
+template <> __device__ __forceinline__ float dot8_lo<bf16_t>(const uint4& a, const uint4& b) {
+    float x[8], y[8];
+    unpack2_lo<bf16_t>(a.x, x[0], x[1]); unpack2_lo<bf16_t>(a.y, x[2], x[3]); unpack2_lo<bf16_t>(a.z, x[4], x[5]); unpack2_lo<bf16_t>(a.w, x[6], x[7]);
+    unpack2_lo<bf16_t>(b.x, y[0], y[1]); unpack2_lo<bf16_t>(b.y, y[2], y[3]); unpack2_lo<bf16_t>(b.z, y[4], y[5]); unpack2_lo<bf16_t>(b.w, y[6], y[7]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s = fmaf(x[c], y[c], s);
+    return s;
+}
+template <> __device__ __forceinline__ float dot8_lo<float>(const uint4&, const uint4&) { return 0.f; }     // (never called: the fast path is 16-bit only)
+
+// sum over the `lph` lanes of a head (lph = head_dim / 8, a power of two): DPP inside a row of 16 lanes, ds_swizzle (no LDS
+// access) across 16, a bpermute only for a head that spans the whole wave.  Every lane of the head ends with the same bits.
+__device__ __forceinline__ float head_sum(float s, int lph) {
+    auto dpp = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    if (lph >= 2) s += dpp(s, std::integral_constant<int, 0xB1>{});         // quad_perm [1,0,3,2]
+    if (lph >= 4) s += dpp(s, std::integral_constant<int, 0x4E>{});         // quad_perm [2,3,0,1]
+    if (lph >= 8) s += dpp(s, std::integral_constant<int, 0x141>{});        // row_half_mirror
+    if (lph >= 16) s += dpp(s, std::integral_constant<int, 0x140>{});       // row_mirror
+    if (lph >= 32) s += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, s), (16 << 10) | 0x1f));
+    if (lph >= 64) s += __shfl_xor(s, 32, 64);
+    return s;
+}
+
 // Rows of q / k / v / ctx are BUFFER rows (position 0 first, chunk_row above); the plan arrays are indexed by packed position.
 // q: [T, ldq] per packed position, or (cls_only) [rows, ldq] holding the query of position 0
 // of each row; k, v: [T, ldkv]; ctx: [T or rows, H].  cls_only: compute query 0 only and
@@ -492,8 +537,9 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
                                                              const int32_t* __restrict__ row_offset,
                                                              const uint8_t* __restrict__ row_uniform,
                                                              const uint8_t* __restrict__ tok_key, int64_t row0,
-                                                             int rows, int tok0, float scaling, int cls_only,
+                                                             int rows, int tok0, float scaling, int flags /* bit 0: cls_only, bit 1: fast path on */,
                                                              const int32_t* __restrict__ tok_pair, T* __restrict__ ctx) {
+    const int cls_only = flags & 1;
     const int groups = (H + 511) >> 9;
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -521,6 +567,65 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
         if (!tok_pair) return brow(t);
         return t - t0 < 64 ? (size_t)__shfl(pslot, t - t0, 64) : (size_t)tok_pair[tok0 + t];
     };
+    const int nk = t1 - t0;
+    if constexpr (sizeof(T) == 2) {
+        if (nk <= ATT_FAST_KEYS && (flags & 2)) {
+            // which keys count: lane j asks for key j, the answer is a wave-uniform bit mask
+            const bool mine = lane < nk && (uniform || tok_key[tok0 + t0 + lane] != 0);
+            const unsigned on = (unsigned)__ballot(mine);
+            uint4 kk[ATT_FAST_KEYS], vv[ATT_FAST_KEYS], qq[ATT_FAST_KEYS];
+#pragma unroll
+            for (int j = 0; j < ATT_FAST_KEYS; ++j) {
+                if (j < nk) {
+                    const size_t kr = qrow(t0 + j);
+                    kk[j] = *(const uint4*)(kbase + kr * ldkv + ccol);
+                    vv[j] = *(const uint4*)(vbase + kr * ldkv + ccol);
+                    if (!cls_only) qq[j] = *(const uint4*)(qbase + kr * ldq + ccol);
+                }
+            }
+            if (cls_only) qq[0] = *(const uint4*)(qbase + (size_t)rl * ldq + ccol);
+            const float sc2 = scaling * 1.4426950408889634f;       // softmax in base 2: exp(x) = 2^(x log2 e)
+#pragma unroll
+            for (int qi = 0; qi < ATT_FAST_KEYS; ++qi) {
+                if (qi < nq) {
+                    float sj[ATT_FAST_KEYS];
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int j = 0; j < ATT_FAST_KEYS; ++j) {
+                        sj[j] = -INFINITY;
+                        if (j < nk && ((on >> j) & 1u)) {
+                            const float d = head_sum(dot8_lo<T>(qq[qi], kk[j]), lph);
+                            sj[j] = uniform ? 0.f : d * sc2;
+                            mx = fmaxf(mx, sj[j]);
+                        }
+                    }
+                    float l = 0.f, acc[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < ATT_FAST_KEYS; ++j) {
+                        if (j < nk && ((on >> j) & 1u)) {
+                            const float pj = __builtin_amdgcn_exp2f(sj[j] - mx);
+                            l += pj;
+                            float v[8];
+                            unpack2_lo<T>(vv[j].x, v[0], v[1]); unpack2_lo<T>(vv[j].y, v[2], v[3]);
+                            unpack2_lo<T>(vv[j].z, v[4], v[5]); unpack2_lo<T>(vv[j].w, v[6], v[7]);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) acc[c] = fmaf(pj, v[c], acc[c]);
+                        }
+                    }
+                    const float inv = 1.0f / l;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] *= inv;
+                    if (active) {
+                        const size_t orow = cls_only ? (size_t)rl : brow(t0 + qi);
+                        store8<T>(ctx + orow * H + col, acc);
+                    }
+                }
+            }
+            return;
+        }
+    }
     for (int qi = 0; qi < nq; ++qi) {
         float q[8];
         load8<T>(qbase + (cls_only ? (size_t)rl : qrow(t0 + qi)) * ldq + ccol, q);

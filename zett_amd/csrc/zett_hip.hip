@@ -75,6 +75,7 @@ struct zett_hypernet {
     int time_gemm = 0;
     int cls_only_last = 1;
     int pair_dedupe = 1;              // layer 0's Q/K/V once per distinct (source id, position) pair (do_forward)
+    int attention_fast = 1;           // rows of <= 8 packed positions: keys / values fetched once, all keys of a query side by side (rowops.hip.h)
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
     int gemm4d_min_k = 512;           // 16-bit launches with K >= this take the four-wave direct-to-LDS tile (r2: with the streamlined epilogues it is ahead of gemm8r down to K = 768: +1.8 % on the XLM-R workload)
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
@@ -450,6 +451,8 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
         h->cls_only_last = value != 0;
     } else if (k == "pair_dedupe") {
         h->pair_dedupe = value != 0;
+    } else if (k == "attention_fast") {
+        h->attention_fast = value != 0;
     } else if (k == "ln_fold") {
         if (value < 0 || value > 2) return fail(ZETT_E_INVALID, "ln_fold must be 0 (off), 1 (encoder and output heads) or 2 (encoder only: A/B)");
         h->ln_fold = (int)value;
@@ -925,7 +928,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 R.gemm(Zt, H, wqkv, H, by_pair ? P : m, 3 * H, H, eq);
                 hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                                    (const T*)BIG, (size_t)3 * H, (const T*)BIG + H, (const T*)BIG + 2 * H, (size_t)3 * H,
-                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 0,
+                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 0 | (h->attention_fast ? 2 : 0),
                                    by_pair ? (const int32_t*)p.tok_pair : (const int32_t*)nullptr, CTX);
                 R.check("attention");
             } else {
@@ -944,7 +947,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 R.gemm(Zt, H, wqkv, H, rows, H, H, eq);
                 hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                                    (const T*)Q, (size_t)H, (const T*)KV, (const T*)KV + H, (size_t)2 * H,
-                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 1,
+                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 1 | (h->attention_fast ? 2 : 0),
                                    (const int32_t*)nullptr, CTX);
                 R.check("attention(position 0)");
                 zrows = rows;

@@ -169,10 +169,96 @@ def make_hn_unigram_model(cfg) -> dict:
     return {"type": "Unigram", "unk_id": 0, "vocab": vocab, "byte_fallback": False}
 
 
-def tokens_for_surface_forms(cfg, ids: np.ndarray):
-    """Target-token strings (byte-level alphabet) that retokenize to the rows of `ids` under make_hn_unigram_model:
-    the pieces of the non-pad ids of the row, concatenated.  Rows must be pad-free up to their length (what
-    make_surface_forms produces with n_special = 0)."""
+# Which bare model the SOURCE model's tokenizer is on each workload (what zett/utils.py:681 calls per target token):
+# Mistral-7B / TinyLlama ship a sentencepiece-style BPE with byte fallback (32 000 entries, ~31.7 k merges), Llama-3 a
+# byte-level BPE of 128 k entries with ignore_merges and no byte fallback, XLM-R a Unigram model of 250 k pieces.
+HN_MODEL_KIND = {
+    "tiny": "unigram", "xlmr_gpt2": "unigram",
+    "tinyllama_neox": "bpe_byte_fallback", "mistral_neox": "bpe_byte_fallback", "mistral_gpt2_32k": "bpe_byte_fallback",
+    "llama3_256k": "bpe_ignore_merges",
+}
+
+_BPE_FALLBACK_CHARS = "_#|{}[]"                       # ASCII characters the BPE vocabulary does NOT hold: they leave as "<0xXX>" ids
+_BPE_HEADS = _PIECE_ALPHABET[:44]                     # a piece is ONE head character followed by tail characters only, and every
+_BPE_TAILS = _PIECE_ALPHABET[44:]                     # merge is (piece, tail character): no merge can cross a piece boundary
+
+
+def make_hn_bpe_model(cfg, byte_fallback: bool = True, ignore_merges: bool = False, seed: int = 0):
+    """A tokenizers-format BPE model JSON shaped like the source models' own tokenizers — one merge per multi-character
+    entry (31.9 k merges at the 32 000-entry Mistral / TinyLlama size, 128 k at Llama-3's), pieces of 1-4 characters (1-5 from
+    40 k entries: mean 3.6, so a target token of the workload's 2.4 pieces is ~8 bytes, as GPT-2 / NeoX tokens are) grown as
+    a random prefix-closed tree in rank order, optional byte fallback — whose segmentation of a concatenation of pieces
+    is that concatenation.  Returns (model, piece_of_id): piece_of_id[i] is the text that retokenizes to id i, for every
+    i in [3, V0 + X).
+
+    Layout of the ids: 0..2 special-token strings; with byte fallback the next 7 are the "<0xXX>" entries of the ASCII
+    characters in _BPE_FALLBACK_CHARS (the vocabulary does not hold those characters, so the library emits the byte
+    token: the fallback branch of merge_word runs on ~0.02 % of the positions, as often as the uniform id sampler of
+    make_surface_forms draws one of those 7 ids); then the 44 head characters; then one entry per merge, in rank order.
+    Entries that exist only so that BPE can start from characters — the tail characters and the other 249 byte tokens —
+    take ids from V0 + X upwards: no surface form ever ends in one, so the id matrix stays inside the embedding matrix."""
+    d = HypernetDims.from_config(cfg)
+    n = d.original_vocab_size + d.n_extra
+    rng = _rng(seed, "hn_bpe_model")
+    vocab: Dict[str, int] = {"<unk>": 0, "<s>": 1, "</s>": 2}
+    piece_of_id: Dict[int, str] = {}
+    nxt = 3
+    if byte_fallback:
+        for ch in _BPE_FALLBACK_CHARS:
+            vocab["<0x%02X>" % ord(ch)] = nxt
+            piece_of_id[nxt] = ch
+            nxt += 1
+    pieces = []
+    for ch in _BPE_HEADS:
+        vocab[ch] = nxt
+        piece_of_id[nxt] = ch
+        pieces.append(ch)
+        nxt += 1
+    merges = []
+    growable = list(pieces)
+    nt = len(_BPE_TAILS)
+    max_piece = 4 if n <= 40000 else 5
+    while nxt < n:
+        k = int(rng.integers(0, len(growable)))
+        parent = growable[k]
+        t = _BPE_TAILS[int(rng.integers(0, nt))]
+        child = parent + t
+        if child in vocab:
+            continue
+        vocab[child] = nxt
+        piece_of_id[nxt] = child
+        merges.append([parent, t])
+        if len(child) < max_piece:
+            growable.append(child)
+        nxt += 1
+    for ch in _BPE_TAILS:                               # start symbols only: beyond the embedding matrix
+        vocab[ch] = nxt
+        nxt += 1
+    if byte_fallback:
+        for b in range(256):
+            key = "<0x%02X>" % b
+            if key not in vocab:
+                vocab[key] = nxt
+                nxt += 1
+    model = {"type": "BPE", "vocab": vocab, "merges": merges, "unk_token": "<unk>", "fuse_unk": bool(byte_fallback),
+             "byte_fallback": bool(byte_fallback), "ignore_merges": bool(ignore_merges), "dropout": None,
+             "continuing_subword_prefix": None, "end_of_word_suffix": None}
+    return model, piece_of_id
+
+
+def make_hn_model(workload_name: str, cfg):
+    """(model JSON, piece_of_id or None) of the workload's synthetic hn tokenizer: the kind of HN_MODEL_KIND."""
+    kind = HN_MODEL_KIND.get(workload_name, "unigram")
+    if kind == "unigram":
+        return make_hn_unigram_model(cfg), None
+    return make_hn_bpe_model(cfg, byte_fallback=kind == "bpe_byte_fallback", ignore_merges=kind == "bpe_ignore_merges")
+
+
+def tokens_for_surface_forms(cfg, ids: np.ndarray, piece_of_id=None):
+    """Target-token strings (byte-level alphabet) that retokenize to the rows of `ids` under the synthetic hn model
+    (make_hn_unigram_model when piece_of_id is None, else the model piece_of_id came with): the pieces of the non-pad ids
+    of the row, concatenated.  Rows must be pad-free up to their length (what make_surface_forms produces with
+    n_special = 0)."""
     d = HypernetDims.from_config(cfg)
     ids = np.asarray(ids)
     lengths = (ids != d.pad_token_id).sum(axis=1)
@@ -185,7 +271,7 @@ def tokens_for_surface_forms(cfg, ids: np.ndarray):
         for i in row[:ln]:
             p = cache.get(i)
             if p is None:
-                p = cache[i] = _piece(i)
+                p = cache[i] = _piece(i) if piece_of_id is None else piece_of_id[i]
             parts.append(p)
         out.append("".join(parts))
     return out
