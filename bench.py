@@ -319,8 +319,11 @@ def main():
     def launch_class(r):
         e = r["epilogue"]
         act = {0: "", 1: " + tanh-GELU", 2: " + erf-GELU"}[(e >> 8) & 3]
+        if e & 16 and e & 64:
+            return "LayerNorm-fold producer on the 16-bit residual stream (16-bit residual in, 16-bit out, row statistics)"
         if e & 16:
-            return "LayerNorm-fold producer (fp32 residual in, fp32 + 16-bit out, row statistics)"
+            return ("LayerNorm-fold producer (fp32 residual in, fp32 + 16-bit out, row statistics)" if e & 2 else
+                    "LayerNorm-fold producer of an output head (fp32 residual in, 16-bit out, row statistics)" + act)
         if e & 32:
             return "LayerNorm-fold consumer, 16-bit out" + act
         if e & 8:

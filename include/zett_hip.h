@@ -147,7 +147,8 @@ typedef struct zett_gemm_record {
     int32_t m, n, k;
     int32_t variant;              /* tile kernel that ran: the "gemm_variant" numbering                          */
     int32_t epilogue;             /* bit 0 16-bit output, 1 fp32 output, 2 residual, 3 Rescaler, 4 LayerNorm-fold producer
-                                     (16-bit copy + partial statistics), 5 LayerNorm-fold consumer; bits 8-9 activation
+                                     (16-bit copy + partial statistics), 5 LayerNorm-fold consumer, 6 residual read from the
+                                     16-bit stream; bits 8-9 activation
                                      (0 none, 1 tanh-GELU, 2 erf-GELU)                                            */
     float ms;                     /* launch duration (0 when "time_gemm" is off)                                  */
     double flops;                 /* 2*m*n*k                                                                      */
@@ -195,7 +196,11 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
 /* Options: "max_chunk_tokens" (packed positions per encoder chunk, >= 1024; default: 12 GiB of per-position
  * workspace, at least 131072 positions: 131072 at H = 4096, ~640 k at H = 768), "time_gemm" (0/1: bracket every
  * GEMM launch with HIP events on the launch stream and report the sum in
- * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "attention_fast" (0/1, default 1, A/B only: rows of at most 8 packed positions
+ * zett_stats.gemm_ms), "cls_only_last_layer" (0/1, default 1), "residual_lo" (0/1/2, default 1: with the LayerNorm fold on, the
+ * encoder's hidden state travels as the 16-bit copy of its pre-LayerNorm sum only — the residual GEMMs read their residual rows
+ * from it and write no fp32 sum; 1 = in F16 mode (the stream is rounded to 11 significand bits per layer: inside the f16
+ * tolerance), 2 = in BF16 mode too (8 bits: outside the bf16 tolerance, A/B only), 0 = fp32 residual stream),
+ * "attention_fast" (0/1, default 1, A/B only: rows of at most 8 packed positions
  * take the attention kernel's register-resident path), "pair_dedupe" (0/1, default 1: layer 0's
  * Q/K/V once per distinct (source id, position) pair; same bits either way), "ln_fold" (0/1/2, default 1: in the 16-bit
  * modes the LayerNorms inside the encoder AND the ProjectorBlock LayerNorm in front of each output head's final Linear are

@@ -278,6 +278,10 @@ struct GemmEpilogue {
     // predicted embeddings and are checked for inf / NaN (ZETT_RANGE_OUTPUT).
     int32_t* range_flag;
     int range_final;
+    // 16-bit residual stream (r4; gemm4d's LN16 producer only): the residual rows are read from the 16-bit copy of the hidden
+    // state (type T) instead of `residual`; res_stats / res_gamma / res_beta / res_index apply to it as they do to `residual`
+    const T* residual_lo;
+    int ld_res_lo;
 };
 
 // Largest finite value of the operand type: what a value written as a 16-bit operand is checked against.  bf16 and fp32

@@ -90,8 +90,14 @@ __device__ int g4d_stagger_ticks, g4d_stagger_mode;
 //   LO_LN      the producer of the output heads' ProjectorBlock LayerNorm (dense2: tanh-GELU + plain fp32 residual): ONLY the
 //              16-bit copy of the sum and the partial statistics leave — nothing reads the fp32 sum again
 //   F32_SCALE_FOLD   its consumer: the final Linear with the Rescaler, on the un-normalised operand (as LO_FOLD, fp32 output)
+//   LN16       (r4) the encoder's producer on a 16-BIT RESIDUAL STREAM: the residual rows come from the 16-bit copy of the hidden
+//              state (residual_lo; LayerNorm'd on the fly, or as stored; indexed or not), and only the 16-bit copy of the sum and
+//              the partial statistics leave — 4 instead of 10 bytes per element, eight columns per lane on both sides (one
+//              16-byte load and one 16-byte store per eight values where F32_LN issues a 16-byte load, a 16-byte and an
+//              8-byte store per four).
+//              Round 3 had tried the 16-bit stream on F32_LN's four-column lane mapping (8-byte loads: slower, NOTEBOOK R3.3).
 enum { G4D_EPI_GENERIC = 0, G4D_EPI_LO = 1, G4D_EPI_F32 = 2, G4D_EPI_F32_SCALE = 3, G4D_EPI_BOTH = 4, G4D_EPI_F32_LN = 5, G4D_EPI_LO_FOLD = 6,
-       G4D_EPI_LO_LN = 7, G4D_EPI_F32_SCALE_FOLD = 8 };
+       G4D_EPI_LO_LN = 7, G4D_EPI_F32_SCALE_FOLD = 8, G4D_EPI_LN16 = 9 };
 constexpr int G4D_EPI_STRIDE = 132;                                   // floats per staged row: 128 columns + 4 of padding
 constexpr int G4D_EPI_REGION = 64 * G4D_EPI_STRIDE * 4;               // bytes per wave
 constexpr int G4D_LDS_BYTES = 4 * G4D_EPI_REGION;                     // 132 KiB (the K loop uses the first 128)
@@ -202,6 +208,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     const int nk = g.K / BK;
+    // LN16 (16-bit residual stream): the residual rows of pass 0 — sixteen 16-byte loads per lane, 64 registers — are requested
+    // from the LAST K step, one per four MFMAs in the request slots that step leaves empty, so that their latency runs under
+    // the MFMAs instead of at the head of the epilogue (the fp32 residual's 128 registers do not exist beside the fragments).
+    // Not for indexed residual rows (layer 0 with the pair lever: the row indices are fetched in the epilogue).
+    constexpr bool LN16K = EPI == G4D_EPI_LN16;
+    uint4 res16[LN16K ? 16 : 1];
+    const bool res16_early = LN16K && g.epi.res_index == nullptr;
+    // row t*4 + lane/16 of pass p of this wave, columns (lane%16)*8 .. +7; rows / columns past the edge are clamped (their values are never stored)
+    auto res16_request = [&](int p, int t) __attribute__((always_inline)) {
+        if constexpr (LN16K) {
+            int grow = m0 + wm * 128 + p * 64 + t * 4 + (lane >> 4);
+            grow = grow < g.M ? grow : g.M - 1;
+            int gc = n0 + wn * 128 + (lane & 15) * 8;
+            gc = gc < g.N ? gc : 0;
+            res16[t] = *(const uint4*)(g.epi.residual_lo + (size_t)grow * g.epi.ld_res_lo + gc);
+        }
+    };
     // ---- prologue: steps 0 and 1 requested, step 0 landed, its block-0 fragments read
 #pragma unroll
     for (int r = 0; r < 8; ++r) dma_w(0, r);
@@ -255,6 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (more2 && p >= 70 && p < 102 && WV == ((p - 70) & 3)) dma_a(kt + 2, (p - 70) >> 2);
             if (more && p >= 103 && p <= 110) read_w(cur ^ 1, 0, p - 103);
             if (more && p >= 111 && p <= 125 && (p & 1) == 1) read_a(cur ^ 1, 0, (p - 111) >> 1);
+            if constexpr (LN16K) { if (!more && p >= 40 && p < 104 && (p & 3) == 0 && res16_early) res16_request(0, (p - 40) >> 2); }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -319,11 +343,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
         // ---- streamlined epilogues (see the header).  No barrier here: the last K step carries it.
         constexpr bool LO = EPI == G4D_EPI_LO || EPI == G4D_EPI_LO_FOLD, SCALE = EPI == G4D_EPI_F32_SCALE || EPI == G4D_EPI_F32_SCALE_FOLD;
-        constexpr bool LNP = EPI == G4D_EPI_F32_LN || EPI == G4D_EPI_LO_LN, FOLD = EPI == G4D_EPI_LO_FOLD || EPI == G4D_EPI_F32_SCALE_FOLD;
-        constexpr bool WF32 = EPI != G4D_EPI_LO_LN;          // the fp32 output is written
+        constexpr bool LN16 = EPI == G4D_EPI_LN16;
+        constexpr bool LNP = EPI == G4D_EPI_F32_LN || EPI == G4D_EPI_LO_LN || LN16, FOLD = EPI == G4D_EPI_LO_FOLD || EPI == G4D_EPI_F32_SCALE_FOLD;
+        constexpr bool WF32 = EPI != G4D_EPI_LO_LN && !LN16;          // the fp32 output is written
         static_assert(!LNP || RES, "a LayerNorm producer is a residual epilogue");
-        static_assert(EPI != G4D_EPI_F32_LN || ACT == ACT_NONE, "the encoder's producer has no activation");
-        constexpr int CPL = LO ? 8 : 4;            // columns per lane
+        static_assert((EPI != G4D_EPI_F32_LN && !LN16) || ACT == ACT_NONE, "the encoder's producer has no activation");
+        static_assert(!LN16 || sizeof(T) == 2, "16-bit residual stream");
+        constexpr int CPL = (LO || LN16) ? 8 : 4;  // columns per lane
         constexpr int LPR = 128 / CPL;             // lanes per row
         constexpr int RPI = 64 / LPR;              // rows per wave instruction
         constexpr int NIT = 64 / RPI;              // instructions per pass
@@ -360,13 +386,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // fetches theirs with v_readlane.  gamma / beta of the lane's four columns sit beside the bias.
         // (no activation in front of a LayerNorm'd residual: gemm4d_epi_mode sends anything else to the generic drain)
         const bool res_ln = RES && ACT == ACT_NONE && e.res_stats != nullptr;
-        float lg[4] = {1.f, 1.f, 1.f, 1.f}, lb[4] = {0.f, 0.f, 0.f, 0.f};
+        float lg[CPL], lb[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { lg[c] = 1.f; lb[c] = 0.f; }
         float2 pst[2] = {make_float2(0.f, 1.f), make_float2(0.f, 1.f)};
         if constexpr (RES && ACT == ACT_NONE) {
             if (res_ln) {
                 if (col_ok) {
-                    const float4 a = *(const float4*)(e.res_gamma + gcol), b = *(const float4*)(e.res_beta + gcol);
-                    lg[0] = a.x; lg[1] = a.y; lg[2] = a.z; lg[3] = a.w; lb[0] = b.x; lb[1] = b.y; lb[2] = b.z; lb[3] = b.w;
+#pragma unroll
+                    for (int c4 = 0; c4 < CPL; c4 += 4) {
+                        const float4 a = *(const float4*)(e.res_gamma + gcol + c4), b = *(const float4*)(e.res_beta + gcol + c4);
+                        lg[c4] = a.x; lg[c4 + 1] = a.y; lg[c4 + 2] = a.z; lg[c4 + 3] = a.w; lb[c4] = b.x; lb[c4 + 1] = b.y; lb[c4 + 2] = b.z; lb[c4 + 3] = b.w;
+                    }
                 }
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
@@ -414,9 +445,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // (LNP: ONE buffer — pass 1's rows are requested after pass 0 has drained; the row statistics and the second
         //  output need the registers that both passes' rows would take, and a spill costs more than that wait)
         constexpr int RB = LNP ? 1 : 2;
-        float4 res[RB][RES ? NIT : 1];
+        float4 res[LN16 ? 1 : RB][(RES && !LN16) ? NIT : 1];
+        // (LN16: res16[] above — eight 16-bit residual values per lane and instruction, 64 registers per pass; both passes at
+        //  once — 128 — was tried first and spills: 456 bytes of scratch per lane)
+        auto load_res16 = [&](int p, int ta, int tb) {      // instructions [ta, tb) of pass p
+            if constexpr (LN16) {
+#pragma unroll
+                for (int t = ta; t < tb; ++t) {
+                    if (res_ix) {
+                        const int grow = grow0 + p * 64 + t * RPI;
+                        const size_t rrow = (size_t)__shfl(rix[p], t * RPI + rsub, 64);       // row t*RPI + rsub of the pass
+                        res16[t] = (grow < g.M && col_ok) ? *(const uint4*)(e.residual_lo + rrow * e.ld_res_lo + gcol) : make_uint4(0u, 0u, 0u, 0u);
+                    } else {
+                        res16_request(p, t);
+                    }
+                }
+            }
+        };
         auto load_res = [&](int p) {
-            if constexpr (RES) {
+            if constexpr (LN16) {
+                load_res16(p, 0, NIT);
+            } else if constexpr (RES) {
 #pragma unroll
                 for (int t = 0; t < NIT; ++t) {
                     const int grow = grow0 + p * 64 + t * RPI;
@@ -439,6 +488,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         region[(i4 * 16 + kq * 4 + r) * G4D_EPI_STRIDE + j * 16 + l15] = acc[4 * p + i4][j][r];
             if constexpr (FOLD)      // row l's statistics into the four floats of padding behind its 128 staged columns
                 *(float2*)(region + lane_e * G4D_EPI_STRIDE + 128) = fst[p];
+            if constexpr (LN16)      // the same place for the statistics of row l's LayerNorm'd residual
+                *(float2*)(region + lane_e * G4D_EPI_STRIDE + 128) = pst[p];
         };
         // FULL: all 64 rows and all 128 columns of the pass lie inside the matrix (wave-uniform): no predicate anywhere.
         // fp32 rows behind a residual go out non-temporal: they are streamed once to the LayerNorm kernel and stay out
@@ -462,7 +513,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) { bb[u * CPL + c] = bias[c]; ss[u * CPL + c] = sc[c]; hh[u * CPL + c] = sh[c]; rr[u * CPL + c] = 0.f; }
-                    if constexpr (RES) {
+                    if constexpr (LN16) {
+                        const uint4 x = res16[t0 + u];
+                        unpack2_lo<T>(x.x, rr[u * 8], rr[u * 8 + 1]); unpack2_lo<T>(x.y, rr[u * 8 + 2], rr[u * 8 + 3]);
+                        unpack2_lo<T>(x.z, rr[u * 8 + 4], rr[u * 8 + 5]); unpack2_lo<T>(x.w, rr[u * 8 + 6], rr[u * 8 + 7]);
+                        if (res_ln) {
+                            const float2 st = *(const float2*)(region + ((t0 + u) * RPI + rsub) * G4D_EPI_STRIDE + 128);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) rr[u * 8 + c] = ln_affine(rr[u * 8 + c], st.x, st.y, lg[c], lb[c]);
+                        }
+                    } else if constexpr (RES) {
                         const float4 x = res[p % RB][t0 + u];
                         rr[u * CPL] = x.x; rr[u * CPL + 1] = x.y; rr[u * CPL + 2] = x.z; rr[u * CPL + 3] = x.w;
                         if (ACT == ACT_NONE && res_ln) {
@@ -503,7 +563,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int x = 0; x < NV; ++x) bad |= out_of_range(v[x], ZETT_F32_MAX);
                 }
-                if constexpr (LNP) {
+                if constexpr (LN16) {
+                    // per-row (sum, sum of squares) over the wave's 128 columns, eight per lane: a reduce-scatter over the 16 lanes
+                    // of a row — after the xor-8 and xor-4 exchanges a lane carries ONE of the group's four instructions' rows,
+                    // after two butterfly steps its totals; lane (idx & 3) == group keeps them
+                    static_assert(!LN16 || (GROUP == 4 && CPL == 8 && RPI == 4), "reduce-scatter layout");
+                    float S[4], Q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float* x = v + 8 * u;
+                        S[u] = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                        Q[u] = __builtin_fmaf(x[0], x[0], __builtin_fmaf(x[1], x[1], __builtin_fmaf(x[2], x[2], __builtin_fmaf(x[3], x[3],
+                               __builtin_fmaf(x[4], x[4], __builtin_fmaf(x[5], x[5], __builtin_fmaf(x[6], x[6], x[7] * x[7])))))));
+                    }
+                    const bool b3 = (idx & 8) != 0, b2 = (idx & 4) != 0;
+                    float ks0 = b3 ? S[2] : S[0], ks1 = b3 ? S[3] : S[1], kq0 = b3 ? Q[2] : Q[0], kq1 = b3 ? Q[3] : Q[1];
+                    ks0 += g4d_xor_lane<8>(b3 ? S[0] : S[2]); ks1 += g4d_xor_lane<8>(b3 ? S[1] : S[3]);
+                    kq0 += g4d_xor_lane<8>(b3 ? Q[0] : Q[2]); kq1 += g4d_xor_lane<8>(b3 ? Q[1] : Q[3]);
+                    float ks = b2 ? ks1 : ks0, kq = b2 ? kq1 : kq0;
+                    ks += g4d_xor_lane<4>(b2 ? ks0 : ks1); kq += g4d_xor_lane<4>(b2 ? kq0 : kq1);
+                    ks += g4d_xor_lane<2>(ks); kq += g4d_xor_lane<2>(kq);
+                    ks += g4d_xor_lane<1>(ks); kq += g4d_xor_lane<1>(kq);
+                    const bool mine = (idx & 3) == (t0 >> 2);
+                    acc_s = mine ? ks : acc_s; acc_q = mine ? kq : acc_q;
+                } else if constexpr (LNP) {
                     // per-row (sum, sum of squares) over the wave's 128 columns: a reduce-scatter over the 32 lanes of a row
                     // group — after the xor-16 and xor-8 exchanges a lane carries ONE of the group's four row pairs, after
                     // three butterfly steps the row's totals; lane (idx & 7) == group keeps them
@@ -531,7 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int u = 0; u < GROUP; ++u) {
                     const int grow = grow0 + p * 64 + (t0 + u) * RPI;
                     if (!FULL && (grow >= g.M || !col_ok)) continue;
-                    if constexpr (LO) {
+                    if constexpr (LO || LN16) {
                         const float4 a = make_float4(v[u * 8], v[u * 8 + 1], v[u * 8 + 2], v[u * 8 + 3]);
                         const float4 b = make_float4(v[u * 8 + 4], v[u * 8 + 5], v[u * 8 + 6], v[u * 8 + 7]);
                         store_out8<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, a, b);
@@ -546,10 +629,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             store_out4<T>(e.out_lo + (size_t)grow * e.ld_lo + gcol, make_float4(x[0], x[1], x[2], x[3]));
                     }
                 }
+                // LN16: the first half of pass 0's residual registers is free once its first two groups are through — pass 1's rows move in
+                if constexpr (LN16) { if (p == 0 && t0 == GROUP) load_res16(1, 0, NIT / 2); }
             }
+            if constexpr (LN16) { if (p == 0) load_res16(1, NIT / 2, NIT); }      // (the second half of pass 1's residual rows)
             if constexpr (LNP) {
                 // the lane holds row ((4 * (idx & 7) + 2 * b4 + b3) * 2 + rsub) of the pass: 64 lanes, 64 rows, one 512-byte store
-                const int rp = ((4 * (idx & 7) + 2 * ((idx >> 4) & 1) + ((idx >> 3) & 1)) << 1) + rsub;
+                // (LN16: row ((4 * (idx & 3) + 2 * b3 + b2) * 4 + rsub))
+                const int rp = LN16 ? (((4 * (idx & 3) + 2 * ((idx >> 3) & 1) + ((idx >> 2) & 1)) << 2) + rsub)
+                                    : (((4 * (idx & 7) + 2 * ((idx >> 4) & 1) + ((idx >> 3) & 1)) << 1) + rsub);
                 const int grow = m0 + wm * 128 + p * 64 + rp;
                 if (grow < g.M && n0 + wn * 128 < g.N)
                     e.stats_part[(size_t)((n0 + wn * 128) >> 7) * e.ld_part + grow] = make_float2(acc_s, acc_q);
@@ -563,7 +651,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef G4D_TRACE
         tr2b = wall_clock64();
 #endif
-        load_res(0);
+        if constexpr (LN16) { if (!res16_early) load_res(0); }
+        else load_res(0);
 #ifdef G4D_TRACE
         trp[0][0] = wall_clock64();
 #endif
@@ -579,7 +668,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef G4D_TRACE
         trp[0][3] = trp[1][0] = wall_clock64();
 #endif
-        if constexpr (LNP) { __builtin_amdgcn_sched_barrier(0); load_res(1); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (LNP && !LN16) { __builtin_amdgcn_sched_barrier(0); load_res(1); __builtin_amdgcn_sched_barrier(0); }
         stage(1);
 #ifdef G4D_TRACE
         __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
@@ -609,6 +698,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <typename T>
 inline int gemm4d_epi_mode(const GemmArgs<T>& g) {
     const GemmEpilogue<T>& e = g.epi;
+    if (e.stats_part && e.residual_lo) {    // LayerNorm producer on the 16-bit residual stream
+        if (sizeof(T) == 2 && e.out_lo && !e.out_f32 && !e.residual && e.act == ACT_NONE && !e.scale && !e.shift && !e.out_f32_b && e.split_col >= g.N &&
+            g.N % 128 == 0 && e.ld_lo % 8 == 0 && e.ld_res_lo % 8 == 0) return G4D_EPI_LN16;
+        return -1;
+    }
     if (e.stats_part) {    // LayerNorm producer: only these instantiations write the partial statistics
         const bool common = e.out_lo && e.residual && !e.scale && !e.shift && !e.out_f32_b && e.split_col >= g.N && g.N % 128 == 0 &&
                             e.ld_lo % 4 == 0 && e.ld_res % 4 == 0;
@@ -672,6 +766,7 @@ inline hipError_t launch_gemm4d(const GemmArgs<T>& g, hipStream_t stream, bool f
     const int mode = (force_generic && !g.epi.stats_part && !g.epi.fold_stats) ? G4D_EPI_GENERIC : gemm4d_epi_mode(g);
     if (mode < 0) return hipErrorInvalidValue;       // a LayerNorm-fold launch whose outputs no instantiation carries
     if (mode == G4D_EPI_F32_LN) return launch_gemm4d_inst<T, ACT_NONE, true, G4D_EPI_F32_LN>(g, stream);
+    if (mode == G4D_EPI_LN16) return launch_gemm4d_inst<T, ACT_NONE, true, G4D_EPI_LN16>(g, stream);
     if (mode == G4D_EPI_LO_LN) return launch_gemm4d_inst<T, ACT_GELU_TANH, true, G4D_EPI_LO_LN>(g, stream);
     if (mode == G4D_EPI_F32_SCALE_FOLD) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE_FOLD>(g, stream);
     if (mode == G4D_EPI_F32_SCALE) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE>(g, stream);

@@ -339,6 +339,7 @@ struct LnReadout {
     const float* bias_w;       // [H] bias_projection.weight, or null (predict_bias off: the bias output is 0)
     const float* bias_b;       // [1]
     float* out_bias;           // [rows] (already offset to the chunk's first row), or null: no readout
+    const void* in_lo;         // 16-bit residual stream: the rows come from here ([rows, ld_in] of the launch's operand type) instead of `in`
 };
 
 constexpr int LN_MAX_VEC = 8;   // 8 float4 x 256 threads = 8192 columns in registers
@@ -382,6 +383,14 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
         x = in + (size_t)r * ld_in;
     }
     auto load = [&](int v) -> float4 {
+        if constexpr (READOUT && sizeof(T) == 2) {
+            if (readout.in_lo) {
+                const uint2 u = *(const uint2*)((const T*)readout.in_lo + (size_t)r * ld_in + v * 4);
+                float4 a;
+                unpack2_lo<T>(u.x, a.x, a.y); unpack2_lo<T>(u.y, a.z, a.w);
+                return a;
+            }
+        }
         float4 a = *(const float4*)(x + v * 4);
         if constexpr (EMBED) {
             const float4 t0 = *(const float4*)(emb.type0 + v * 4);

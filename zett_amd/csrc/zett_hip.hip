@@ -75,6 +75,7 @@ struct zett_hypernet {
     int time_gemm = 0;
     int cls_only_last = 1;
     int pair_dedupe = 1;              // layer 0's Q/K/V once per distinct (source id, position) pair (do_forward)
+    int residual_lo = 1;              // 16-bit residual stream of the encoder (gemm4d LN16 producers): 1 = in f16 mode, 2 = in bf16 mode too (A/B), 0 = fp32 stream
     int attention_fast = 1;           // rows of <= 8 packed positions: keys / values fetched once, all keys of a query side by side (rowops.hip.h)
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
     int gemm4d_min_k = 512;           // 16-bit launches with K >= this take the four-wave direct-to-LDS tile (r2: with the streamlined epilogues it is ahead of gemm8r down to K = 768: +1.8 % on the XLM-R workload)
@@ -451,6 +452,9 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
         h->cls_only_last = value != 0;
     } else if (k == "pair_dedupe") {
         h->pair_dedupe = value != 0;
+    } else if (k == "residual_lo") {
+        if (value < 0 || value > 2) return fail(ZETT_E_INVALID, "residual_lo must be 0 (fp32 residual stream), 1 (16-bit stream in f16 mode) or 2 (in bf16 mode too)");
+        h->residual_lo = (int)value;
     } else if (k == "attention_fast") {
         h->attention_fast = value != 0;
     } else if (k == "ln_fold") {
@@ -639,11 +643,11 @@ struct Runner {
             zett_gemm_record r{};
             r.m = M; r.n = N; r.k = K; r.variant = variant;
             r.epilogue = (e.out_lo ? 1 : 0) | ((e.out_f32 || e.out_f32_b) ? 2 : 0) | (e.residual ? 4 : 0) | ((e.scale || e.shift) ? 8 : 0) |
-                         (e.stats_part ? 16 : 0) | (e.fold_stats ? 32 : 0) | (e.act << 8);
+                         (e.stats_part ? 16 : 0) | (e.fold_stats ? 32 : 0) | (e.residual_lo ? 64 : 0) | (e.act << 8);
             r.flops = fl;
             const double mn = (double)M * (double)N;
             r.bytes = ((double)M + (double)N) * (double)K * sizeof(T) + (e.out_lo ? mn * sizeof(T) : 0.0) + ((e.out_f32 || e.out_f32_b) ? mn * 4.0 : 0.0) +
-                      (e.residual ? mn * 4.0 : 0.0) + (e.stats_part ? (double)M * (N / 128) * 8.0 : 0.0) + ((e.fold_stats || e.res_stats) ? (double)M * 8.0 : 0.0);
+                      (e.residual ? mn * 4.0 : 0.0) + (e.residual_lo ? mn * sizeof(T) : 0.0) + (e.stats_part ? (double)M * (N / 128) * 8.0 : 0.0) + ((e.fold_stats || e.res_stats) ? (double)M * 8.0 : 0.0);
             h->gemm_log.push_back(r);
         }
         const hipError_t err = launch_gemm_variant(variant, g, st);      // gemm_launch.hip.h: the tile kernels live in their own translation units
@@ -660,8 +664,9 @@ struct Runner {
     }
 
     void layernorm(const float* in, int rows, const float* gamma, const float* beta, float eps, float* of, T* ol, float* stats = nullptr,
-                   LnReadout readout = LnReadout{}) {
+                   LnReadout readout = LnReadout{}, const T* in_lo = nullptr) {
         if (rc || rows <= 0) return;
+        readout.in_lo = in_lo;          // (16-bit residual stream: the rows are read from the 16-bit copy of the sum; READOUT instantiations only)
         const int H = h->cfg.hidden;
         const dim3 grid = H <= 2048 ? dim3((rows + 3) / 4) : dim3(rows);      // H <= 2048: a wave per row, four rows per workgroup
 #define ZETT_LN_LAUNCH(TPR, RO) hipLaunchKernelGGL((layernorm_rows_kernel<T, false, TPR, RO>), grid, dim3(256), 0, st, in, H, rows, H, gamma, beta, eps, of, ol, stats, (float*)nullptr, LnEmbed{}, 0, readout)
@@ -815,6 +820,13 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     // weights and normalises in its epilogue.  gemm4d only: off when a tile variant is forced.
     const bool fold = h->ln_fold && !std::is_same<T, float>::value && h->gemm_variant == 0 && H % 128 == 0 && H >= 512 &&
                       (int)h->fold_up.size() == c.layers;
+    // 16-bit residual stream (r4): with the fold on, the encoder's hidden state travels ONLY as the 16-bit copy of the
+    // pre-LayerNorm sum (+ statistics): the producers read their residual rows from it (LN16 epilogue: 4 instead of 10 bytes
+    // per element, 16-byte accesses on both sides) and no fp32 sum is written; Zt and Ct alternate as its buffers (Ct is free
+    // until the readout).  f16 only by default: the rounding of the stream is 2^-11 per layer there (rel-L2 of the outputs
+    // 0.8e-3 -> 1.0e-3 against a tolerance of 2.5e-3), in bf16 2^-8 would leave the tolerance.
+    const bool lo_stream = fold && c.layers >= 1 && sizeof(T) == 2 &&
+                           (h->residual_lo == 2 || (h->residual_lo == 1 && std::is_same<T, f16_t>::value));
     const size_t ws_parts = fold ? (size_t)(H / 128) * (size_t)MC * sizeof(float2) : 0;
     if (int rc = h->lnparts.reserve(ws_parts)) return rc;
     float2* PARTS = h->lnparts.as<float2>();
@@ -898,12 +910,12 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         if (pairs) {
             LnEmbed pe = emb;
             pe.tok_slot = p.pair_tslot; pe.tok_pos = p.pair_pos; pe.tok_row = nullptr;
-            embed_ln(pe, P, 0, Zt, hs_stats, hs_sum);
+            embed_ln(pe, P, 0, Zt, hs_stats, lo_stream ? (float*)nullptr : hs_sum);
             hipLaunchKernelGGL(pair_rows_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, tok0, r0, rows, p, brow_pair);
             R.check("pair_rows");
             h->stats.distinct_positions = P;
         } else {
-            embed_ln(emb, m, tok0, Zt, hs_stats, hs_sum);
+            embed_ln(emb, m, tok0, Zt, hs_stats, lo_stream ? (float*)nullptr : hs_sum);
         }
 
         int zrows = m;            // rows of the current hidden state: m, or `rows` (position 0 only) in a position-0-only last layer
@@ -956,20 +968,30 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             float* s1 = other(hs_sum);
             float* st1 = other_stats(hs_stats);
             GemmEpilogue<T> eo = R.epi();
-            eo.bias = R.Wf(lp + "attention.output.dense.bias"); eo.residual = hs_sum; eo.ld_res = H;
-            eo.res_stats = hs_stats; eo.res_gamma = hs_gamma; eo.res_beta = hs_beta;
+            eo.bias = R.Wf(lp + "attention.output.dense.bias");
             if (pairs && l == 0) eo.res_index = brow_pair;       // hs_sum / hs_stats are still per pair here
-            eo.out_f32 = s1; eo.ld_f32 = H;
-            if (fold) { eo.out_lo = Zt; eo.ld_lo = H; eo.stats_part = PARTS; eo.ld_part = (int)MC; }
+            if (lo_stream) {
+                // the hidden state is Zt: the embeddings' LayerNorm output itself (layer 0: used as stored), or the raw 16-bit
+                // sum of the previous layer with its statistics; the new sum goes to Ct
+                eo.residual_lo = Zt; eo.ld_res_lo = H;
+                if (raw) { eo.res_stats = hs_stats; eo.res_gamma = hs_gamma; eo.res_beta = hs_beta; }
+                eo.out_lo = Ct; eo.ld_lo = H; eo.stats_part = PARTS; eo.ld_part = (int)MC;
+            } else {
+                eo.residual = hs_sum; eo.ld_res = H;
+                eo.res_stats = hs_stats; eo.res_gamma = hs_gamma; eo.res_beta = hs_beta;
+                eo.out_f32 = s1; eo.ld_f32 = H;
+                if (fold) { eo.out_lo = Zt; eo.ld_lo = H; eo.stats_part = PARTS; eo.ld_part = (int)MC; }
+            }
             R.gemm(CTX, H, R.Wlo(lp + "attention.output.dense.weight"), H, zrows, H, H, eo);
             const float* g1 = R.Wf(lp + "attention.output.LayerNorm.weight");
             const float* b1 = R.Wf(lp + "attention.output.LayerNorm.bias");
+            const T* mid = lo_stream ? Ct : Zt;                  // 16-bit operand of intermediate.dense
             GemmEpilogue<T> ei = R.epi();
             ei.act = ACT_GELU_ERF; ei.out_lo = BIG; ei.ld_lo = I;
             if (fold) {          // the attention-output LayerNorm is folded into intermediate.dense
                 R.ln_stats(PARTS, (int)MC, zrows, c.ln_eps_encoder, st1);
                 ei.bias = h->fold_up[l].b; ei.fold_stats = st1; ei.fold_c = h->fold_up[l].c;
-                R.gemm(Zt, H, (const T*)h->fold_up[l].w, H, zrows, I, H, ei);
+                R.gemm(mid, H, (const T*)h->fold_up[l].w, H, zrows, I, H, ei);
             } else {
                 R.layernorm(s1, zrows, g1, b1, c.ln_eps_encoder, nullptr, Zt, st1);
                 ei.bias = R.Wf(lp + "intermediate.dense.bias");
@@ -979,10 +1001,16 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             float* s2 = other(s1);
             float* st2 = other_stats(st1);
             GemmEpilogue<T> ef = R.epi();
-            ef.bias = R.Wf(lp + "output.dense.bias"); ef.residual = s1; ef.ld_res = H;
-            ef.res_stats = st1; ef.res_gamma = g1; ef.res_beta = b1;
-            ef.out_f32 = s2; ef.ld_f32 = H;
-            if (fold && !last) { ef.out_lo = Zt; ef.ld_lo = H; ef.stats_part = PARTS; ef.ld_part = (int)MC; }
+            ef.bias = R.Wf(lp + "output.dense.bias");
+            if (lo_stream) {      // (also in the last layer: the readout takes the 16-bit sum)
+                ef.residual_lo = Ct; ef.ld_res_lo = H; ef.res_stats = st1; ef.res_gamma = g1; ef.res_beta = b1;
+                ef.out_lo = Zt; ef.ld_lo = H; ef.stats_part = PARTS; ef.ld_part = (int)MC;
+            } else {
+                ef.residual = s1; ef.ld_res = H;
+                ef.res_stats = st1; ef.res_gamma = g1; ef.res_beta = b1;
+                ef.out_f32 = s2; ef.ld_f32 = H;
+                if (fold && !last) { ef.out_lo = Zt; ef.ld_lo = H; ef.stats_part = PARTS; ef.ld_part = (int)MC; }
+            }
             R.gemm(BIG, I, R.Wlo(lp + "output.dense.weight"), I, zrows, H, I, ef);
             hs_gamma = R.Wf(lp + "output.LayerNorm.weight");
             hs_beta = R.Wf(lp + "output.LayerNorm.bias");
@@ -1000,7 +1028,8 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         // (no encoder layer: the embeddings' LayerNorm is simply taken again for those rows)
         R.layernorm(hs_sum, rows, hs_gamma, hs_beta, c.ln_eps_encoder, Cf, Ct, nullptr,
                     LnReadout{c.predict_bias ? R.Wf("bias_projection.weight") : (const float*)nullptr,
-                              c.predict_bias ? R.Wf("bias_projection.bias") : (const float*)nullptr, out_bias + r0});
+                              c.predict_bias ? R.Wf("bias_projection.bias") : (const float*)nullptr, out_bias + r0},
+                    lo_stream ? (const T*)Zt : (const T*)nullptr);
         R.check("readout");
         const bool last_chunk = r1 == N;
         if (last_chunk && !R.rc) HIP_TRY(hipEventRecord(h->out_ready[ZETT_OUT_BIAS], st));      // out_bias complete (zett_stream_wait_output)
