@@ -338,9 +338,15 @@ def main():
         gather = RowGather(blocks, mode=gather_mode) if exchange else None
         ready = None if args.no_early_gather else engine.stream_wait_output
         outs = None
+        # the step's id matrices: every block retokenized at the head of the step, without a host round trip
+        # (zett_retokenize_async; the truncation count of all steps is asked for once, after the timed region)
+        sfms = ids_blocks if retok is None else [retok.run_async(*texts[k], seq_len) for k in range(len(blocks))]
+        if len(blocks) > 1:
+            ahead.wait_stream(torch.cuda.current_stream(device))      # behind this step's retokenization
         for k, b in enumerate(blocks):
-            sfm = ids_blocks[k] if retok is None else retok.run(*texts[k], seq_len)[0]
-            outs = engine.forward(sfm, src, lang_arg)
+            outs = engine.forward(sfms[k], src, lang_arg)
+            if k + 1 < len(blocks):
+                engine.prepare(sfms[k + 1], ahead)                    # the next block's plan runs under this block's forward (zett_forward_prepare)
             st_k = engine.stats()
             for key in acc:
                 acc[key] += st_k[key]
@@ -359,6 +365,7 @@ def main():
     gemm_ms = gemm_fl = 0.0
     launches = 0
     out = None
+    ahead = torch.cuda.Stream(device=device) if len(blocks) > 1 else None
     for _ in range(args.warmup):
         out = step()        # the previous outputs stay referenced while the next step runs, as in the timed loop: the
                             # caching allocator gets both output sets it will alternate between before the clock starts
@@ -376,6 +383,8 @@ def main():
     gemm_ms, gemm_fl, launches = acc["gemm_ms"], acc["gemm_flops_timed"], acc["gemm_launches"]
     timed_classes = {k: list(v) for k, v in classes.items()}
     torch.cuda.synchronize()   # (every step ends with its own all-gathers complete on the compute stream)
+    if retok is not None and retok.result() != 0:
+        raise SystemExit("a retokenized surface form was truncated")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -26,8 +26,9 @@
 extern "C" {
 #endif
 
-#define ZETT_ABI_VERSION 4      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range;
-                                   4: ZETT_RETOK_WORDPIECE (zett_retok_model gained piece_continuing, max_input_chars_per_word) */
+#define ZETT_ABI_VERSION 5      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range;
+                                   4: ZETT_RETOK_WORDPIECE (zett_retok_model gained piece_continuing, max_input_chars_per_word);
+                                   5: zett_forward_prepare, zett_retokenize_async / zett_retok_result */
 
 enum zett_status {
     ZETT_OK = 0,
@@ -139,6 +140,20 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
                  const void* source_embeddings, int src_dtype, int64_t v_src, int32_t lang_index,
                  float* out_in, float* out_out, float* out_bias, void* stream);
 
+/* How asynchronous zett_forward is.  The launches of a forward are sized by its PLAN (packed positions, distinct source ids,
+ * distinct (id, position) pairs: integers computed on the device from the surface forms), so zett_forward enqueues the plan
+ * (six small kernels), waits on the HOST for it and for its error word (ZETT_E_INDEX is returned synchronously, as the
+ * reference's IndexError is raised), enqueues the ~60 launches of the forward and returns while they run.  Made on `stream`
+ * itself, the plan sits behind whatever that stream still holds — a second zett_forward on the same stream waits for the
+ * whole first one before it can enqueue anything.  zett_forward_prepare removes that wait: it enqueues the plan of the NEXT
+ * zett_forward (same surface_forms pointer, n_rows, seq) on a stream the handle owns, behind the work `input_stream` holds NOW
+ * (the stream the surface forms were produced on — pass one that is not busy with an earlier forward, e.g. the stream the
+ * retokenizer ran on before the first forward was enqueued) and returns at once; plans live in two slots that forwards take
+ * in turn, so the plan of forward k+1 runs while the kernels of forward k read theirs (it waits for forward k-1 to release
+ * its slot).  The matching zett_forward then waits on the host for the plan only.  A prepared plan that the next
+ * zett_forward does not match is discarded.  The reference has no counterpart (XLA sizes nothing from data). */
+int zett_forward_prepare(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq, void* input_stream);
+
 int zett_get_stats(const zett_hypernet* h, zett_stats* out);
 
 /* Per-launch record of the GEMMs of the most recent zett_forward ("time_gemm" on: durations from HIP events recorded on
@@ -167,8 +182,8 @@ int zett_get_gemm_log(const zett_hypernet* h, zett_gemm_record* out, int64_t cap
  *     the outputs of its row (inf / NaN propagate through every residual add), so ZETT_RANGE_OUTPUT is the catch-all
  *     and the other bits say where it started;
  *   - zett_check_range waits for `stream`, reads the word of the most recent zett_forward on the handle and returns
- *     ZETT_E_RANGE if it is non-zero (0 otherwise); *flags (may be NULL) receives the word.  zett_forward itself
- *     stays asynchronous.  What to do on a hit is the caller's policy: the Python layer (zett_amd/hypernet.py)
+ *     ZETT_E_RANGE if it is non-zero (0 otherwise); *flags (may be NULL) receives the word.  zett_forward itself does not
+ *     wait for its kernels (see zett_forward_prepare for what it does wait for).  What to do on a hit is the caller's policy: the Python layer (zett_amd/hypernet.py)
  *     re-runs the call with bf16 operands (fp32's exponent range, same MFMA rate) and warns; a hit in BF16 / F32
  *     mode means the outputs are non-finite in the reference's own arithmetic too (non-finite inputs or weights).
  *     With zett_set_option("range_accumulate", 1) zett_forward no longer clears the word and zett_check_range clears it
@@ -200,6 +215,12 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
  * encoder's hidden state travels as the 16-bit copy of its pre-LayerNorm sum only — the residual GEMMs read their residual rows
  * from it and write no fp32 sum; 1 = in F16 mode (the stream is rounded to 11 significand bits per layer: inside the f16
  * tolerance), 2 = in BF16 mode too (8 bits: outside the bf16 tolerance, A/B only), 0 = fp32 residual stream),
+ * "concurrent_lanes" (0/1/2, default 0, A/B only: a call that is one chunk runs as two half-vocabulary chunks on two streams
+ * at once — the caller's and one the handle owns, forked behind the hoisted table and joined before zett_forward's work on
+ * `stream` ends — so that the partly filled last round of one chain's GEMMs can be filled by the other's; 1 = when the narrowest
+ * launches would leave > 8 % of fewer than four CU-rounds idle, the pair lever is not taken and "time_gemm" is off, 2 = always.
+ * Measured: 4 096-row shard of the 4096-wide hypernet (2.375 rounds) 8.85 -> 8.82 ms, every larger call slower: each 256x256
+ * tile owns its CU, the dispatcher gains only the partial rounds.  Same bits),
  * "attention_fast" (0/1, default 1, A/B only: rows of at most 8 packed positions
  * take the attention kernel's register-resident path), "pair_dedupe" (0/1, default 1: layer 0's
  * Q/K/V once per distinct (source id, position) pair; same bits either way), "ln_fold" (0/1/2, default 1: in the 16-bit
@@ -268,6 +289,18 @@ int zett_retok_destroy(zett_retok* r);
 int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* offsets,
                     int64_t n_tokens, int32_t maxlen, int32_t pad_id, int32_t* out,
                     int64_t* n_truncated, int64_t* bad_token, void* stream);
+
+/* The same without the two host round trips of zett_retokenize (which reads the text length, offsets[n_tokens], back before it
+ * launches, and the counts after): the caller passes n_text — it built the text — and the call returns as soon as its six
+ * kernels are enqueued on `stream`.  Counts and errors are collected by zett_retok_result, ONCE for all asynchronous calls
+ * since the previous query: it waits for the last of them, sums their truncated tokens into *n_truncated, and on a failure
+ * returns what zett_retokenize would (ZETT_E_KEY / ZETT_E_STATE) for the EARLIEST failing call, whose ordinal since the
+ * previous query goes to *bad_call and whose token index to *bad_token (both nullable; -1 when nothing failed).  The id
+ * matrices of the calls before the failing one are complete.  A synchronous zett_retokenize in between discards what the
+ * asynchronous calls before it reported.  The reference has no counterpart (its loop is host code). */
+int zett_retokenize_async(zett_retok* r, const uint8_t* token_chars, const int32_t* offsets, int64_t n_tokens, int64_t n_text,
+                          int32_t maxlen, int32_t pad_id, int32_t* out, void* stream);
+int zett_retok_result(zett_retok* r, int64_t* n_truncated, int64_t* bad_call, int64_t* bad_token);
 
 /* ---- training use of the forward ---------------------------------------------------------
  * Replaces: the hypernetwork forward inside the loss of the reference's train_step / eval_step (train.py:1007-1013,

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void chars_to_bytes_kernel(const uint8_t* __re
                                                              const int16_t* __restrict__ cp_to_byte,
                                                              int32_t* __restrict__ blk_count,      // MODE 0 out / MODE 1 in (scanned)
                                                              uint8_t* __restrict__ raw, uint32_t* __restrict__ raw_pos,
-                                                             int32_t* __restrict__ err_pos) {
+                                                             unsigned long long* __restrict__ err_pos, uint32_t call) {
     __shared__ int16_t s_tab[324];
     __shared__ int s_red[4];
     __shared__ uint8_t s_next[256];        // first byte of the following thread's span
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void chars_to_bytes_kernel(const uint8_t* __re
         if (c < 0x80) cp = c;
         else if (c >= 0xC2 && c <= 0xDF && (b[i + 1] & 0xC0) == 0x80 && base + i + 1 < n_text) cp = ((c & 0x1F) << 6) | (b[i + 1] & 0x3F);
         const int byte = (cp >= 0 && cp < 324) ? s_tab[cp] : -1;
-        if (byte < 0) atomicMin(err_pos, (int32_t)(base + i < 0x7fffffff ? base + i : 0x7ffffffe));
+        if (byte < 0) atomicMin(err_pos, ((unsigned long long)call << 32) | (uint32_t)(base + i < 0x7fffffff ? base + i : 0x7ffffffe));      // earliest call, then earliest position
         raw[pos] = (uint8_t)(byte < 0 ? 0 : byte);
         ++pos;
     }
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const u
                                                           const int32_t* __restrict__ raw_off, int64_t n_tokens,
                                                           int maxlen, int32_t pad_id, int32_t* __restrict__ out, int32_t* __restrict__ scratch,
                                                           unsigned long long* __restrict__ n_truncated,
-                                                          int32_t* __restrict__ err_unk) {
+                                                          unsigned long long* __restrict__ err_unk, uint32_t call) {
     __shared__ RetokLds L;
     __shared__ __attribute__((aligned(16))) uint8_t s_text[RT_TEXT_BYTES + 16];
     __shared__ __attribute__((aligned(8))) int32_t s_arena[RT_ARENA_WORDS];
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const u
             ok = segment_token<GlobalMem>(t, L, sg, len, n_sym, scr, w, pad_id);
         }
         if (!ok) {
-            atomicMax(err_unk, (int32_t)(tok < 0x7ffffffe ? tok + 1 : 0x7fffffff));
+            atomicMin(err_unk, ((unsigned long long)call << 32) | (uint32_t)(tok < 0x7ffffffe ? tok : 0x7ffffffe));      // earliest call, then earliest token
             return;
         }
         if (w.n > maxlen) atomicAdd(n_truncated, 1ull);      // zett/utils.py:683-685
@@ -525,7 +525,12 @@ struct zett_retok {
     zett::RetokTables t{};
     std::vector<void*> owned;
     zett::DevBuf raw, raw_pos, raw_off, blk, scratch, misc;
-    int32_t* host_pinned = nullptr;
+    int32_t* host_pinned = nullptr;      // [0..1] text length (sync entry point); [4..9] the three 64-bit result words; [12..17] their initial values
+    hipEvent_t done = nullptr;           // behind the last enqueued call's result copy
+    uint32_t calls = 0;                  // calls enqueued since the last result query (ordinal of the next call)
+    struct Call { const int32_t* offsets; int64_t n_tokens; };
+    std::vector<Call> recent;            // the calls since the last result query (for the token of a KeyError)
+    bool words_ready = false;            // the device result words hold their initial values
 };
 
 namespace zett {
@@ -655,7 +660,8 @@ int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
     t.kind = m->kind; t.unk_id = m->unk_id; t.fuse_unk = m->fuse_unk; t.byte_fallback = m->byte_fallback;
     t.ignore_merges = m->ignore_merges; t.max_piece_len = pt.max_len; t.max_word_chars = m->max_input_chars_per_word;
     t.unk_score = m->unigram_min_score - 10.0;   // tokenizers kUnkPenalty
-    HIP_TRY(hipHostMalloc((void**)&r->host_pinned, 64, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&r->host_pinned, 128, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
     *out = r;
     return 0;
 }
@@ -666,7 +672,107 @@ int zett_retok_destroy(zett_retok* r) {
     for (void* p : r->owned) (void)hipFree(p);
     for (zett::DevBuf* b : {&r->raw, &r->raw_pos, &r->raw_off, &r->blk, &r->scratch, &r->misc}) b->release();
     if (r->host_pinned) (void)hipHostFree(r->host_pinned);
+    if (r->done) (void)hipEventDestroy(r->done);
     delete r;
+    return 0;
+}
+
+// result words on the device (r->misc): [0] err_pos = (call << 32 | text position) of the first character outside the byte
+// table, [1] err_unk = (call << 32 | token) of the first token that needed a missing unk id, [2] tokens cut to maxlen —
+// accumulated over the calls since the last result query
+static int retok_reset_words(zett_retok* r, hipStream_t st) {
+    unsigned long long* init = (unsigned long long*)(r->host_pinned + 12);
+    init[0] = ~0ull; init[1] = ~0ull; init[2] = 0ull;
+    if (int rc = r->misc.reserve(64)) return rc;
+    HIP_TRY(hipMemcpyAsync(r->misc.p, init, 24, hipMemcpyHostToDevice, st));
+    r->words_ready = true;
+    r->calls = 0;
+    r->recent.clear();
+    return 0;
+}
+
+int zett_retokenize_async(zett_retok* r, const uint8_t* token_chars, const int32_t* offsets, int64_t n_tokens, int64_t n_text,
+                          int32_t maxlen, int32_t pad_id, int32_t* out, void* stream) {
+    using namespace zett;
+    if (!r) return fail(ZETT_E_INVALID, "null argument");
+    if (n_tokens < 0 || maxlen < 1 || n_text < 0 || n_text >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "bad shape");
+    if (n_tokens == 0) return 0;
+    if (!offsets || !out) return fail(ZETT_E_INVALID, "null argument");
+    if (n_text > 0 && !token_chars) return fail(ZETT_E_INVALID, "token_chars is null");
+    ZETT_ON_DEVICE(r->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (!r->words_ready) { if (int rc = retok_reset_words(r, st)) return rc; }
+    const int n_blocks = (int)((n_text + CH_PER_BLOCK - 1) / CH_PER_BLOCK);
+    if (int rc = r->raw.reserve((size_t)n_text + 16)) return rc;
+    if (int rc = r->raw_pos.reserve(((size_t)n_text + 1) * 4)) return rc;
+    if (int rc = r->raw_off.reserve(((size_t)n_tokens + 1) * 4)) return rc;
+    if (int rc = r->blk.reserve(((size_t)n_blocks + 2) * 2 * 4)) return rc;
+    if (int rc = r->scratch.reserve(((size_t)n_text * SCR_PER_BYTE + (size_t)n_tokens * SCR_FIXED + 64) * 4)) return rc;
+    int32_t* blk_count = r->blk.as<int32_t>();
+    int32_t* blk_scan = blk_count + n_blocks + 1;
+    unsigned long long* words = r->misc.as<unsigned long long>();
+    const uint32_t call = r->calls++;
+    r->recent.push_back({offsets, n_tokens});
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1024), dim3(256), 0, st, out, n_tokens * (int64_t)maxlen, pad_id);   // :662-666
+    if (n_blocks > 0) {
+        hipLaunchKernelGGL((chars_to_bytes_kernel<0>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
+                           blk_count, (uint8_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, call);
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, blk_count, blk_scan, (int64_t)n_blocks);
+        hipLaunchKernelGGL((chars_to_bytes_kernel<1>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
+                           blk_scan, r->raw.as<uint8_t>(), r->raw_pos.as<uint32_t>(), words, call);
+    } else {
+        HIP_TRY(hipMemsetAsync(blk_scan, 0, 8, st));
+    }
+    hipLaunchKernelGGL(token_raw_offsets_kernel, dim3((unsigned)((n_tokens + 1 + 255) / 256)), dim3(256), 0, st, offsets, n_tokens,
+                       n_text, r->raw_pos.as<uint32_t>(), blk_scan, n_blocks, r->raw_off.as<int32_t>());
+    hipLaunchKernelGGL(retok_tokens_kernel, dim3((unsigned)((n_tokens + 63) / 64)), dim3(64), 0, st, r->t, r->raw.as<uint8_t>(),
+                       r->raw_off.as<int32_t>(), n_tokens, maxlen, pad_id, out, r->scratch.as<int32_t>(), words + 2, words + 1, call);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(r->host_pinned + 4, words, 24, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(r->done, st));
+    return 0;
+}
+
+int zett_retok_result(zett_retok* r, int64_t* n_truncated, int64_t* bad_call, int64_t* bad_token) {
+    using namespace zett;
+    if (!r || !n_truncated) return fail(ZETT_E_INVALID, "null argument");
+    *n_truncated = 0;
+    if (bad_call) *bad_call = -1;
+    if (bad_token) *bad_token = -1;
+    if (r->calls == 0) return 0;
+    ZETT_ON_DEVICE(r->device);
+    HIP_TRY(hipEventSynchronize(r->done));
+    unsigned long long w[3];
+    memcpy(w, r->host_pinned + 4, 24);
+    const std::vector<zett_retok::Call> recent = r->recent;
+    r->words_ready = false;          // the next call starts from fresh words
+    r->calls = 0;
+    r->recent.clear();
+    if (w[0] != ~0ull) {                                       // KeyError: locate the token of the first bad character
+        const uint32_t call = (uint32_t)(w[0] >> 32);
+        const int32_t pos = (int32_t)(w[0] & 0xffffffffu);
+        int64_t lo = -1;
+        if (call < recent.size()) {
+            const auto& cl = recent[call];
+            std::vector<int32_t> ho((size_t)cl.n_tokens + 1);
+            HIP_TRY(hipMemcpy(ho.data(), cl.offsets, ((size_t)cl.n_tokens + 1) * 4, hipMemcpyDeviceToHost));
+            int64_t hi = cl.n_tokens;
+            lo = 0;                                            // last token with offset <= pos
+            while (lo + 1 < hi) { const int64_t mid = (lo + hi) / 2; if (ho[mid] <= pos) lo = mid; else hi = mid; }
+        }
+        if (bad_call) *bad_call = call;
+        if (bad_token) *bad_token = lo;
+        return fail(ZETT_E_KEY, "token %lld holds a character outside the byte-level table (text offset %d)", (long long)lo, pos);
+    }
+    if (w[1] != ~0ull) {
+        const int64_t tok = (int64_t)(w[1] & 0xffffffffu);
+        if (bad_call) *bad_call = (int64_t)(w[1] >> 32);
+        if (bad_token) *bad_token = tok;
+        if (r->t.kind == ZETT_RETOK_WORDPIECE)
+            return fail(ZETT_E_STATE, "WordPiece error: Missing [UNK] token from the vocabulary (token %lld)", (long long)tok);
+        return fail(ZETT_E_STATE, "Encountered an unknown token but `unk_id` is missing (token %lld)", (long long)tok);
+    }
+    *n_truncated = (int64_t)w[2];
     return 0;
 }
 
@@ -681,62 +787,18 @@ int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* of
     if (!offsets || !out) return fail(ZETT_E_INVALID, "null argument");
     ZETT_ON_DEVICE(r->device);
     hipStream_t st = (hipStream_t)stream;
+    if (r->calls) {                  // results of earlier asynchronous calls nobody asked for: drop them
+        int64_t t, c, b;
+        (void)zett_retok_result(r, &t, &c, &b);
+    }
     // total text length = offsets[n_tokens]
     int32_t* hp = r->host_pinned;
     HIP_TRY(hipMemcpyAsync(hp, offsets + n_tokens, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const int64_t n_text = hp[0];
     if (n_text < 0) return fail(ZETT_E_INVALID, "offsets must be non-decreasing from 0");
-    if (n_text > 0 && !token_chars) return fail(ZETT_E_INVALID, "token_chars is null");
-    const int n_blocks = (int)((n_text + CH_PER_BLOCK - 1) / CH_PER_BLOCK);
-    if (int rc = r->raw.reserve((size_t)n_text + 16)) return rc;
-    if (int rc = r->raw_pos.reserve(((size_t)n_text + 1) * 4)) return rc;
-    if (int rc = r->raw_off.reserve(((size_t)n_tokens + 1) * 4)) return rc;
-    if (int rc = r->blk.reserve(((size_t)n_blocks + 2) * 2 * 4)) return rc;
-    if (int rc = r->misc.reserve(64)) return rc;
-    if (int rc = r->scratch.reserve(((size_t)n_text * SCR_PER_BYTE + (size_t)n_tokens * SCR_FIXED + 64) * 4)) return rc;
-    int32_t* blk_count = r->blk.as<int32_t>();
-    int32_t* blk_scan = blk_count + n_blocks + 1;
-    int32_t* err_pos = r->misc.as<int32_t>();                 // [0] first bad text position
-    int32_t* err_unk = err_pos + 1;                           // [1] 1 + token that needed a missing unk id
-    unsigned long long* ntr = (unsigned long long*)(err_pos + 2);
-    hp[0] = 0x7fffffff; hp[1] = 0; hp[2] = 0; hp[3] = 0;
-    HIP_TRY(hipMemcpyAsync(err_pos, hp, 16, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(fill_i32_kernel, dim3(1024), dim3(256), 0, st, out, n_tokens * (int64_t)maxlen, pad_id);   // :662-666
-    if (n_blocks > 0) {
-        hipLaunchKernelGGL((chars_to_bytes_kernel<0>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
-                           blk_count, (uint8_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr);
-        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, blk_count, blk_scan, (int64_t)n_blocks);
-        hipLaunchKernelGGL((chars_to_bytes_kernel<1>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
-                           blk_scan, r->raw.as<uint8_t>(), r->raw_pos.as<uint32_t>(), err_pos);
-    } else {
-        HIP_TRY(hipMemsetAsync(blk_scan, 0, 8, st));
-    }
-    hipLaunchKernelGGL(token_raw_offsets_kernel, dim3((unsigned)((n_tokens + 1 + 255) / 256)), dim3(256), 0, st, offsets, n_tokens,
-                       n_text, r->raw_pos.as<uint32_t>(), blk_scan, n_blocks, r->raw_off.as<int32_t>());
-    hipLaunchKernelGGL(retok_tokens_kernel, dim3((unsigned)((n_tokens + 63) / 64)), dim3(64), 0, st, r->t, r->raw.as<uint8_t>(),
-                       r->raw_off.as<int32_t>(), n_tokens, maxlen, pad_id, out, r->scratch.as<int32_t>(), ntr, err_unk);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(hp, err_pos, 16, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (hp[0] != 0x7fffffff) {                                 // KeyError: locate the token of the first bad character
-        std::vector<int32_t> ho((size_t)n_tokens + 1);
-        HIP_TRY(hipMemcpy(ho.data(), offsets, ((size_t)n_tokens + 1) * 4, hipMemcpyDeviceToHost));
-        int64_t lo = 0, hi = n_tokens;                         // last token with offset <= pos
-        while (lo + 1 < hi) { const int64_t mid = (lo + hi) / 2; if (ho[mid] <= hp[0]) lo = mid; else hi = mid; }
-        if (bad_token) *bad_token = lo;
-        return fail(ZETT_E_KEY, "token %lld holds a character outside the byte-level table (text offset %d)", (long long)lo, hp[0]);
-    }
-    if (hp[1] != 0) {
-        if (bad_token) *bad_token = hp[1] - 1;
-        if (r->t.kind == ZETT_RETOK_WORDPIECE)
-            return fail(ZETT_E_STATE, "WordPiece error: Missing [UNK] token from the vocabulary (token %d)", hp[1] - 1);
-        return fail(ZETT_E_STATE, "Encountered an unknown token but `unk_id` is missing (token %d)", hp[1] - 1);
-    }
-    unsigned long long trunc;
-    memcpy(&trunc, hp + 2, 8);
-    *n_truncated = (int64_t)trunc;
-    return 0;
+    if (int rc = zett_retokenize_async(r, token_chars, offsets, n_tokens, n_text, maxlen, pad_id, out, stream)) return rc;
+    return zett_retok_result(r, n_truncated, nullptr, bad_token);
 }
 
 }  // extern "C"

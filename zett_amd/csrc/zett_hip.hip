@@ -76,21 +76,40 @@ struct zett_hypernet {
     int cls_only_last = 1;
     int pair_dedupe = 1;              // layer 0's Q/K/V once per distinct (source id, position) pair (do_forward)
     int residual_lo = 1;              // 16-bit residual stream of the encoder (gemm4d LN16 producers): 1 = in f16 mode, 2 = in bf16 mode too (A/B), 0 = fp32 stream
+    int concurrent_lanes = 0;         // a one-chunk call as TWO half-vocabulary chunks on two streams (do_forward): 0 never, 1 auto (when the narrow GEMMs
+                                      // of the call leave > 8 % of their last round of 256 CUs idle: the 4 096-row shards of 8 GPUs), 2 always
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};      // fork, lane 1: bias written / out_in written / done
     int attention_fast = 1;           // rows of <= 8 packed positions: keys / values fetched once, all keys of a query side by side (rowops.hip.h)
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
     int gemm4d_min_k = 512;           // 16-bit launches with K >= this take the four-wave direct-to-LDS tile (r2: with the streamlined epilogues it is ahead of gemm8r down to K = 768: +1.8 % on the XLM-R workload)
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
                                       // 7 = 256x256 four-wave direct-to-LDS, 8 = as 7 with the generic epilogue drain
     // workspace
-    DevBuf plan_i32, plan_u8, table, x0, yf, yt, big, pre, ctx, cf, ct, lnstats, lnparts;
+    // The plan of a forward (integers: packed positions, distinct ids, pairs) lives in one of TWO slots that forwards take in
+    // turn, so that the plan of the NEXT forward can be made (zett_forward_prepare, on plan_stream) while the kernels of the
+    // current one still read theirs.
+    struct PlanSlot {
+        DevBuf i32, u8;
+        int32_t* host = nullptr;          // pinned: row offsets [N+1], distinct ids, error word, distinct pairs
+        size_t host_ints = 0;
+        hipEvent_t done = nullptr;        // the plan's kernels and copies have run
+        hipEvent_t released = nullptr;    // the forward that used this slot has finished with it
+        const int32_t* sfm = nullptr;     // what the slot was prepared for (zett_forward_prepare), pending until a forward takes it
+        int64_t n_rows = 0;
+        int seq = 0;
+        bool pending = false;
+    } plan[2];
+    int plan_cur = 0;                 // slot of the most recent forward
+    hipStream_t plan_stream = nullptr;
+    hipEvent_t plan_fork = nullptr;
+    DevBuf table, x0, yf, yt, big, pre, ctx, cf, ct, lnstats, lnparts;
     hipEvent_t out_ready[2] = {nullptr, nullptr};      // zett_stream_wait_output: out_in / out_bias of the last forward complete
     bool out_recorded = false;
     int range_accumulate = 0;         // 1: zett_forward does not clear the range word, zett_check_range clears it after reading (a caller
                                       // that runs several asynchronous forwards and asks once at the end: zett_amd/sharding.py)
     int32_t* range_word = nullptr;    // device: zett_range_bits of the forward in flight (cleared when a forward starts)
     int32_t* range_host = nullptr;    // pinned: where zett_check_range / zett_finalize read it
-    int32_t* host_pinned = nullptr;
-    size_t host_pinned_ints = 0;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     std::vector<double> ev_flops;
@@ -212,15 +231,105 @@ static WorkspaceSizes workspace_sizes(const zett_config& c, size_t es, int seq, 
     WorkspaceSizes w{};
     if (cap <= 0) cap = chunk_token_cap(c, es);
     w.chunk_tokens = std::max<int64_t>(std::min<int64_t>(cap, std::max<int64_t>(Ttot, D)), seq + lam);
-    const size_t MC = (size_t)w.chunk_tokens, MCS = MC + 384;
+    const size_t MC = (size_t)w.chunk_tokens, MCS = MC + 768;       // (384 slack rows per lane: two concurrent lanes at most)
     const size_t wide = (size_t)std::max(c.intermediate, 3 * c.hidden);
     w.table = (size_t)D * c.hidden * 4;
     w.x0 = MCS * c.n_in_embd * es;
-    w.f32_rows = MC * c.hidden * 4;
+    w.f32_rows = MCS * c.hidden * 4;               // (the second lane's slice starts 384 rows behind the first one's rows)
     w.lo_rows = MCS * c.hidden * es;
     w.big = MCS * wide * es;
-    w.stats = 2 * MC * 2 * sizeof(float);          // (mean, rstd) per row: two LayerNorms in flight
+    w.stats = 2 * MCS * 2 * sizeof(float);         // (mean, rstd) per row: two LayerNorms in flight
     return w;
+}
+
+// Where the arrays of a plan lie in a slot (pure pointer arithmetic: the same answer when the plan is made and when a
+// forward takes it).  Pair plan (lever 4): only where it can pay — at least two encoder layers (layer 0 must not be the
+// position-0-only one), and a key space not much larger than the batch (a 250 k-id source vocabulary against 50 k rows
+// repeats few pairs and would pay for clearing and scanning 2 M flags).
+struct PlanLayout {
+    PlanArrays p{};
+    int32_t* scan_tmp = nullptr;
+    bool pair_plan = false;
+    int64_t PK = 0;
+};
+static PlanLayout plan_layout(const zett_hypernet* h, const zett_hypernet::PlanSlot& s, int64_t N, int seq) {
+    const zett_config& c = h->cfg;
+    const int lam = c.embed_lang ? 1 : 0;
+    const int V = c.original_vocab_size + c.n_extra;
+    const int64_t max_tok = N * (int64_t)(seq + lam);
+    PlanLayout L;
+    PlanArrays& p = L.p;
+    // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] tok_row[T] [pair plan] err[1] scan scratch
+    int32_t* base = s.i32.as<int32_t>();
+    p.row_count = base; base += N;
+    p.row_offset = base; base += N + 1;
+    p.id_flag = base; base += V;
+    p.id_slot = base; base += V + 1;
+    p.id_list = base; base += V;
+    p.tok_slot = base; base += max_tok;
+    p.tok_pos = base; base += max_tok;
+    p.tok_row = base; base += max_tok;
+    L.PK = pair_keys(c, seq);
+    L.pair_plan = h->pair_dedupe && c.layers >= 2 && L.PK <= std::max<int64_t>(4 * max_tok, (int64_t)1 << 23) && L.PK < (int64_t)0x7fffffff;
+    if (L.pair_plan) {
+        p.tok_pkey = base; base += max_tok;
+        p.tok_pair = base; base += max_tok;
+        p.pair_tslot = base; base += max_tok;
+        p.pair_pos = base; base += max_tok;
+        p.pair_flag = base; base += L.PK;
+        p.pair_slot = base; base += L.PK + 1;
+    }
+    p.err = base; base += 1;
+    L.scan_tmp = base;
+    p.row_uniform = s.u8.as<uint8_t>();
+    p.tok_key = p.row_uniform + N;
+    return L;
+}
+
+// The plan of one forward into slot s, on stream st: six small kernels, three scans, and the copy of the row offsets and the
+// three counters to pinned memory; s.done is recorded behind them.
+static int enqueue_plan(zett_hypernet* h, zett_hypernet::PlanSlot& s, const int32_t* sfm, int64_t N, int seq, hipStream_t st) {
+    const zett_config& c = h->cfg;
+    const int lam = c.embed_lang ? 1 : 0;
+    const int V = c.original_vocab_size + c.n_extra;
+    const int64_t max_tok = N * (int64_t)(seq + lam);
+    if (int rc = s.i32.reserve(plan_i32_bytes(c, N, seq))) return rc;
+    if (int rc = s.u8.reserve((size_t)N + (size_t)max_tok)) return rc;
+    const size_t need_ints = (size_t)N + 1 + 3;
+    if (s.host_ints < need_ints) {
+        if (s.host) (void)hipHostFree(s.host);
+        s.host = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&s.host, need_ints * 4, hipHostMallocDefault));
+        s.host_ints = need_ints;
+    }
+    if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    if (!s.released) HIP_TRY(hipEventCreateWithFlags(&s.released, hipEventDisableTiming));
+    const PlanLayout L = plan_layout(h, s, N, seq);
+    const PlanArrays& p = L.p;
+    HIP_TRY(hipMemsetAsync(p.id_flag, 0, (size_t)V * 4, st));
+    HIP_TRY(hipMemsetAsync(p.err, 0, 4, st));
+    if (L.pair_plan) HIP_TRY(hipMemsetAsync(p.pair_flag, 0, (size_t)L.PK * 4, st));
+    const int rb = (int)((N + 255) / 256);
+    hipLaunchKernelGGL(plan_rows_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
+    launch_exclusive_scan(p.row_count, p.row_offset, N, L.scan_tmp, st);
+    launch_exclusive_scan(p.id_flag, p.id_slot, (int64_t)V, L.scan_tmp, st);
+    hipLaunchKernelGGL(plan_tokens_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
+    if (L.pair_plan) {
+        launch_exclusive_scan(p.pair_flag, p.pair_slot, L.PK, L.scan_tmp, st);
+        hipLaunchKernelGGL(plan_pairs_kernel, dim3((unsigned)((max_tok + 255) / 256)), dim3(256), 0, st, N, p);
+    }
+    hipLaunchKernelGGL(plan_idlist_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, p);
+    HIP_TRY(hipGetLastError());
+    // the row offsets, the distinct-id count, the error word and the pair count to the host
+    int32_t* hoff = s.host;
+    HIP_TRY(hipMemcpyAsync(hoff, p.row_offset, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hoff + N + 1, p.id_slot + V, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hoff + N + 2, p.err, 4, hipMemcpyDeviceToHost, st));
+    hoff[N + 3] = 0;
+    if (L.pair_plan) HIP_TRY(hipMemcpyAsync(hoff + N + 3, p.pair_slot + L.PK, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(s.done, st));
+    s.sfm = sfm; s.n_rows = N; s.seq = seq;
+    return 0;
 }
 
 template <typename T>
@@ -266,12 +375,21 @@ int zett_destroy(zett_hypernet* h) {
         if (kv.second.lo && kv.second.lo != (void*)kv.second.f32) (void)hipFree(kv.second.lo);
     }
     for (void* p : h->owned) (void)hipFree(p);
-    for (DevBuf* b : {&h->plan_i32, &h->plan_u8, &h->table, &h->x0, &h->yf, &h->yt, &h->big, &h->pre, &h->ctx, &h->cf, &h->ct, &h->lnstats, &h->lnparts})
+    for (DevBuf* b : {&h->table, &h->x0, &h->yf, &h->yt, &h->big, &h->pre, &h->ctx, &h->cf, &h->ct, &h->lnstats, &h->lnparts})
         b->release();
-    if (h->host_pinned) (void)hipHostFree(h->host_pinned);
+    for (auto& ps : h->plan) {
+        ps.i32.release(); ps.u8.release();
+        if (ps.host) (void)hipHostFree(ps.host);
+        if (ps.done) (void)hipEventDestroy(ps.done);
+        if (ps.released) (void)hipEventDestroy(ps.released);
+    }
+    if (h->plan_stream) (void)hipStreamDestroy(h->plan_stream);
+    if (h->plan_fork) (void)hipEventDestroy(h->plan_fork);
     if (h->range_word) (void)hipFree(h->range_word);
     if (h->range_host) (void)hipHostFree(h->range_host);
     for (hipEvent_t e : h->out_ready) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->lane_ev) if (e) (void)hipEventDestroy(e);
+    if (h->lane_stream) (void)hipStreamDestroy(h->lane_stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
     return 0;
@@ -455,6 +573,9 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "residual_lo") {
         if (value < 0 || value > 2) return fail(ZETT_E_INVALID, "residual_lo must be 0 (fp32 residual stream), 1 (16-bit stream in f16 mode) or 2 (in bf16 mode too)");
         h->residual_lo = (int)value;
+    } else if (k == "concurrent_lanes") {
+        if (value < 0 || value > 2) return fail(ZETT_E_INVALID, "concurrent_lanes must be 0 (never), 1 (auto) or 2 (whenever a call is one chunk of >= 512 rows)");
+        h->concurrent_lanes = (int)value;
     } else if (k == "attention_fast") {
         h->attention_fast = value != 0;
     } else if (k == "ln_fold") {
@@ -486,7 +607,7 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
     const int64_t max_tok = n_rows * (int64_t)(seq + (c.embed_lang ? 1 : 0));
     // worst case of the plan: no pad position, every position a different source id
     const WorkspaceSizes w = workspace_sizes(c, elt_size(h->precision), seq, max_tok, std::min<int64_t>(V, max_tok), h->max_chunk_tokens);
-    const size_t parts = c.hidden % 128 == 0 ? (size_t)(c.hidden / 128) * (size_t)w.chunk_tokens * 8 : 0;      // LayerNorm-fold partials
+    const size_t parts = c.hidden % 128 == 0 ? (size_t)(c.hidden / 128) * ((size_t)w.chunk_tokens + 768) * 8 : 0;      // LayerNorm-fold partials
     *out_bytes = (int64_t)(w.total() + parts + plan_i32_bytes(c, n_rows, seq) + (size_t)n_rows + (size_t)max_tok);
     return 0;
 }
@@ -528,6 +649,33 @@ int zett_check_range(zett_hypernet* h, void* stream, int32_t* flags) {
                 (w & ZETT_RANGE_ACTIVATION) ? " a 16-bit activation (Q/K/V, FFN intermediate or the operand copy of the residual sum) beyond the half range;" : "",
                 (w & ZETT_RANGE_OUTPUT) ? " non-finite predicted embeddings;" : "",
                 h->precision == ZETT_PREC_F16 ? "f16: re-run with ZETT_PREC_BF16" : h->precision == ZETT_PREC_BF16 ? "bf16" : "f32");
+}
+
+int zett_forward_prepare(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq, void* input_stream) {
+    if (!h) return fail(ZETT_E_INVALID, "null handle");
+    if (!h->finalized) return fail(ZETT_E_STATE, "zett_finalize has not been called");
+    const zett_config& c = h->cfg;
+    if (n_rows < 0 || seq < 1) return fail(ZETT_E_INVALID, "bad surface-form shape [%lld, %d]", (long long)n_rows, seq);
+    if (n_rows == 0) return 0;
+    if (!surface_forms) return fail(ZETT_E_INVALID, "null tensor argument");
+    if (n_rows * (int64_t)(seq + 1) >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many positions for one call");
+    (void)c;
+    ZETT_ON_DEVICE(h->device);
+    if (!h->plan_stream) {      // highest priority: the plan's small workgroups must get CUs while a forward's GEMM tiles own the chip
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&h->plan_stream, hipStreamNonBlocking, greatest));
+    }
+    if (!h->plan_fork) HIP_TRY(hipEventCreateWithFlags(&h->plan_fork, hipEventDisableTiming));
+    zett_hypernet::PlanSlot& ps = h->plan[h->plan_cur ^ 1];
+    if (ps.pending) HIP_TRY(hipEventSynchronize(ps.done));           // replaces a prepared plan nobody took
+    // behind the surface forms (whatever input_stream holds now) and behind the forward that last read this slot
+    HIP_TRY(hipEventRecord(h->plan_fork, (hipStream_t)input_stream));
+    HIP_TRY(hipStreamWaitEvent(h->plan_stream, h->plan_fork, 0));
+    if (ps.released) HIP_TRY(hipStreamWaitEvent(h->plan_stream, ps.released, 0));
+    if (int rc = enqueue_plan(h, ps, surface_forms, n_rows, seq, h->plan_stream)) return rc;
+    ps.pending = true;
+    return 0;
 }
 
 int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq,
@@ -730,68 +878,27 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     h->gemm_log.clear();
 
     // ---- plan ---------------------------------------------------------------------
-    // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] tok_row[T] err[1] scan scratch
-    if (int rc = h->plan_i32.reserve(plan_i32_bytes(c, N, seq))) return rc;
-    if (int rc = h->plan_u8.reserve((size_t)N + (size_t)max_tok)) return rc;
-    PlanArrays p{};
-    int32_t* base = h->plan_i32.as<int32_t>();
-    p.row_count = base; base += N;
-    p.row_offset = base; base += N + 1;
-    p.id_flag = base; base += V;
-    p.id_slot = base; base += V + 1;
-    p.id_list = base; base += V;
-    p.tok_slot = base; base += max_tok;
-    p.tok_pos = base; base += max_tok;
-    p.tok_row = base; base += max_tok;
-    // Pair plan (lever 4, below): only where it can pay — at least two encoder layers (layer 0 must not be the position-0-only
-    // one), and a key space not much larger than the batch (a 250 k-id source vocabulary against 50 k rows repeats few pairs
-    // and would pay for clearing and scanning 2 M flags).
-    const int64_t PK = pair_keys(c, seq);
-    const bool pair_plan = h->pair_dedupe && c.layers >= 2 && PK <= std::max<int64_t>(4 * max_tok, (int64_t)1 << 23) && PK < (int64_t)0x7fffffff;
-    if (pair_plan) {
-        p.tok_pkey = base; base += max_tok;
-        p.tok_pair = base; base += max_tok;
-        p.pair_tslot = base; base += max_tok;
-        p.pair_pos = base; base += max_tok;
-        p.pair_flag = base; base += PK;
-        p.pair_slot = base; base += PK + 1;
+    // The slot the previous forward did not use.  Prepared for exactly this call (zett_forward_prepare): its plan ran on the
+    // plan stream, the host waits for THAT (not for earlier work on st) and st is ordered behind it.  Otherwise the plan is
+    // made here, on st, and the host waits for it — and so for whatever was enqueued on st before.
+    zett_hypernet::PlanSlot& ps = h->plan[h->plan_cur ^ 1];
+    if (ps.pending && ps.sfm == sfm && ps.n_rows == N && ps.seq == seq) {
+        HIP_TRY(hipStreamWaitEvent(st, ps.done, 0));
+    } else {
+        if (ps.pending) HIP_TRY(hipEventSynchronize(ps.done));       // a prepared plan nobody took: let it finish before the slot is reused
+        if (ps.released) HIP_TRY(hipStreamWaitEvent(st, ps.released, 0));      // (the forward before the previous one read this slot)
+        if (int rc = enqueue_plan(h, ps, sfm, N, seq, st)) return rc;
     }
-    p.err = base; base += 1;
-    int32_t* scan_tmp = base;
-    p.row_uniform = h->plan_u8.as<uint8_t>();
-    p.tok_key = p.row_uniform + N;
-    HIP_TRY(hipMemsetAsync(p.id_flag, 0, (size_t)V * 4, st));
-    HIP_TRY(hipMemsetAsync(p.err, 0, 4, st));
+    ps.pending = false;
+    h->plan_cur ^= 1;
+    const PlanLayout PL = plan_layout(h, ps, N, seq);
+    const PlanArrays& p = PL.p;
+    const bool pair_plan = PL.pair_plan;
     if (!h->range_accumulate) HIP_TRY(hipMemsetAsync(h->range_word, 0, 4, st));          // range guard: the word of THIS forward (zett_check_range)
     for (hipEvent_t& e : h->out_ready)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (pair_plan) HIP_TRY(hipMemsetAsync(p.pair_flag, 0, (size_t)PK * 4, st));
-    const int rb = (int)((N + 255) / 256);
-    hipLaunchKernelGGL(plan_rows_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
-    launch_exclusive_scan(p.row_count, p.row_offset, N, scan_tmp, st);
-    launch_exclusive_scan(p.id_flag, p.id_slot, (int64_t)V, scan_tmp, st);
-    hipLaunchKernelGGL(plan_tokens_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
-    if (pair_plan) {
-        launch_exclusive_scan(p.pair_flag, p.pair_slot, PK, scan_tmp, st);
-        hipLaunchKernelGGL(plan_pairs_kernel, dim3((unsigned)((max_tok + 255) / 256)), dim3(256), 0, st, N, p);
-    }
-    hipLaunchKernelGGL(plan_idlist_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, p);
-    HIP_TRY(hipGetLastError());
-    // bring the row offsets, the distinct-id count and the error word to the host
-    const size_t need_ints = (size_t)N + 1 + 3;
-    if (h->host_pinned_ints < need_ints) {
-        if (h->host_pinned) (void)hipHostFree(h->host_pinned);
-        h->host_pinned = nullptr;
-        HIP_TRY(hipHostMalloc((void**)&h->host_pinned, need_ints * 4, hipHostMallocDefault));
-        h->host_pinned_ints = need_ints;
-    }
-    int32_t* hoff = h->host_pinned;
-    HIP_TRY(hipMemcpyAsync(hoff, p.row_offset, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(hoff + N + 1, p.id_slot + V, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(hoff + N + 2, p.err, 4, hipMemcpyDeviceToHost, st));
-    hoff[N + 3] = 0;
-    if (pair_plan) HIP_TRY(hipMemcpyAsync(hoff + N + 3, p.pair_slot + PK, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventSynchronize(ps.done));
+    int32_t* hoff = ps.host;
     if (hoff[N + 2] != 0)
         return fail(ZETT_E_INDEX, "surface-form row %d holds an id outside [0, %d) (original_vocab_size %d + %d fallback rows)",
                     hoff[N + 2] - 1, V, c.original_vocab_size, c.n_extra);
@@ -804,7 +911,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     // ---- workspace ------------------------------------------------------------------
     const WorkspaceSizes ws = workspace_sizes(c, sizeof(T), seq, Ttot, D, h->max_chunk_tokens);
     const int64_t MC = ws.chunk_tokens;
-    const size_t MCS = (size_t)MC + 384;      // slack rows: the 384-row GEMM tile reads whole tiles of A
+    const size_t MCS = (size_t)MC + 768;      // slack rows: the 384-row GEMM tile reads whole tiles of A (per lane, two lanes)
     if (int rc = h->table.reserve(ws.table)) return rc;
     if (int rc = h->x0.reserve(ws.x0)) return rc;
     if (int rc = h->yf.reserve(ws.f32_rows)) return rc;
@@ -827,7 +934,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     // 0.8e-3 -> 1.0e-3 against a tolerance of 2.5e-3), in bf16 2^-8 would leave the tolerance.
     const bool lo_stream = fold && c.layers >= 1 && sizeof(T) == 2 &&
                            (h->residual_lo == 2 || (h->residual_lo == 1 && std::is_same<T, f16_t>::value));
-    const size_t ws_parts = fold ? (size_t)(H / 128) * (size_t)MC * sizeof(float2) : 0;
+    const size_t ws_parts = fold ? (size_t)(H / 128) * MCS * sizeof(float2) : 0;
     if (int rc = h->lnparts.reserve(ws_parts)) return rc;
     float2* PARTS = h->lnparts.as<float2>();
     float* TBL = h->table.as<float>();
@@ -844,7 +951,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     // LayerNorm output (the next residual epilogue) recomputes it with ln_affine from the sum it reads anyway.
     // Zf and PRE alternate as the sum buffers, STa and STb as their statistics.
     float* STa = h->lnstats.as<float>();
-    float* STb = STa + 2 * (size_t)MC;
+    float* STb = STa + 2 * MCS;
 
     Runner<T> R{h, st};
     R.a_rows_readable = (long)MCS;
@@ -873,14 +980,34 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     const float* lang_vec = lam ? R.Wf("lang_embeddings.weight") + (size_t)lang_index * H : nullptr;
     const float scaling = 1.0f / std::sqrt((float)(H / c.heads));
     const int groups = (H + 511) / 512;
-    int64_t r0 = 0;
-    while (r0 < N && !R.rc) {
-        int64_t r1 = r0 + 1;
-        while (r1 < N && (int64_t)hoff[r1 + 1] - hoff[r0] <= MC) ++r1;
+    // One chunk = vocabulary rows [r0, r1) on one LANE: a stream and a slice of every workspace buffer starting `off` rows in.
+    // Normally there is one lane (the caller's stream, offset 0) and the chunks follow each other.  A call that is ONE chunk
+    // can instead run as two half-vocabulary chunks on two lanes at once (r4, "concurrent_lanes"): rows are independent, so the
+    // two chains of launches interleave on the chip workgroup by workgroup — the last, partly filled round of 256 CUs of one
+    // chain's GEMM is filled by the other's, and one chain's prologues / epilogues run under the other's K loops.  That is what
+    // a 4 096-row shard of 8 GPUs needs: its N = 4096 launches are 608 tiles = 2.375 rounds.  (Same bits: a row's arithmetic
+    // does not depend on the chunk it is in.)  ev_mode: 0 = no completion events, 1 = record out_ready on this lane's stream,
+    // 2 = lane 1 of a pair (records lane_ev[1..3]), 3 = lane 0 of a pair (out_ready follows lane 1's events).
+    struct Lane { hipStream_t st; size_t off; };
+    const size_t ld_parts = MCS;
+    auto run_chunk = [&](int64_t r0, int64_t r1, const Lane& lane, int ev_mode) -> int {
         const int rows = (int)(r1 - r0);
         const int tok0 = hoff[r0];
         const int m = hoff[r1] - tok0;
         h->stats.chunks += 1;
+        hipStream_t st = lane.st;
+        R.st = lane.st;
+        R.a_rows_readable = (long)(MCS - lane.off);
+        float* const Zf = h->yf.as<float>() + lane.off * H;
+        T* const Zt = h->yt.as<T>() + lane.off * H;
+        T* const BIG = h->big.as<T>() + lane.off * (size_t)std::max(I, 3 * H);
+        float* const PRE = h->pre.as<float>() + lane.off * H;
+        T* const CTX = h->ctx.as<T>() + lane.off * H;
+        float* const Cf = h->cf.as<float>() + lane.off * H;
+        T* const Ct = h->ct.as<T>() + lane.off * H;
+        float* const STa = h->lnstats.as<float>() + 2 * lane.off;
+        float* const STb = STa + 2 * MCS;
+        float2* const PARTS = h->lnparts.as<float2>() + lane.off;
 
         LnEmbed emb{TBL, p.tok_slot, p.tok_pos, R.Wf("model.embeddings.token_type_embeddings.weight"),
                     R.Wf("model.embeddings.position_embeddings.weight"), lang_vec, seq, p.tok_row, p.row_offset, r0, rows};
@@ -975,12 +1102,12 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 // sum of the previous layer with its statistics; the new sum goes to Ct
                 eo.residual_lo = Zt; eo.ld_res_lo = H;
                 if (raw) { eo.res_stats = hs_stats; eo.res_gamma = hs_gamma; eo.res_beta = hs_beta; }
-                eo.out_lo = Ct; eo.ld_lo = H; eo.stats_part = PARTS; eo.ld_part = (int)MC;
+                eo.out_lo = Ct; eo.ld_lo = H; eo.stats_part = PARTS; eo.ld_part = (int)ld_parts;
             } else {
                 eo.residual = hs_sum; eo.ld_res = H;
                 eo.res_stats = hs_stats; eo.res_gamma = hs_gamma; eo.res_beta = hs_beta;
                 eo.out_f32 = s1; eo.ld_f32 = H;
-                if (fold) { eo.out_lo = Zt; eo.ld_lo = H; eo.stats_part = PARTS; eo.ld_part = (int)MC; }
+                if (fold) { eo.out_lo = Zt; eo.ld_lo = H; eo.stats_part = PARTS; eo.ld_part = (int)ld_parts; }
             }
             R.gemm(CTX, H, R.Wlo(lp + "attention.output.dense.weight"), H, zrows, H, H, eo);
             const float* g1 = R.Wf(lp + "attention.output.LayerNorm.weight");
@@ -989,7 +1116,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             GemmEpilogue<T> ei = R.epi();
             ei.act = ACT_GELU_ERF; ei.out_lo = BIG; ei.ld_lo = I;
             if (fold) {          // the attention-output LayerNorm is folded into intermediate.dense
-                R.ln_stats(PARTS, (int)MC, zrows, c.ln_eps_encoder, st1);
+                R.ln_stats(PARTS, (int)ld_parts, zrows, c.ln_eps_encoder, st1);
                 ei.bias = h->fold_up[l].b; ei.fold_stats = st1; ei.fold_c = h->fold_up[l].c;
                 R.gemm(mid, H, (const T*)h->fold_up[l].w, H, zrows, I, H, ei);
             } else {
@@ -1004,12 +1131,12 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             ef.bias = R.Wf(lp + "output.dense.bias");
             if (lo_stream) {      // (also in the last layer: the readout takes the 16-bit sum)
                 ef.residual_lo = Ct; ef.ld_res_lo = H; ef.res_stats = st1; ef.res_gamma = g1; ef.res_beta = b1;
-                ef.out_lo = Zt; ef.ld_lo = H; ef.stats_part = PARTS; ef.ld_part = (int)MC;
+                ef.out_lo = Zt; ef.ld_lo = H; ef.stats_part = PARTS; ef.ld_part = (int)ld_parts;
             } else {
                 ef.residual = s1; ef.ld_res = H;
                 ef.res_stats = st1; ef.res_gamma = g1; ef.res_beta = b1;
                 ef.out_f32 = s2; ef.ld_f32 = H;
-                if (fold && !last) { ef.out_lo = Zt; ef.ld_lo = H; ef.stats_part = PARTS; ef.ld_part = (int)MC; }
+                if (fold && !last) { ef.out_lo = Zt; ef.ld_lo = H; ef.stats_part = PARTS; ef.ld_part = (int)ld_parts; }
             }
             R.gemm(BIG, I, R.Wlo(lp + "output.dense.weight"), I, zrows, H, I, ef);
             hs_gamma = R.Wf(lp + "output.LayerNorm.weight");
@@ -1017,11 +1144,11 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             hs_sum = s2; hs_stats = st2;
             // (the last layer's output LayerNorm is the readout below: position 0 only, whatever the layer computed)
             if (!last) {
-                if (fold) { R.ln_stats(PARTS, (int)MC, zrows, c.ln_eps_encoder, st2); raw = true; }
+                if (fold) { R.ln_stats(PARTS, (int)ld_parts, zrows, c.ln_eps_encoder, st2); raw = true; }
                 else R.layernorm(s2, zrows, hs_gamma, hs_beta, c.ln_eps_encoder, nullptr, Zt, st2);
             }
         }
-        if (R.rc) break;
+        if (R.rc) return R.rc;
 
         // position-0 readout + bias head (modeling_hypernet.py:231-234, 260-265) = the last LayerNorm, on the first `rows`
         // buffer rows: Cf = fp32 hidden[:,0] (residual of the heads' ProjectorBlocks), Ct its operand copy, bias head fused.
@@ -1031,14 +1158,17 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                               c.predict_bias ? R.Wf("bias_projection.bias") : (const float*)nullptr, out_bias + r0},
                     lo_stream ? (const T*)Zt : (const T*)nullptr);
         R.check("readout");
-        const bool last_chunk = r1 == N;
-        if (last_chunk && !R.rc) HIP_TRY(hipEventRecord(h->out_ready[ZETT_OUT_BIAS], st));      // out_bias complete (zett_stream_wait_output)
+        if (!R.rc) {          // out_bias complete (zett_stream_wait_output)
+            if (ev_mode == 2) HIP_TRY(hipEventRecord(h->lane_ev[1], st));
+            if (ev_mode == 3) HIP_TRY(hipStreamWaitEvent(st, h->lane_ev[1], 0));
+            if (ev_mode == 1 || ev_mode == 3) HIP_TRY(hipEventRecord(h->out_ready[ZETT_OUT_BIAS], st));
+        }
 
         // output heads (modeling_hypernet.py:236-258)
         // LayerNorm fold of the heads (r3): the ProjectorBlock's LayerNorm in front of each final Linear is not a launch either
         const bool fold_heads = fold && h->ln_fold == 1 && h->fold_head_in.w != nullptr;
         {
-            if (fold_heads) R.projector("output_projection.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX, PARTS, (int)MC, STa);
+            if (fold_heads) R.projector("output_projection.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX, PARTS, (int)ld_parts, STa);
             else R.projector("output_projection.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX);
             GemmEpilogue<T> e = R.epi();
             e.bias = fold_heads ? h->fold_head_in.b : R.Wf("output_projection.1.bias");
@@ -1049,10 +1179,14 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             const int width = c.single_head ? EIN : E;
             if (c.single_head && c.separate_out) { e.split_col = E; e.out_f32_b = out_out + (size_t)r0 * E; }
             R.gemm(CTX, H, fold_heads ? (const T*)h->fold_head_in.w : R.Wlo("output_projection.1.weight"), H, rows, width, H, e);
-            if (last_chunk && !R.rc) HIP_TRY(hipEventRecord(h->out_ready[ZETT_OUT_IN], st));     // out_in complete: the second head runs behind it
+            if (!R.rc) {      // out_in complete: the second head runs behind it
+                if (ev_mode == 2) HIP_TRY(hipEventRecord(h->lane_ev[2], st));
+                if (ev_mode == 3) HIP_TRY(hipStreamWaitEvent(st, h->lane_ev[2], 0));
+                if (ev_mode == 1 || ev_mode == 3) HIP_TRY(hipEventRecord(h->out_ready[ZETT_OUT_IN], st));
+            }
         }
         if (c.separate_out && !c.single_head) {
-            if (fold_heads) R.projector("output_projection_out.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX, PARTS, (int)MC, STa);
+            if (fold_heads) R.projector("output_projection_out.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX, PARTS, (int)ld_parts, STa);
             else R.projector("output_projection_out.0.", Ct, Cf, rows, BIG, PRE, nullptr, CTX);
             GemmEpilogue<T> e = R.epi();
             e.bias = fold_heads ? h->fold_head_out.b : R.Wf("output_projection_out.1.bias");
@@ -1062,9 +1196,49 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             e.out_f32 = out_out + (size_t)r0 * E; e.ld_f32 = E; e.range_final = 1;
             R.gemm(CTX, H, fold_heads ? (const T*)h->fold_head_out.w : R.Wlo("output_projection_out.1.weight"), H, rows, E, H, e);
         }
-        r0 = r1;
+        return R.rc;
+    };
+    // two lanes?  Only a call that is one chunk and would not take the pair lever (which needs the whole call in one chunk and is
+    // worth more).  auto = the launches of width H (attention output, FFN down: the fewest tiles) would leave more than 8 % of the
+    // CU-rounds they occupy idle, on a hypernet wide enough for that to be the cost (H >= 1024), and per-launch timing is off
+    // (concurrent launches share the chip: their HIP-event durations overlap and would be counted twice).
+    // Measured (r4, same box, Mistral shape): 4 096 rows 9.25 -> 9.11 ms; 8 192 rows 16.14 -> 16.12; 16 384 rows and every full
+    // vocabulary slower (28.9 -> 29.8; headline 53.1 -> 55.2 with the pair lever lost): the dispatcher interleaves the two
+    // chains' workgroups, but each 256x256 tile still owns its CU, so only the partial last rounds gain.
+    bool two_lanes = false;
+    if (h->concurrent_lanes && Ttot <= MC && N >= 512) {
+        const int Pn = pair_plan ? hoff[N + 3] : 0;
+        const bool pairs_taken = pair_plan && Pn > 0 && (int64_t)Pn * 100 <= Ttot * 85;
+        const double r = (double)((Ttot + 255) / 256) * (double)((H + 255) / 256) / 256.0;
+        two_lanes = h->concurrent_lanes == 2 ||
+                    (!pairs_taken && !h->time_gemm && H >= 1024 && r < 4.0 && (std::ceil(r) - r) / std::ceil(r) > 0.08);
     }
+    if (two_lanes) {
+        if (!h->lane_stream) HIP_TRY(hipStreamCreateWithFlags(&h->lane_stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : h->lane_ev)
+            if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        // the split is a multiple of 256 rows (the position-0-only last layer and the heads keep their number of row tiles)
+        int64_t ra = ((N / 2 + 128) / 256) * 256;
+        ra = std::min<int64_t>(std::max<int64_t>(ra, 256), N - 1);
+        const size_t off1 = (size_t)(hoff[ra] - hoff[0]) + 384;
+        HIP_TRY(hipEventRecord(h->lane_ev[0], st));                       // fork: the plan and the table are complete
+        HIP_TRY(hipStreamWaitEvent(h->lane_stream, h->lane_ev[0], 0));
+        if (int rc = run_chunk(ra, N, Lane{h->lane_stream, off1}, 2)) return rc;
+        HIP_TRY(hipEventRecord(h->lane_ev[3], h->lane_stream));
+        if (int rc = run_chunk(0, ra, Lane{st, 0}, 3)) return rc;
+        HIP_TRY(hipStreamWaitEvent(st, h->lane_ev[3], 0));                // join
+    } else {
+        int64_t r0 = 0;
+        while (r0 < N) {
+            int64_t r1 = r0 + 1;
+            while (r1 < N && (int64_t)hoff[r1 + 1] - hoff[r0] <= MC) ++r1;
+            if (int rc = run_chunk(r0, r1, Lane{st, 0}, r1 == N ? 1 : 0)) return rc;
+            r0 = r1;
+        }
+    }
+    R.st = st;
     if (R.rc) return R.rc;
+    HIP_TRY(hipEventRecord(ps.released, st));          // the plan slot may be rewritten behind this point (zett_forward_prepare)
     h->out_recorded = true;
 
     if (h->time_gemm) {

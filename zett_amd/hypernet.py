@@ -144,6 +144,19 @@ class HipEngine:
         _lib.check(self.lib.zett_get_stats(self.handle, C.byref(s)))
         return {n: getattr(s, n) for n, _ in s._fields_}
 
+    def prepare(self, surface_forms: torch.Tensor, input_stream: Optional["torch.cuda.Stream"] = None) -> None:
+        """zett_forward_prepare: enqueue the plan of the NEXT forward(surface_forms, ...) on the handle's own stream, behind the
+        work `input_stream` (default: the current stream) holds now.  The forward that follows with the SAME tensor then waits
+        on the host for that plan only, not for whatever its stream still holds (include/zett_hip.h).  The tensor must already
+        be what the C ABI takes — int32, contiguous, on the engine's device — so that the forward sees the same pointer."""
+        if surface_forms.dtype != torch.int32 or not surface_forms.is_contiguous() or surface_forms.device != self.device or surface_forms.dim() != 2:
+            raise ValueError("prepare() takes the int32, contiguous [n_tokens, surface_maxlen] tensor on the engine's device that forward() will get")
+        n, seq = surface_forms.shape
+        with torch.cuda.device(self.device):
+            stream = (input_stream or torch.cuda.current_stream(self.device)).cuda_stream
+            _lib.check(self.lib.zett_forward_prepare(self.handle, C.c_void_p(surface_forms.data_ptr()), n, seq, C.c_void_p(stream)),
+                       "zett_forward_prepare")
+
     def forward(self, surface_forms: torch.Tensor, source_embeddings: torch.Tensor, lang_index: int):
         d = self.dims
         if surface_forms.dim() != 2:

@@ -198,7 +198,7 @@ def all_gather_rows(local: torch.Tensor, n_rows: int, per: int, group=None) -> t
 
 
 def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group=None, chunks: int = 2,
-                    ready: Optional[Callable] = None, mode: str = "auto"):
+                    ready: Optional[Callable] = None, mode: str = "auto", prepare: Optional[Callable] = None):
     """Run `predict(rows) -> (pred_in, pred_out | None, bias)` on this rank's rows and return the full result on every
     rank.  The vocabulary is processed in `chunks` row blocks whose exchange overlaps the next block's forward (module
     docstring); chunks = 1 is the plain shard-then-gather.  `ready` (RowGather: early start of pred_in / bias) and `mode`
@@ -206,6 +206,11 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
 
     `predict` is typically ``lambda rows: engine.forward(rows, source_embeddings, lang)`` with
     ``ready=engine.stream_wait_output``.  Without an initialised process group this is just ``predict(target_surface_forms)``.
+
+    `prepare(rows, stream)` (``engine.prepare``: zett_forward_prepare) — with more than one block per rank, the plan of block
+    k + 1 is enqueued as soon as block k's forward is, on the engine's own stream behind a side stream that holds nothing but
+    the surface forms' readiness: block k + 1's zett_forward then does not wait on the host for block k's kernels.  Needs the
+    surface forms as the int32, contiguous tensor on the engine's device that `predict` hands to the engine unchanged.
     """
     if not (dist.is_available() and dist.is_initialized()):
         return predict(target_surface_forms)
@@ -215,11 +220,20 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
     if not blocks:
         return predict(target_surface_forms)
     gather = RowGather(blocks, group, mode)
-    for b in blocks:
-        rows = target_surface_forms[b.lo:b.hi]
-        if b.hi - b.lo == 0:                           # more ranks than rows in the block: compute one dummy row, contribute none
-            rows = target_surface_forms[:1]
+
+    def rows_of(b):
+        # (more ranks than rows in the block: compute one dummy row, contribute none)
+        return target_surface_forms[b.lo:b.hi] if b.hi > b.lo else target_surface_forms[:1]
+
+    ahead = None
+    if prepare is not None and len(blocks) > 1 and target_surface_forms.is_cuda:
+        ahead = torch.cuda.Stream(device=target_surface_forms.device)
+        ahead.wait_stream(torch.cuda.current_stream(target_surface_forms.device))      # the surface forms are complete behind this point
+    for k, b in enumerate(blocks):
+        rows = rows_of(b)
         outs = predict(rows)
+        if ahead is not None and k + 1 < len(blocks):
+            prepare(rows_of(blocks[k + 1]), ahead)
         if b.hi - b.lo == 0:
             outs = tuple(None if t is None else t[:0] for t in outs)
         gather.add(b, outs, ready)

@@ -226,7 +226,9 @@ class DeviceRetokenizer:
         if n:
             np.cumsum(np.fromiter(map(len, encoded), dtype=np.int64, count=n), out=offsets[1:])
         text = np.frombuffer(b"".join(encoded) or b"\0", dtype=np.uint8)
-        return torch.from_numpy(text.copy()).to(self.device), torch.from_numpy(offsets).to(self.device), n
+        d_text = torch.from_numpy(text.copy()).to(self.device)
+        d_text._zett_n_text = int(offsets[-1])          # the text length, known here: run_async() needs it without a device round trip
+        return d_text, torch.from_numpy(offsets).to(self.device), n
 
     def run(self, d_text: torch.Tensor, d_off: torch.Tensor, n: int, maxlen: int, tokens: Optional[Sequence[str]] = None) -> Tuple[torch.Tensor, int]:
         """Device side: zett_retokenize on resident text/offsets -> int32 [n, maxlen] on the device + n_truncated."""
@@ -246,6 +248,33 @@ class DeviceRetokenizer:
             raise Exception(self.lib.zett_last_error().decode())      # tokenizers raises a bare Exception here
         _lib.check(rc, "zett_retokenize")
         return out, int(n_trunc.value)
+
+    def run_async(self, d_text: torch.Tensor, d_off: torch.Tensor, n: int, maxlen: int) -> torch.Tensor:
+        """zett_retokenize_async: as run(), without waiting — the id matrix is enqueued on the current stream, the count of
+        truncated tokens and any error (KeyError, missing unk id) are collected by result(), once for all calls since the
+        last result()."""
+        out = torch.empty((n, maxlen), dtype=torch.int32, device=self.device)
+        n_text = getattr(d_text, "_zett_n_text", None)
+        if n_text is None:
+            n_text = int(d_off[-1].item()) if n else 0          # (text not made by encode(): one device round trip)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.zett_retokenize_async(self.handle, C.c_void_p(d_text.data_ptr()), C.c_void_p(d_off.data_ptr()), n,
+                                                n_text, int(maxlen), self.spec.pad_token_id,
+                                                C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+        _lib.check(rc, "zett_retokenize_async")
+        return out
+
+    def result(self) -> int:
+        """Waits for the asynchronous calls since the last result(): their number of truncated tokens; raises what run() raises."""
+        n_trunc, bad_call, bad = C.c_int64(0), C.c_int64(-1), C.c_int64(-1)
+        rc = self.lib.zett_retok_result(self.handle, C.byref(n_trunc), C.byref(bad_call), C.byref(bad))
+        if rc == _lib.E_KEY:
+            raise KeyError(f"call {bad_call.value}, token {bad.value}: {self.lib.zett_last_error().decode()}")
+        if rc == _lib.E_STATE:
+            raise Exception(self.lib.zett_last_error().decode())
+        _lib.check(rc, "zett_retok_result")
+        return int(n_trunc.value)
 
     def __call__(self, tokens: Sequence[str], maxlen: int) -> Tuple[torch.Tensor, int]:
         """int32 [len(tokens), maxlen] on the device + number of truncated tokens."""

@@ -179,7 +179,8 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
             eng.range_flags()                           # (clears whatever an earlier call left)
 
             def predict_rows(rows):
-                return predict_sharded(lambda r: eng.forward(r.to(device), source_embeddings, lang), rows, ready=eng.stream_wait_output)
+                r32 = rows.to(device=device, dtype=torch.int32).contiguous()        # what the C ABI takes: prepare() and forward() see one pointer
+                return predict_sharded(lambda r: eng.forward(r, source_embeddings, lang), r32, ready=eng.stream_wait_output, prepare=eng.prepare)
 
             if not args.do_batching:
                 out = predict_rows(target_surface_form_matrix)
