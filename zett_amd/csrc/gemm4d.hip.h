@@ -4,7 +4,7 @@
 // launch with K >= 2048: 4-8 % faster than the register-staged eight-wave kernels on the shapes of the benchmark step,
 // residual or not (tools/gemm_bench), 5 % slower at K = 1024.  Same geometry as the hipBLASLt kernel the yardstick
 // runs; the experiments that led here (ablations, K-start staggering, schedules with 3-4 barriers) are in
-// tools/experiments/gemm4dx.hip.h.
+// gemm4dx.hip.h on the `experiments` branch.
 //
 //   C[M,N] = epilogue( A[M,K] · W[N,K]ᵀ )      (contract and epilogue of gemm.hip.h; bit-identical results)
 //
@@ -24,11 +24,11 @@
 // XOR-swizzled by (row>>1)&7, applied to each lane's SOURCE address and undone on the ds_read_b128 side.
 // The K reduction order per accumulator is that of every other tile variant.
 //
-// Epilogue (r2).  A per-tile timeline (tools/experiments/trace4d.hip) showed 8 / 17 / 19 us of epilogue (plain bf16
+// Epilogue (r2).  A per-tile timeline (trace4d.hip, `experiments` branch) showed 8 / 17 / 19 us of epilogue (plain bf16
 // / erf-GELU / fp32 residual) behind an 80-88 us K loop at K = 4096, none of it memory latency: the generic drain of
 // gemm_tile.hip.h spends its time on run-time epilogue flags (select chains, exec-mask branches), on a dependent
 // packed-FMA chain per pair of GELU values, and on 16-byte accesses with 16-byte holes for fp32 rows (half the
-// per-CU rate alone, a tenth under load: tools/experiments/store_bench.hip).  The three epilogues that carry the
+// per-CU rate alone, a tenth under load: store_bench.hip, `experiments` branch).  The three epilogues that carry the
 // benchmark step are therefore compiled as their own instantiations (EPI below): everything about the output is a
 // template parameter, fp32 rows and residual rows are read and written as whole 512-byte row segments (four
 // columns per lane), the 16-bit output as 256-byte segments (eight columns per lane), the staged rows are padded
@@ -70,13 +70,6 @@ template <int K> __device__ __forceinline__ float g4d_xor_lane(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (K << 10) | 0x1f));
 }
 
-#ifdef G4D_TRACE
-// per-tile timeline (tools/experiments/trace4d.hip): [block]{start, K loop begins, K loop ends, end, hw id} in 10 ns ticks
-__device__ unsigned long long g4d_trace[32768 * 8];
-// wave 0's epilogue: {barrier+cols, then per pass: residual loads issued, staged in LDS, vmcnt(0), drain issued; all stores acknowledged}
-__device__ unsigned long long g4d_trace_epi[32768 * 16];
-__device__ int g4d_stagger_ticks, g4d_stagger_mode;
-#endif
 
 // EPI: which epilogue the instantiation carries.
 //   GENERIC    EpiDrain of gemm_tile.hip.h: every combination of outputs, decided at run time
@@ -107,14 +100,6 @@ template <typename T, int ACT = ACT_NONE, bool RES = false, int EPI = G4D_EPI_GE
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4d_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
-#ifdef G4D_TRACE
-    if (g4d_stagger_ticks > 0 && blockIdx.x < 256) {      // experiment: XCD x of the first round starts x/8 of the spread late
-        const unsigned long long t_in = wall_clock64();
-        const unsigned long long d = (unsigned long long)g4d_stagger_ticks * (g4d_stagger_mode == 0 ? (blockIdx.x & 7) : (blockIdx.x >> 3) & 7) / 8;
-        while (wall_clock64() - t_in < d) __builtin_amdgcn_s_sleep(8);
-    }
-    const unsigned long long tr0 = wall_clock64();
-#endif
 
     const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
@@ -282,9 +267,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-#ifdef G4D_TRACE
-    const unsigned long long tr1 = wall_clock64();
-#endif
     typedef std::integral_constant<bool, true> yes_t;
     typedef std::integral_constant<bool, false> no_t;
     auto k_loop = [&](auto wave_c) {
@@ -299,11 +281,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else k_loop(std::integral_constant<int, 3>{});
 
     asm volatile("s_nop 15\n\ts_nop 15");     // last MFMA (8 passes) -> first accumulator read
-#ifdef G4D_TRACE
-    const unsigned long long tr2 = wall_clock64();
-    unsigned long long trp[2][4] = {};
-    unsigned long long tr2b = tr2;
-#endif
     // the lane-derived indices of the epilogue are recomputed from an opaque copy of the thread id: kept alive
     // across the K loop (the compiler shares them with the prologue's) they are what no longer fits in 256 VGPRs
     int tid_e = tid;
@@ -648,50 +625,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (full) drain(p, std::integral_constant<bool, true>{});
             else drain(p, std::integral_constant<bool, false>{});
         };
-#ifdef G4D_TRACE
-        tr2b = wall_clock64();
-#endif
         if constexpr (LN16) { if (!res16_early) load_res(0); }
         else load_res(0);
-#ifdef G4D_TRACE
-        trp[0][0] = wall_clock64();
-#endif
         stage(0);
         __builtin_amdgcn_sched_barrier(0);         // (pass 1's residual registers only exist once pass 0's accumulators are staged)
         if constexpr (!LNP) load_res(1);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef G4D_TRACE
-        __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
-        trp[0][1] = trp[0][2] = wall_clock64();
-#endif
         drain_pass(0);
-#ifdef G4D_TRACE
-        trp[0][3] = trp[1][0] = wall_clock64();
-#endif
         if constexpr (LNP && !LN16) { __builtin_amdgcn_sched_barrier(0); load_res(1); __builtin_amdgcn_sched_barrier(0); }
         stage(1);
-#ifdef G4D_TRACE
-        __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
-        trp[1][1] = trp[1][2] = wall_clock64();
-#endif
         drain_pass(1);
-#ifdef G4D_TRACE
-        trp[1][3] = wall_clock64();
-#endif
         range_report(e.range_flag, bad, W16 ? ZETT_RANGE_BIT_ACTIVATION : ZETT_RANGE_BIT_OUTPUT);
     }
-#ifdef G4D_TRACE
-    __builtin_amdgcn_s_waitcnt(GEMM_WAIT_VMCNT0);
-    if (tid_e == 0 && blockIdx.x < 32768) {
-        unsigned long long* o = g4d_trace + (size_t)blockIdx.x * 8;
-        o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = wall_clock64(); o[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
-        o[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
-        unsigned long long* q = g4d_trace_epi + (size_t)blockIdx.x * 16;
-        q[0] = tr2b - tr2;
-        for (int p = 0; p < 2; ++p) { q[1 + 4 * p] = trp[p][0] - tr2; q[2 + 4 * p] = trp[p][1] - tr2; q[3 + 4 * p] = trp[p][2] - tr2; q[4 + 4 * p] = trp[p][3] - tr2; }
-        q[9] = o[3] - tr2;
-    }
-#endif
 }
 
 // Which epilogue a launch gets.  force_generic: zett_set_option("gemm_variant", 8) (A/B and the bit-identity test).

@@ -764,7 +764,7 @@ struct Runner {
         // `a_rows_readable` >= tiles*384 rows (every A operand here is a workspace buffer with
         // that slack) and N must be a multiple of 256.  (The kernels that led to gemm8r and gemm4d
         // -- four-wave register-staged, eight-wave LDS-DMA, gemm8r on 16x16x32 MFMAs -- live in
-        // tools/experiments/ with tools/gemm_bench.)
+        // tools/experiments/ with tools/gemm_bench on the `experiments` branch.)
         constexpr bool is_f32 = std::is_same<T, float>::value;
         int variant = h->gemm_variant;
         if (variant == 0) {
