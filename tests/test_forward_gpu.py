@@ -85,3 +85,27 @@ def test_big_batch_golden(path, precision):
     del w
     out = util.hip_forward(model, case["ids"], src, case["lang"])
     _check(case, [None if o is None else o[case["sample"]] for o in out], precision)
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("hidden,heads,rows,lang,layers", [(640, 10, 1237, True, 3), (640, 10, 333, False, 2), (1152, 18, 2051, True, 3)])
+def test_fold_epilogues_on_edge_shapes_vs_oracle(precision, hidden, heads, rows, lang, layers):
+    """The LayerNorm-fold producers (fp32 stream in bf16, 16-bit residual stream in f16: residual rows requested from the last
+    K step, clamped at the matrix edge) on shapes none of the reference-shaped goldens has: a hidden width that fills only half
+    of the last 256-column tile (640 = 2.5 tiles, 1152 = 4.5), row counts that end inside a 64-row pass, with / without the
+    language token and the pair lever.  Checked against the numpy oracle at the tolerance of the arithmetic."""
+    from oracle import hypernet_ref
+    cfg, _, _, hist = synth.workload("xlmr_gpt2")
+    cfg = dict(cfg, n_embd=256, hn_hidden_size=hidden, hn_intermediate_size=2 * hidden, hn_num_attention_heads=heads,
+               hn_n_layers=layers, hn_embed_lang_id=lang, original_vocab_size=5000, hn_n_extra_tokens=7, vocab_size=5007,
+               separate_out_embeddings=True)
+    w = synth.make_weights(cfg, seed=9)
+    src = synth.make_source_embeddings(cfg, seed=9)
+    ids = synth.make_surface_forms(cfg, rows, seed=9, hist=hist, n_special=2)
+    li = 3 if lang else None
+    want = hypernet_ref.forward(w, cfg, ids, src, lang_index=li)
+    model = util.hip_model(cfg, w, precision)
+    got = util.hip_forward(model, ids, src, li)
+    keep = ~util.all_pad_rows(cfg, ids)
+    for g, r, what in zip(got, want, ("pred_in", "pred_out", "bias")):
+        util.CLOSE[precision](g[keep], r[keep], f"edge {hidden} {precision} {what}")

@@ -21,3 +21,7 @@ done
 ZETT_GEMM_LOG=1 $bench --steps 1 --warmup 1 --no-cpu-baseline --no-alt-precision 2> $out/gemm_launch_log.txt > /dev/null
 find $out -name "*.db" -delete; find $out -name "*agent_info*" -delete
 du -sh $out
+# the narrow workloads get their own kernel tables and counter passes (tools/profile_workload.sh), and the headline a power / clock trace
+for w in xlmr_gpt2 tinyllama_neox; do bash $GRAFT_REPO_ROOT/tools/profile_workload.sh $tag $w > $out/workload_$w.log 2>&1; done
+bash $GRAFT_REPO_ROOT/tools/power_trace.sh $tag mistral_gpt2_32k > $out/power.log 2>&1
+bash $GRAFT_REPO_ROOT/tools/power_trace.sh $tag xlmr_gpt2 >> $out/power.log 2>&1
