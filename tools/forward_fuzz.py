@@ -38,12 +38,17 @@ def case(seed):
                hn_surface_maxlen=int(rng.choice([1, 2, 3, 7, 8, 12])))
     rows = int(rng.choice([1, 2, 17, 130, 700, 2500, 4000]))
     opts = dict(gemm_variant=int(rng.choice([0, 0, 1, 2, 3, 7, 8])), ln_fold=int(rng.choice([0, 1, 1, 2])), cls_only_last_layer=int(rng.integers(2)),
-                pair_dedupe=int(rng.integers(2)))
+                pair_dedupe=int(rng.integers(2)),
+                # r4: the 16-bit residual stream (1 = f16 only, 2 = bf16 too), the attention kernel's register-resident path,
+                # the call as two concurrent half-vocabulary chunks
+                residual_lo=int(rng.choice([0, 1, 1, 2])), attention_fast=int(rng.choice([0, 1, 1])), concurrent_lanes=int(rng.choice([0, 0, 2])))
     if rng.random() < 0.3:
         opts["max_chunk_tokens"] = int(rng.choice([1024, 2048, 5000]))
     if rng.random() < 0.3:
         opts["gemm4d_min_k"] = int(rng.choice([64, 128, 4096]))
     precision = str(rng.choice(["f32", "f16", "bf16"]))
+    if precision == "bf16" and opts["residual_lo"] == 2:
+        opts["residual_lo"] = 1          # (a bf16 residual stream is an A/B option with its own, looser tolerance: tests/test_forward_gpu.py)
     return cfg, rows, opts, precision, int(rng.choice([0, 1, 2, rows]))
 
 
