@@ -98,6 +98,7 @@ struct zett_hypernet {
         const int32_t* sfm = nullptr;     // what the slot was prepared for (zett_forward_prepare), pending until a forward takes it
         int64_t n_rows = 0;
         int seq = 0;
+        bool pair_plan = false;           // the layout it was made with (an option changed in between: the forward plans again)
         bool pending = false;
     } plan[2];
     int plan_cur = 0;                 // slot of the most recent forward
@@ -328,7 +329,7 @@ static int enqueue_plan(zett_hypernet* h, zett_hypernet::PlanSlot& s, const int3
     hoff[N + 3] = 0;
     if (L.pair_plan) HIP_TRY(hipMemcpyAsync(hoff + N + 3, p.pair_slot + L.PK, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(s.done, st));
-    s.sfm = sfm; s.n_rows = N; s.seq = seq;
+    s.sfm = sfm; s.n_rows = N; s.seq = seq; s.pair_plan = L.pair_plan;
     return 0;
 }
 
@@ -882,7 +883,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     // plan stream, the host waits for THAT (not for earlier work on st) and st is ordered behind it.  Otherwise the plan is
     // made here, on st, and the host waits for it — and so for whatever was enqueued on st before.
     zett_hypernet::PlanSlot& ps = h->plan[h->plan_cur ^ 1];
-    if (ps.pending && ps.sfm == sfm && ps.n_rows == N && ps.seq == seq) {
+    if (ps.pending && ps.sfm == sfm && ps.n_rows == N && ps.seq == seq && ps.pair_plan == plan_layout(h, ps, N, seq).pair_plan) {
         HIP_TRY(hipStreamWaitEvent(st, ps.done, 0));
     } else {
         if (ps.pending) HIP_TRY(hipEventSynchronize(ps.done));       // a prepared plan nobody took: let it finish before the slot is reused

@@ -156,6 +156,7 @@ class HipEngine:
             stream = (input_stream or torch.cuda.current_stream(self.device)).cuda_stream
             _lib.check(self.lib.zett_forward_prepare(self.handle, C.c_void_p(surface_forms.data_ptr()), n, seq, C.c_void_p(stream)),
                        "zett_forward_prepare")
+        self._prepared = surface_forms          # the plan reads it on a stream torch's allocator does not know: keep it alive until the next forward has waited for the plan
 
     def forward(self, surface_forms: torch.Tensor, source_embeddings: torch.Tensor, lang_index: int):
         d = self.dims
@@ -181,6 +182,7 @@ class HipEngine:
                 _TORCH_TO_ZETT[src.dtype], src.shape[0], int(lang_index),
                 C.c_void_p(out_in.data_ptr()), C.c_void_p(out_out.data_ptr() if out_out is not None else 0),
                 C.c_void_p(out_bias.data_ptr()), C.c_void_p(stream))
+        self._prepared = None                   # (zett_forward waited on the host for every plan that read a prepared tensor)
         _lib.check(rc, "zett_forward")
         return out_in, out_out, out_bias
 
