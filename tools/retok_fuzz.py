@@ -25,7 +25,7 @@ from tests import retok_random as rr  # noqa: E402
 
 def case(seed):
     rng = random.Random(77000 + seed)
-    make = rr.random_bpe if rng.random() < 0.5 else rr.random_unigram
+    make = rng.choice([rr.random_bpe, rr.random_unigram, rr.random_wordpiece])          # (WordPiece: r4)
     size = rng.choice([3, 10, 40, 80, 200, 600])
     model = make(rng, size)
     tokens = rr.random_tokens(rng, rng.choice([1, 50, 400]), maxlen=rng.choice([1, 4, 12, 40])) + rr.random_tokens(rng, rng.choice([0, 10]), maxlen=300)
@@ -72,6 +72,12 @@ def main():
                     retok_ref.surface_form_matrix_c(om, tokens + specials, width, 77)
                 except Exception:
                     ok = True                           # the oracle refuses the same input (e.g. an unknown byte without unk)
+            else:                                       # the library refused (a word that needs a missing [UNK] / unk id): so must the oracle
+                try:
+                    om = retok_ref.model_from_tokenizer_json(model)
+                    [retok_ref.tokenize(om, retok_ref.token_to_bytes(tok)) for tok in tokens]
+                except Exception:
+                    ok = True
             if not ok:
                 bad = bad or {"seed": seed, "error": err}
                 break
