@@ -5,7 +5,18 @@ classes, so ``AutoModel.from_pretrained(<zett checkpoint>)`` returns the HIP-bac
 ``ZettHypernet`` (the reference registers its torch port the same way in
 scripts/convert_to_pt.py:26-27).
 """
-from .config import MODEL_TYPE, ZettHypernetConfig  # noqa: F401
+import os as _os
+
+# One process per GPU under torchrun (WORLD_SIZE > 1): the row exchange is real xGMI traffic, and it — like the plan-ahead of
+# zett_forward_prepare — overlaps a forward only if its streams do not share the forward's HARDWARE queue.  The HIP runtime
+# multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) queues, and an eagerly initialised RCCL communicator takes
+# its share first (profiles/r4g_blocks.md, NOTEBOOK R4.9).  Eight queues keep them apart.  Read when the HIP runtime initialises
+# (the first CUDA call of the process), hence set here, at import; a value the user set wins.  Not for a single process: there
+# the "exchange" is a local copy and serialised streams are the faster schedule (65.3 vs 69.4 ms per four-block step).
+if int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from .config import MODEL_TYPE, ZettHypernetConfig  # noqa: F401,E402
 
 
 def _register() -> None:
