@@ -702,6 +702,7 @@ int zett_retokenize_async(zett_retok* r, const uint8_t* token_chars, const int32
     ZETT_ON_DEVICE(r->device);
     hipStream_t st = (hipStream_t)stream;
     if (!r->words_ready) { if (int rc = retok_reset_words(r, st)) return rc; }
+    if (r->calls >= (1u << 20)) return fail(ZETT_E_STATE, "2^20 asynchronous calls without zett_retok_result: collect the results first");
     const int n_blocks = (int)((n_text + CH_PER_BLOCK - 1) / CH_PER_BLOCK);
     if (int rc = r->raw.reserve((size_t)n_text + 16)) return rc;
     if (int rc = r->raw_pos.reserve(((size_t)n_text + 1) * 4)) return rc;
