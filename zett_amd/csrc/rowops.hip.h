@@ -50,6 +50,8 @@ struct PlanArrays {
     int32_t* pair_pos;      // [P]   its position index
     uint8_t* tok_key;       // [T]   visible as key
     int32_t* err;           // [1]   set to 1 + row on an out-of-range id
+    int32_t* counters;      // [3]   behind row_offset[N]: distinct ids, the error word, distinct pairs — what the host reads with the row offsets, in ONE copy
+    int32_t n_pair_keys;    //       size of pair_flag (0: no pair plan)
 };
 
 __global__ void plan_rows_kernel(const int32_t* __restrict__ sfm, int64_t n_rows, int seq, int pad, int lam,
@@ -216,6 +218,11 @@ __global__ void pair_rows_kernel(int m, int tok0, int64_t row0, int rows, PlanAr
 __global__ void plan_idlist_kernel(int n_ids, PlanArrays p) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id < n_ids && p.id_flag[id]) p.id_list[p.id_slot[id]] = id;
+    if (id == 0) {          // (the last kernel of a plan: every scan has run)
+        p.counters[0] = p.id_slot[n_ids];
+        p.counters[1] = p.err[0];
+        p.counters[2] = p.n_pair_keys ? p.pair_slot[p.n_pair_keys] : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -214,7 +214,7 @@ static size_t plan_i32_bytes(const zett_config& c, int64_t N, int seq) {
     // + the pair plan: tok_pkey[T] tok_pair[T] pair_tslot[T] pair_pos[T] pair_flag[K] pair_slot[K+1], K = (V+1)(L+lang)
     const int64_t K = pair_keys(c, seq);
     const size_t scan_scratch = 2 * ((size_t)std::max<int64_t>(std::max<int64_t>(N, V), K) / SCAN_CHUNK + 2) + 1;
-    return ((size_t)N + (N + 1) + V + (V + 1) + V + 7 * (size_t)max_tok + 2 * (size_t)K + 2 + scan_scratch) * 4;
+    return ((size_t)N + (N + 1) + 3 + V + (V + 1) + V + 7 * (size_t)max_tok + 2 * (size_t)K + 2 + scan_scratch) * 4;
 }
 
 // Packed positions per encoder chunk when the caller has not set "max_chunk_tokens": 12 GiB of per-position workspace,
@@ -252,6 +252,7 @@ struct PlanLayout {
     int32_t* scan_tmp = nullptr;
     bool pair_plan = false;
     int64_t PK = 0;
+    size_t n_clear = 0;          // int32 words at the head of the arena that a plan starts from zero
 };
 static PlanLayout plan_layout(const zett_hypernet* h, const zett_hypernet::PlanSlot& s, int64_t N, int seq) {
     const zett_config& c = h->cfg;
@@ -260,27 +261,32 @@ static PlanLayout plan_layout(const zett_hypernet* h, const zett_hypernet::PlanS
     const int64_t max_tok = N * (int64_t)(seq + lam);
     PlanLayout L;
     PlanArrays& p = L.p;
-    // int32 arena: row_count[N] row_offset[N+1] id_flag[V] id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] tok_row[T] [pair plan] err[1] scan scratch
+    // int32 arena: what a plan clears first, in one piece — id_flag[V] pair_flag[PK] err[1] — then row_count[N] row_offset[N+1]
+    // counters[3] (read by the host in one copy with the row offsets) id_slot[V+1] id_list[V] tok_slot[T] tok_pos[T] tok_row[T]
+    // [pair plan] scan scratch
+    L.PK = pair_keys(c, seq);
+    L.pair_plan = h->pair_dedupe && c.layers >= 2 && L.PK <= std::max<int64_t>(4 * max_tok, (int64_t)1 << 23) && L.PK < (int64_t)0x7fffffff;
     int32_t* base = s.i32.as<int32_t>();
+    p.id_flag = base; base += V;
+    if (L.pair_plan) { p.pair_flag = base; base += L.PK; }
+    p.err = base; base += 1;
+    L.n_clear = (size_t)(base - s.i32.as<int32_t>());
     p.row_count = base; base += N;
     p.row_offset = base; base += N + 1;
-    p.id_flag = base; base += V;
+    p.counters = base; base += 3;
     p.id_slot = base; base += V + 1;
     p.id_list = base; base += V;
     p.tok_slot = base; base += max_tok;
     p.tok_pos = base; base += max_tok;
     p.tok_row = base; base += max_tok;
-    L.PK = pair_keys(c, seq);
-    L.pair_plan = h->pair_dedupe && c.layers >= 2 && L.PK <= std::max<int64_t>(4 * max_tok, (int64_t)1 << 23) && L.PK < (int64_t)0x7fffffff;
+    p.n_pair_keys = L.pair_plan ? (int32_t)L.PK : 0;
     if (L.pair_plan) {
         p.tok_pkey = base; base += max_tok;
         p.tok_pair = base; base += max_tok;
         p.pair_tslot = base; base += max_tok;
         p.pair_pos = base; base += max_tok;
-        p.pair_flag = base; base += L.PK;
         p.pair_slot = base; base += L.PK + 1;
     }
-    p.err = base; base += 1;
     L.scan_tmp = base;
     p.row_uniform = s.u8.as<uint8_t>();
     p.tok_key = p.row_uniform + N;
@@ -307,9 +313,7 @@ static int enqueue_plan(zett_hypernet* h, zett_hypernet::PlanSlot& s, const int3
     if (!s.released) HIP_TRY(hipEventCreateWithFlags(&s.released, hipEventDisableTiming));
     const PlanLayout L = plan_layout(h, s, N, seq);
     const PlanArrays& p = L.p;
-    HIP_TRY(hipMemsetAsync(p.id_flag, 0, (size_t)V * 4, st));
-    HIP_TRY(hipMemsetAsync(p.err, 0, 4, st));
-    if (L.pair_plan) HIP_TRY(hipMemsetAsync(p.pair_flag, 0, (size_t)L.PK * 4, st));
+    HIP_TRY(hipMemsetAsync(s.i32.p, 0, L.n_clear * 4, st));          // id_flag, pair_flag, err: one piece of the arena
     const int rb = (int)((N + 255) / 256);
     hipLaunchKernelGGL(plan_rows_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
     launch_exclusive_scan(p.row_count, p.row_offset, N, L.scan_tmp, st);
@@ -321,13 +325,8 @@ static int enqueue_plan(zett_hypernet* h, zett_hypernet::PlanSlot& s, const int3
     }
     hipLaunchKernelGGL(plan_idlist_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, p);
     HIP_TRY(hipGetLastError());
-    // the row offsets, the distinct-id count, the error word and the pair count to the host
-    int32_t* hoff = s.host;
-    HIP_TRY(hipMemcpyAsync(hoff, p.row_offset, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(hoff + N + 1, p.id_slot + V, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(hoff + N + 2, p.err, 4, hipMemcpyDeviceToHost, st));
-    hoff[N + 3] = 0;
-    if (L.pair_plan) HIP_TRY(hipMemcpyAsync(hoff + N + 3, p.pair_slot + L.PK, 4, hipMemcpyDeviceToHost, st));
+    // the row offsets and, right behind them, the three counters (distinct ids, error word, distinct pairs) to the host: one copy
+    HIP_TRY(hipMemcpyAsync(s.host, p.row_offset, ((size_t)N + 1 + 3) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(s.done, st));
     s.sfm = sfm; s.n_rows = N; s.seq = seq; s.pair_plan = L.pair_plan;
     return 0;
