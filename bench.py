@@ -166,6 +166,195 @@ def measure_traffic_live(args, timeout_s=240):
                         "write_bytes_per_launch": totals["WRITE_SIZE"] * 1024 / launches["WRITE_SIZE"]}
 
 
+HBM_PEAK_TBS = 8.0            # HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a streaming copy achieves
+HBM_ACHIEVABLE_TBS = 6.3
+RIDGE_FLOP_PER_BYTE = 2500.0 / HBM_ACHIEVABLE_TBS      # ~400: below it a launch cannot reach the MFMA roof even at the achievable HBM rate
+
+
+def launch_class(r):
+    e = r["epilogue"]
+    act = {0: "", 1: " + tanh-GELU", 2: " + erf-GELU"}[(e >> 8) & 3]
+    if e & 16 and e & 64:
+        return "LayerNorm-fold producer on the 16-bit residual stream (16-bit residual in, 16-bit out, row statistics)"
+    if e & 16:
+        return ("LayerNorm-fold producer (fp32 residual in, fp32 + 16-bit out, row statistics)" if e & 2 else
+                "LayerNorm-fold producer of an output head (fp32 residual in, 16-bit out, row statistics)" + act)
+    if e & 32:
+        return "LayerNorm-fold consumer, 16-bit out" + act
+    if e & 8:
+        return "output head (Rescaler, fp32 out)"
+    if e & 4:
+        return "fp32 residual, fp32 out" + act
+    if (e & 3) == 3:
+        return "fp32 + 16-bit out" + act
+    return ("16-bit out" if e & 1 else "fp32 out") + act
+
+
+def class_table(classes, steps, peak):
+    """by_class rows of the roofline object: per launch class, the FLOP / HIP-event-time ratio against the MFMA roof AND the
+    algorithmic bytes / time ratio against HBM (launches of the narrow hypernets sit near the ridge, N*K/(N+K) ~ 400 FLOP/B:
+    both fractions say what they are)."""
+    out = []
+    for k, v in sorted(classes.items(), key=lambda kv: -kv[1][1]):
+        n, ms, fl, by = v
+        tf = (fl / (ms * 1e-3) / 1e12) if ms > 0 else None
+        tbs = (by / (ms * 1e-3) / 1e12) if ms > 0 else None
+        out.append({"class": k, "launches_per_step": n / max(steps, 1), "ms_per_step": ms / max(steps, 1), "achieved": tf,
+                    "frac": (tf / peak) if tf is not None else None,
+                    "algorithmic_gb_per_launch": by / n / 1e9 if n else None,
+                    "flop_per_byte": (fl / by) if by else None,
+                    "hbm_tb_per_s": tbs, "hbm_frac": (tbs / HBM_PEAK_TBS) if tbs is not None else None})
+    return out
+
+
+def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0):
+    """One more workload of BASELINE.json on this GPU, measured AFTER the timed region of the main line and reported under
+    `configs` (never `value`): the same step — surface forms resident in HBM -> GPU retokenization -> hypernet forward — with
+    per-launch HIP events, `steps` steps.  shard_of = P > 0: the rows are what rank 0 of P ranks computes of the workload's
+    vocabulary (zett_amd.sharding.plan_blocks: the single-GPU proxy of the P-GPU step, exchange excluded)."""
+    from zett_amd.hypernet import HipEngine
+    from zett_amd.sharding import plan_blocks
+    from zett_amd.surface_forms import DeviceRetokenizer, HnTokenizerSpec
+
+    cfg, default_rows, src_dtype, hist = synth.workload(workload)
+    vocab_rows = rows or default_rows
+    dims = HypernetDims.from_config(cfg)
+    lang = 3 if dims.embed_lang else -1
+    peak = PEAK_TFLOPS[precision]
+    engine = HipEngine(dims, 1e-5, device, precision)
+    engine.load_weights(device_weights(cfg, device, seed=0))
+    engine.set_option("time_gemm", 1)
+    ids_all = synth.make_surface_forms(cfg, vocab_rows, seed=0, hist=hist)
+    if shard_of:
+        blocks = plan_blocks(vocab_rows, shard_of, 0, 1)
+        ids_np = np.concatenate([ids_all[b.lo:b.hi] for b in blocks])
+    else:
+        ids_np = ids_all
+    n = int(ids_np.shape[0])
+    seq_len = int(ids_np.shape[1])
+    hn_model, piece_of_id = synth.make_hn_model(workload, cfg)
+    spec = HnTokenizerSpec.from_model_json(hn_model, ["<unk>", "<s>", "</s>"], [0, 1, 2], dims.pad_token_id)
+    retok = DeviceRetokenizer(spec, device)
+    d_text, d_off, n_tok = retok.encode(synth.tokens_for_surface_forms(cfg, ids_np, piece_of_id))
+    sfm0, n_trunc0 = retok.run(d_text, d_off, n_tok, seq_len)
+    if n_trunc0 != 0 or not torch.equal(sfm0.cpu(), torch.from_numpy(ids_np)):
+        raise SystemExit(f"{workload}: the retokenized surface forms differ from the workload's id matrix")
+    # random source embeddings generated in HBM (the side lines have no CPU twin to agree with)
+    g = torch.Generator(device=device)
+    g.manual_seed(1)
+    src = (0.02 * torch.randn((dims.original_vocab_size, dims.n_in_embd), device=device, generator=g)).to(getattr(torch, src_dtype))
+    classes, acc = {}, {"gemm_ms": 0.0, "gemm_flops_timed": 0.0, "gemm_launches": 0}
+
+    def one():
+        out = engine.forward(retok.run_async(d_text, d_off, n_tok, seq_len), src, lang)
+        st_k = engine.stats()
+        for key in acc:
+            acc[key] += st_k[key]
+        for r in engine.gemm_log():
+            c = classes.setdefault(launch_class(r), [0, 0.0, 0.0, 0.0])
+            c[0] += 1; c[1] += r["ms"]; c[2] += r["flops"]; c[3] += r["bytes"]
+        return out
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    classes.clear()
+    for key in acc:
+        acc[key] = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if retok.result() != 0:
+        raise SystemExit("a retokenized surface form was truncated")
+    st = engine.stats()
+    flags = engine.range_flags()
+    tf = acc["gemm_flops_timed"] / (acc["gemm_ms"] * 1e-3) / 1e12 if acc["gemm_ms"] > 0 else 0.0
+    by = sum(v[3] for v in classes.values())
+    tbs = by / (acc["gemm_ms"] * 1e-3) / 1e12 if acc["gemm_ms"] > 0 else 0.0
+    res = {"workload": workload + (f" (rank 0 of {shard_of}: {n} of {vocab_rows} rows)" if shard_of else ""), "rows": n, "dtype": precision,
+           "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "value": n * steps / dt, "unit": "token-embeddings/s",
+           "packed_tokens": st["packed_tokens"], "distinct_source_ids": st["distinct_ids"], "distinct_id_position_pairs": st["distinct_positions"],
+           "range_flags": flags,
+           "roofline": {"bound": "mfma" if (acc["gemm_flops_timed"] / by if by else 1e9) >= RIDGE_FLOP_PER_BYTE else "mfma/hbm (launch intensity under the ridge)",
+                        "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                        "flop_per_byte": (acc["gemm_flops_timed"] / by) if by else None, "ridge_flop_per_byte": RIDGE_FLOP_PER_BYTE,
+                        "hbm_tb_per_s": tbs, "hbm_frac": tbs / HBM_PEAK_TBS, "hbm_frac_of_achievable": tbs / HBM_ACHIEVABLE_TBS,
+                        "gemm_ms_per_step": acc["gemm_ms"] / steps, "non_gemm_ms_per_step": dt / steps * 1e3 - acc["gemm_ms"] / steps,
+                        "by_class": class_table(classes, steps, peak)}}
+    engine.close()
+    retok.close()
+    del src, engine
+    torch.cuda.empty_cache()
+    return res
+
+
+def api_path(workload, precision, device, reps=3):
+    """Throughput through the KEPT API (README.md:91-121 of the reference): a Python list[str] of byte-level target tokens ->
+    zett_amd.get_surface_form_matrix (zett/utils.py:651-689: returns a numpy matrix) -> ZettHypernet.__call__(torch.from_numpy(m),
+    source_embeddings=...) (hf_hypernet/modeling_hypernet.py:156-163), wall per vocabulary, host work, H2D / D2H copies and the
+    f16 range check included.  Also the documented fast path that leaves the matrix on the GPU (surface_form_matrix_device).
+    A side measurement after the timed region; never `value`."""
+    import zett_amd
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    from zett_amd.surface_forms import HnTokenizerSpec, surface_form_matrix_device
+
+    cfg, rows, src_dtype, hist = synth.workload(workload)
+    dims = HypernetDims.from_config(cfg)
+    with torch.device(device):
+        model = ZettHypernet(ZettHypernetConfig(**cfg))
+    model.load_state_dict(device_weights(cfg, device, seed=0))
+    model = model.to(device).eval()
+    model.precision = precision
+    ids_np = synth.make_surface_forms(cfg, rows, seed=0, hist=hist)
+    hn_model, piece_of_id = synth.make_hn_model(workload, cfg)
+    spec = HnTokenizerSpec.from_model_json(hn_model, ["<unk>", "<s>", "</s>"], [0, 1, 2], dims.pad_token_id)
+    tokens = synth.tokens_for_surface_forms(cfg, ids_np, piece_of_id)
+    maxlen = int(ids_np.shape[1])
+    g = torch.Generator(device=device)
+    g.manual_seed(1)
+    src = (0.02 * torch.randn((dims.original_vocab_size, dims.n_in_embd), device=device, generator=g)).to(getattr(torch, src_dtype))
+    lang = torch.tensor(3) if dims.embed_lang else None
+
+    def numpy_api():
+        t0 = time.perf_counter()
+        m, n_trunc = zett_amd.get_surface_form_matrix(tokens, maxlen, tokenizer_to_use=spec)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            out = model(torch.from_numpy(m), source_embeddings=src, lang_index=lang)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        return (t2 - t0) * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3, m, out
+
+    def device_api():
+        t0 = time.perf_counter()
+        m, n_trunc = surface_form_matrix_device(tokens, maxlen, spec, device)
+        with torch.no_grad():
+            out = model(m, source_embeddings=src, lang_index=lang)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    numpy_api(); device_api()                                   # warm-up: engine build + weight upload, retokenizer tables
+    runs = [numpy_api() for _ in range(reps)]
+    if not np.array_equal(runs[-1][3], ids_np):
+        raise SystemExit("api_path: get_surface_form_matrix differs from the workload's id matrix")
+    dev = [device_api() for _ in range(reps)]
+    best = min(runs, key=lambda r: r[0])
+    res = {"workload": workload, "rows": rows, "dtype": model.precision, "reps": reps,
+           "ms": best[0], "ms_get_surface_form_matrix": best[1], "ms_hypernet_call": best[2],
+           "ms_all_reps": [r[0] for r in runs],
+           "device_matrix_ms": min(dev), "device_matrix_ms_all_reps": dev,
+           "what": "list[str] -> zett_amd.get_surface_form_matrix (numpy out) -> ZettHypernet.__call__(torch.from_numpy(m), source_embeddings=...) "
+                   "-> torch.cuda.synchronize(); device_matrix_ms: surface_form_matrix_device (matrix stays in HBM) -> ZettHypernet.__call__; "
+                   "best of `reps`, after one warm-up call of each"}
+    model._drop_engines()
+    del model, src
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +376,8 @@ def main():
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B only: the encoder's LayerNorms as launches instead of folded into the GEMMs around them (zett_set_option ln_fold 0)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 PMC passes that measure roofline.traffic after the timed region (N = 1, default workload sizes); "
                     "the figure then comes from profiles/pmc_traffic.json if that still matches the HIP sources, else null")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the side measurements of the other 1-GPU BASELINE configs, the 8-GPU shard proxy (`configs`) "
+                    "and of the kept Python API (`api_path`) after the timed region")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="A/B only: any zett_set_option key (repeatable), applied last")
     ap.add_argument("--no-retokenize", action="store_true", help="A/B only: start every step from the id matrix instead of the surface forms")
     ap.add_argument("--chunks", type=int, default=2, help="N > 1: row blocks per step (zett_amd/sharding.py: the all-gather of a block overlaps the next block's forward)")
@@ -198,6 +389,8 @@ def main():
     ap.add_argument("--no-early-gather", action="store_true", help="N > 1, A/B: start the exchange of pred_in / bias behind the whole forward instead of behind their own completion point")
     args = ap.parse_args()
 
+    import zett_amd
+    zett_amd.configure_hw_queues()          # (N > 1: before the HIP runtime initialises)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -315,24 +508,6 @@ def main():
     acc = {"gemm_ms": 0.0, "gemm_flops_timed": 0.0, "gemm_launches": 0}
     exposed = []          # N > 1: per step, how long the compute stream waited for the row exchange after its last forward
     classes = {}          # launch class -> [launches, ms, flops, algorithmic bytes] over the timed steps (zett_get_gemm_log)
-
-    def launch_class(r):
-        e = r["epilogue"]
-        act = {0: "", 1: " + tanh-GELU", 2: " + erf-GELU"}[(e >> 8) & 3]
-        if e & 16 and e & 64:
-            return "LayerNorm-fold producer on the 16-bit residual stream (16-bit residual in, 16-bit out, row statistics)"
-        if e & 16:
-            return ("LayerNorm-fold producer (fp32 residual in, fp32 + 16-bit out, row statistics)" if e & 2 else
-                    "LayerNorm-fold producer of an output head (fp32 residual in, 16-bit out, row statistics)" + act)
-        if e & 32:
-            return "LayerNorm-fold consumer, 16-bit out" + act
-        if e & 8:
-            return "output head (Rescaler, fp32 out)"
-        if e & 4:
-            return "fp32 residual, fp32 out" + act
-        if (e & 3) == 3:
-            return "fp32 + 16-bit out" + act
-        return ("16-bit out" if e & 1 else "fp32 out") + act
 
     def step():
         gather = RowGather(blocks, mode=gather_mode) if exchange else None
@@ -461,11 +636,7 @@ def main():
                      "traffic_over_algorithmic": (traffic / (alg_bytes / alg_launches)) if (traffic and alg_launches) else None,
                      # the same FLOP / HIP-event-time ratio per launch class (zett_get_gemm_log), so that the fraction can be
                      # read class by class: K loops are alike, the epilogues differ
-                     "by_class": [{"class": k, "launches_per_step": v[0] / max(args.steps, 1), "ms_per_step": v[1] / max(args.steps, 1),
-                                   "achieved": (v[2] / (v[1] * 1e-3) / 1e12) if v[1] > 0 else None,
-                                   "frac": (v[2] / (v[1] * 1e-3) / 1e12 / peak) if v[1] > 0 else None,
-                                   "algorithmic_gb_per_launch": v[3] / v[0] / 1e9 if v[0] else None}
-                                  for k, v in sorted(timed_classes.items(), key=lambda kv: -kv[1][1])]},
+                     "by_class": class_table(timed_classes, args.steps, peak)},
         # N > 1: the part of a step the compute stream spent waiting for the row exchange (HIP events around the waits in
         # RowGather.finish, this rank); the rest of the exchange ran under forwards
         "exchange_exposed_ms_per_step": (sum(x for x in exposed if x is not None) / max(len(exposed), 1)) if exchange else None,
@@ -540,6 +711,28 @@ def main():
                               "gemm_tflops": f32_tf, "roofline_frac": f32_tf / PEAK_TFLOPS["f32"], "peak": PEAK_TFLOPS["f32"],
                               "note": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32, gemm8r tile); measured after the timed region"}
         f32_engine.close()
+    if rank == 0 and world == 1 and not exchange and not args.no_side_configs and not args.rows and args.workload == "mistral_gpt2_32k":
+        # Side measurements, outside the timed region and never `value`: the other 1-GPU configs of BASELINE.json (C2, C3) and the
+        # single-GPU proxy of the 8-GPU step (rank 0's share of the headline vocabulary), so that they are in the driver's record;
+        # then the same workloads through the kept Python API.
+        engine.close()
+        torch.cuda.empty_cache()
+        result["configs"] = []
+        for name, shard_of in (("xlmr_gpt2", 0), ("tinyllama_neox", 0), ("mistral_gpt2_32k", 8)):
+            try:
+                result["configs"].append(side_config(name, 0, args.precision, device, steps=3, warmup=1, shard_of=shard_of))
+            except Exception as e:          # a side line that cannot run must not take the benchmark line with it
+                result["configs"].append({"workload": name, "error": f"{type(e).__name__}: {e}"})
+        result["api_path"] = []
+        for name in ("xlmr_gpt2", "mistral_gpt2_32k"):
+            try:
+                r = api_path(name, args.precision, device)
+                ref = ms_per_step if name == args.workload else next((c["ms_per_step"] for c in result["configs"] if c.get("workload") == name and "ms_per_step" in c), None)
+                r["ms_per_step_engine"] = ref
+                r["over_engine_step"] = (r["ms"] / ref) if ref else None
+                result["api_path"].append(r)
+            except Exception as e:
+                result["api_path"].append({"workload": name, "error": f"{type(e).__name__}: {e}"})
     if rank == 0 and world == 1 and not exchange and not args.no_live_traffic and not args.rows:
         # roofline.traffic measured HERE: same build, same box, same workload, right after the timed region
         live, info = measure_traffic_live(args)

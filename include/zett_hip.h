@@ -297,7 +297,10 @@ int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* of
  * returns what zett_retokenize would (ZETT_E_KEY / ZETT_E_STATE) for the EARLIEST failing call, whose ordinal since the
  * previous query goes to *bad_call and whose token index to *bad_token (both nullable; -1 when nothing failed).  The id
  * matrices of the calls before the failing one are complete.  A synchronous zett_retokenize in between discards what the
- * asynchronous calls before it reported; at most 2^20 calls may be outstanding between two queries (ZETT_E_STATE beyond).  The reference has no counterpart (its loop is host code). */
+ * asynchronous calls before it reported; at most 2^20 calls may be outstanding between two queries (ZETT_E_STATE beyond).
+ * LIFETIME: `offsets` of every outstanding call must stay allocated and unchanged until zett_retok_result returns — on a
+ * ZETT_E_KEY it is read back to name the failing token (zett_amd.surface_forms.DeviceRetokenizer holds the tensors).  A call
+ * that fails while it enqueues is taken back (it does not count as outstanding).  The reference has no counterpart (its loop is host code). */
 int zett_retokenize_async(zett_retok* r, const uint8_t* token_chars, const int32_t* offsets, int64_t n_tokens, int64_t n_text,
                           int32_t maxlen, int32_t pad_id, int32_t* out, void* stream);
 int zett_retok_result(zett_retok* r, int64_t* n_truncated, int64_t* bad_call, int64_t* bad_token);

@@ -18,7 +18,9 @@ grep "zett gemm" $src/gemm_launch_log.txt > ${pre}_gemm_launch_log.txt
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 g = [r for r in rows if "gemm" in r["Name"]]
-z = [r for r in rows if "zett::" in r["Name"] and "convert_f32" not in r["Name"] and "fold_weight" not in r["Name"]]
+# (rocprofv3 writes some names demangled — "zett::retok_tokens_kernel(...)" — and some mangled — "_ZN4zett16gemm4d_tn_kernel...")
+z = [r for r in rows if ("zett::" in r["Name"] or "_ZN4zett" in r["Name"]) and "convert_f32" not in r["Name"] and "fold_weight" not in r["Name"]]
+assert all(r in z for r in g), "a GEMM kernel the path filter does not see"
 tot = sum(int(r["TotalDurationNs"]) for r in g); calls = sum(int(r["Calls"]) for r in g); allz = sum(int(r["TotalDurationNs"]) for r in z)
 print(f"GEMM kernels (all tile variants): {calls} launches, {tot / 1e6:.1f} ms in 8 forwards = {tot / 8e6:.2f} ms per forward; every kernel of the path "
       f"(zett::*): {allz / 8e6:.2f} ms per forward, of which {100 * (allz - tot) / allz:.1f} % is not a GEMM.")

@@ -7,14 +7,25 @@ scripts/convert_to_pt.py:26-27).
 """
 import os as _os
 
-# One process per GPU under torchrun (WORLD_SIZE > 1): the row exchange is real xGMI traffic, and it — like the plan-ahead of
-# zett_forward_prepare — overlaps a forward only if its streams do not share the forward's HARDWARE queue.  The HIP runtime
-# multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) queues, and an eagerly initialised RCCL communicator takes
-# its share first (profiles/r4g_blocks.md, NOTEBOOK R4.9).  Eight queues keep them apart.  Read when the HIP runtime initialises
-# (the first CUDA call of the process), hence set here, at import; a value the user set wins.  Not for a single process: there
-# the "exchange" is a local copy and serialised streams are the faster schedule (65.3 vs 69.4 ms per four-block step).
-if int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1:
-    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+def configure_hw_queues(world_size=None, log=True) -> bool:
+    """Launcher hook (bench.py, scripts/transfer.py call it first thing; importing the package does NOT): one process per GPU
+    under torchrun (WORLD_SIZE > 1) wants GPU_MAX_HW_QUEUES=8.  The row exchange is real xGMI traffic there, and it — like the
+    plan-ahead of zett_forward_prepare — overlaps a forward only if its streams do not share the forward's HARDWARE queue; the
+    HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) queues and an eagerly initialised RCCL
+    communicator takes its share first (profiles/r4g_blocks.md, NOTEBOOK R4.9).  The variable is read when the HIP runtime
+    initialises (the first CUDA call of the process): call this BEFORE any torch.cuda call; a value the user set wins; a single
+    process keeps the default (its "exchange" is a local copy and serialised streams are the faster schedule).  Returns True
+    when the variable was set here."""
+    world = int(world_size if world_size is not None else (_os.environ.get("WORLD_SIZE", "1") or 1))
+    if world <= 1 or "GPU_MAX_HW_QUEUES" in _os.environ:
+        return False
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    if log and int(_os.environ.get("RANK", "0") or 0) == 0:
+        import sys
+        print(f"[zett_amd] WORLD_SIZE={world}: GPU_MAX_HW_QUEUES=8 for this process (set it yourself to override)", file=sys.stderr)
+    return True
+
 
 from .config import MODEL_TYPE, ZettHypernetConfig  # noqa: F401,E402
 

@@ -74,7 +74,11 @@ def _object_stale(src: str, obj: str) -> bool:
     return any(os.path.getmtime(p) > built for p in [src, *_includes(src)])
 
 
+LAST_BUILD = {"hipcc_commands": 0}      # what the most recent build() did (printed by __graft_entry__.build)
+
+
 def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
+    LAST_BUILD["hipcc_commands"] = 0
     if not force and not is_stale():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
@@ -96,6 +100,7 @@ def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
         list(pool.map(run, todo))
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp", *objs])
+    LAST_BUILD["hipcc_commands"] = len(todo) + 1
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

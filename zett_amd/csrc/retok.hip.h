@@ -713,24 +713,36 @@ int zett_retokenize_async(zett_retok* r, const uint8_t* token_chars, const int32
     int32_t* blk_scan = blk_count + n_blocks + 1;
     unsigned long long* words = r->misc.as<unsigned long long>();
     const uint32_t call = r->calls++;
-    r->recent.push_back({offsets, n_tokens});
-    hipLaunchKernelGGL(fill_i32_kernel, dim3(1024), dim3(256), 0, st, out, n_tokens * (int64_t)maxlen, pad_id);   // :662-666
-    if (n_blocks > 0) {
-        hipLaunchKernelGGL((chars_to_bytes_kernel<0>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
-                           blk_count, (uint8_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, call);
-        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, blk_count, blk_scan, (int64_t)n_blocks);
-        hipLaunchKernelGGL((chars_to_bytes_kernel<1>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
-                           blk_scan, r->raw.as<uint8_t>(), r->raw_pos.as<uint32_t>(), words, call);
-    } else {
-        HIP_TRY(hipMemsetAsync(blk_scan, 0, 8, st));
+    r->recent.push_back({offsets, n_tokens});          // (the caller keeps `offsets` alive until zett_retok_result: include/zett_hip.h)
+    // a failed enqueue takes its call back: zett_retok_result must not wait on a `done` event that was never recorded for it,
+    // and the words (which kernels of this call may already have touched) start afresh with the next call
+    auto enqueue = [&]() -> int {
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(1024), dim3(256), 0, st, out, n_tokens * (int64_t)maxlen, pad_id);   // :662-666
+        if (n_blocks > 0) {
+            hipLaunchKernelGGL((chars_to_bytes_kernel<0>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
+                               blk_count, (uint8_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, call);
+            hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, blk_count, blk_scan, (int64_t)n_blocks);
+            hipLaunchKernelGGL((chars_to_bytes_kernel<1>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
+                               blk_scan, r->raw.as<uint8_t>(), r->raw_pos.as<uint32_t>(), words, call);
+        } else {
+            HIP_TRY(hipMemsetAsync(blk_scan, 0, 8, st));
+        }
+        hipLaunchKernelGGL(token_raw_offsets_kernel, dim3((unsigned)((n_tokens + 1 + 255) / 256)), dim3(256), 0, st, offsets, n_tokens,
+                           n_text, r->raw_pos.as<uint32_t>(), blk_scan, n_blocks, r->raw_off.as<int32_t>());
+        hipLaunchKernelGGL(retok_tokens_kernel, dim3((unsigned)((n_tokens + 63) / 64)), dim3(64), 0, st, r->t, r->raw.as<uint8_t>(),
+                           r->raw_off.as<int32_t>(), n_tokens, maxlen, pad_id, out, r->scratch.as<int32_t>(), words + 2, words + 1, call);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(r->host_pinned + 4, words, 24, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(r->done, st));
+        return 0;
+    };
+    if (int rc = enqueue()) {
+        (void)hipStreamSynchronize(st);
+        r->calls--;
+        r->recent.pop_back();
+        if (r->calls == 0) r->words_ready = false;
+        return rc;
     }
-    hipLaunchKernelGGL(token_raw_offsets_kernel, dim3((unsigned)((n_tokens + 1 + 255) / 256)), dim3(256), 0, st, offsets, n_tokens,
-                       n_text, r->raw_pos.as<uint32_t>(), blk_scan, n_blocks, r->raw_off.as<int32_t>());
-    hipLaunchKernelGGL(retok_tokens_kernel, dim3((unsigned)((n_tokens + 63) / 64)), dim3(64), 0, st, r->t, r->raw.as<uint8_t>(),
-                       r->raw_off.as<int32_t>(), n_tokens, maxlen, pad_id, out, r->scratch.as<int32_t>(), words + 2, words + 1, call);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(r->host_pinned + 4, words, 24, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(r->done, st));
     return 0;
 }
 

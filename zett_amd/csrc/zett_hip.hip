@@ -891,6 +891,20 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     }
     ps.pending = false;
     h->plan_cur ^= 1;
+    // From here on kernels that read the slot (and the pinned host words) may be enqueued: whatever way this function is left —
+    // a failed launch, a failed workspace reservation, a lane that fails after the other one was launched — the second lane is
+    // joined to `st` and ps.released is recorded behind everything, so that a later zett_forward_prepare / zett_forward never
+    // rewrites the plan under kernels still in flight.
+    struct SlotGuard {
+        zett_hypernet* h; zett_hypernet::PlanSlot* ps; hipStream_t st; bool lane_forked = false;
+        ~SlotGuard() {
+            if (lane_forked && h->lane_stream && h->lane_ev[3]) {
+                (void)hipEventRecord(h->lane_ev[3], h->lane_stream);
+                (void)hipStreamWaitEvent(st, h->lane_ev[3], 0);
+            }
+            if (ps->released) (void)hipEventRecord(ps->released, st);
+        }
+    } slot_guard{h, &ps, st};
     const PlanLayout PL = plan_layout(h, ps, N, seq);
     const PlanArrays& p = PL.p;
     const bool pair_plan = PL.pair_plan;
@@ -1223,10 +1237,9 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         const size_t off1 = (size_t)(hoff[ra] - hoff[0]) + 384;
         HIP_TRY(hipEventRecord(h->lane_ev[0], st));                       // fork: the plan and the table are complete
         HIP_TRY(hipStreamWaitEvent(h->lane_stream, h->lane_ev[0], 0));
+        slot_guard.lane_forked = true;                                    // (joined by the guard on every exit path)
         if (int rc = run_chunk(ra, N, Lane{h->lane_stream, off1}, 2)) return rc;
-        HIP_TRY(hipEventRecord(h->lane_ev[3], h->lane_stream));
         if (int rc = run_chunk(0, ra, Lane{st, 0}, 3)) return rc;
-        HIP_TRY(hipStreamWaitEvent(st, h->lane_ev[3], 0));                // join
     } else {
         int64_t r0 = 0;
         while (r0 < N) {
@@ -1238,8 +1251,12 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     }
     R.st = st;
     if (R.rc) return R.rc;
-    HIP_TRY(hipEventRecord(ps.released, st));          // the plan slot may be rewritten behind this point (zett_forward_prepare)
-    h->out_recorded = true;
+    if (slot_guard.lane_forked) {                      // join now (the guard then has nothing left to join)
+        HIP_TRY(hipEventRecord(h->lane_ev[3], h->lane_stream));
+        HIP_TRY(hipStreamWaitEvent(st, h->lane_ev[3], 0));
+        slot_guard.lane_forked = false;
+    }
+    h->out_recorded = true;          // (ps.released — the plan slot may be rewritten behind it, zett_forward_prepare — is recorded by the guard)
 
     if (h->time_gemm) {
         HIP_TRY(hipStreamSynchronize(st));

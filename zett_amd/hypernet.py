@@ -230,6 +230,8 @@ class ZettHypernet(PreTrainedModel):
         # forward (one 4-byte read behind a stream sync), and on a hit repeat the call with bf16 operands (fp32's
         # exponent range, the arithmetic of the reference CLI) with a warning; the model then stays on bf16.  Set
         # range_guard = False to take the asynchronous forward and call engine(...).range_flags() yourself.
+        # The per-call check covers f16 ONLY: bf16 / f32 forwards have nothing to fall back to and stay asynchronous — a caller
+        # that wants their non-finite-output warning calls check_outputs() (predict_vocabulary does, once, at the end).
         self.range_guard = True
         for name, shape in weight_shapes(self.dims).items():
             _attach(self, name, nn.Parameter(torch.empty(shape, dtype=torch.float32), requires_grad=False))
@@ -273,6 +275,7 @@ class ZettHypernet(PreTrainedModel):
         for eng in self._engines.values():
             eng.close()
         self._engines.clear()
+        self.__dict__.pop("_param_list", None)
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -286,8 +289,11 @@ class ZettHypernet(PreTrainedModel):
         return out
 
     def refresh_weights(self) -> None:
-        """Re-upload parameters now.  Not needed for correctness any more: engine() notices in-place modification through
-        the parameters' version counters and rebuilds; kept for callers that want the upload to happen at a chosen point."""
+        """Re-upload parameters at the next forward.  REQUIRED after writes that go through ``p.data`` (``p.data.copy_(...)``,
+        ``p.data.add_(...)``, an EMA or a manual weight load written that way): those do not bump the tensor's version
+        counter (torch semantics), so engine() cannot see them.  Writes through the parameter itself (``optimizer.step()``,
+        ``p.copy_()`` / ``p.add_()`` under no_grad, ``load_state_dict``, ``.to()``) and storage replacement (``p.data = t``)
+        are noticed without it."""
         self._drop_engines()
 
     def engine(self, device: torch.device, precision: Optional[str] = None) -> HipEngine:
@@ -295,10 +301,11 @@ class ZettHypernet(PreTrainedModel):
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         key = (str(device), precision)
-        # An engine holds the weight copy uploaded when it was built.  Parameters modified in place since then (optimizer.step(),
-        # p.data.copy_(...), p.add_(...): all bump the tensor's version counter; p.data = t replaces the storage) make it stale:
-        # rebuilt here, so that eval / no_grad prediction after a training step never runs on pre-training weights
-        # (train.py's eval_step pattern).  Costs one pass over ~50 Python attributes per forward.
+        # An engine holds the weight copy uploaded when it was built.  Parameters modified in place since then through the
+        # parameter (optimizer.step(), p.copy_(...), p.add_(...): they bump the tensor's version counter) or given a new storage
+        # (p.data = t) make it stale: rebuilt here, so that eval / no_grad prediction after a training step never runs on
+        # pre-training weights (train.py's eval_step pattern).  NOT seen: writes through p.data (p.data.add_(...) leaves the
+        # version counter alone) — those callers call refresh_weights().  Costs one pass over ~50 tensors per forward (~15 us).
         stamp = self._weights_stamp()
         eng = self._engines.get(key)
         if eng is not None and eng.weights_stamp != stamp:
@@ -312,7 +319,17 @@ class ZettHypernet(PreTrainedModel):
         return eng
 
     def _weights_stamp(self):
-        return tuple((p._version, p.data_ptr()) for p in self.parameters())
+        # (the list of Parameter objects is cached: _drop_engines — every path that can replace them: .to(), load_state_dict —
+        #  forgets it; named_parameters() walks ~40 modules and was most of this function's cost)
+        params = self.__dict__.get("_param_list")
+        if params is None:
+            params = self.__dict__["_param_list"] = list(self.parameters())
+        try:
+            return tuple([(p._version, p.data_ptr()) for p in params])
+        except RuntimeError:
+            # a model built under torch.inference_mode(): inference tensors have no version counter (and cannot be modified
+            # in place outside inference mode either); the storage pointers alone identify the upload
+            return tuple([(0, p.data_ptr()) for p in params])
 
     # ---- the forward ----------------------------------------------------------------------
     def forward(self, target_surface_forms, target_priors=None, source_embeddings=None, lang_index=None,
@@ -359,6 +376,7 @@ class ZettHypernet(PreTrainedModel):
         if self.precision in ("f16", "fp16", "float16") and self.range_guard:
             try:
                 eng = self.engine(device)
+                self._last_engine = eng
                 out = eng.forward(surface_forms, source_embeddings, lang)
                 flags = eng.range_flags()
             except _lib.RangeError as err:           # zett_finalize: a weight does not fit the half type

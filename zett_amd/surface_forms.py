@@ -217,6 +217,7 @@ class DeviceRetokenizer:
         index = device.index if device.index is not None else torch.cuda.current_device()
         _lib.check(self.lib.zett_retok_create(C.byref(m), index, C.byref(handle)), "zett_retok_create")
         self.handle = handle
+        self._outstanding = []          # (text, offsets) tensors of the asynchronous calls since the last result()
 
     def encode(self, tokens: Sequence[str]) -> Tuple[torch.Tensor, torch.Tensor, int]:
         """Host side of a call: UTF-8 text of the byte-level token strings + int32 offsets, copied to the device."""
@@ -263,12 +264,14 @@ class DeviceRetokenizer:
                                                 n_text, int(maxlen), self.spec.pad_token_id,
                                                 C.c_void_p(out.data_ptr()), C.c_void_p(stream))
         _lib.check(rc, "zett_retokenize_async")
+        self._outstanding.append((d_text, d_off))       # zett_retok_result reads `offsets` back on a KeyError: alive until result()
         return out
 
     def result(self) -> int:
         """Waits for the asynchronous calls since the last result(): their number of truncated tokens; raises what run() raises."""
         n_trunc, bad_call, bad = C.c_int64(0), C.c_int64(-1), C.c_int64(-1)
         rc = self.lib.zett_retok_result(self.handle, C.byref(n_trunc), C.byref(bad_call), C.byref(bad))
+        self._outstanding.clear()
         if rc == _lib.E_KEY:
             raise KeyError(f"call {bad_call.value}, token {bad.value}: {self.lib.zett_last_error().decode()}")
         if rc == _lib.E_STATE:

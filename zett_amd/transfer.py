@@ -50,29 +50,30 @@ Predict = Callable[[torch.Tensor], Tuple[torch.Tensor, Optional[torch.Tensor], t
 
 def get_sample_indices(n: int, p: np.ndarray, batch_size: int, min_k: int, n_samples: int,
                        rng: Optional[np.random.Generator] = None) -> np.ndarray:
-    """Prior-weighted batch composition of ``--sample_batches`` (zett/utils.py:612-648): every
-    token appears at least ``min_k`` times through shuffled passes, the rest of each batch is
-    drawn without replacement proportionally to exp(prior)."""
+    """Batch composition of ``--sample_batches`` (contract of zett/utils.py:612-648): the ``n_samples`` batches form
+    ``min_k`` sweeps of ``n_samples // min_k`` batches; within a sweep a fresh shuffle of all ``n`` tokens is dealt over the
+    sweep's batches (``n // per_sweep`` each, the sweep's last batch takes the remainder), so every token is visited at
+    least ``min_k`` times; each batch is then filled up to ``batch_size`` with tokens drawn without replacement,
+    proportionally to exp(prior), from those it does not hold yet.  The random stream is consumed in the reference's order
+    (one permutation up front and one after each sweep, one weighted draw per batch)."""
     rng = rng or np.random.default_rng()
-    weights = np.exp(np.where(p > NEGATIVE_INF_FILL_VALUE, p, -np.inf))
-    n_per_k = n_samples // min_k
-    assert n_per_k * min_k == n_samples
-    order = rng.permutation(n)
-    cursor = 0
+    per_sweep, rem = divmod(n_samples, min_k)
+    assert rem == 0 and per_sweep > 0
+    share = n // per_sweep
+    # dealt[j] = the slice of a sweep's shuffle that batch j of the sweep holds
+    bounds = [(j * share, n if j == per_sweep - 1 else (j + 1) * share) for j in range(per_sweep)]
+    prior_weight = np.exp(np.where(p > NEGATIVE_INF_FILL_VALUE, p, -np.inf))
     out = np.empty((n_samples, batch_size), dtype=np.int32)
+    shuffle = rng.permutation(n)
     for i in range(n_samples):
-        closing = (i + 1) % n_per_k == 0
-        take = len(order) - cursor if closing else len(order) // n_per_k
-        out[i, :take] = order[cursor:cursor + take]
-        if closing:
-            cursor = 0
-            order = rng.permutation(n)
-        else:
-            cursor += take
-        rest = weights.copy()
-        rest[out[i, :take]] = 0
-        rest /= rest.sum()
-        out[i, take:] = rng.choice(n, size=batch_size - take, p=rest, replace=False)
+        lo, hi = bounds[i % per_sweep]
+        dealt = shuffle[lo:hi]
+        out[i, :len(dealt)] = dealt
+        if (i + 1) % per_sweep == 0:
+            shuffle = rng.permutation(n)          # (the reference draws the next sweep's shuffle before the batch's fill)
+        w = prior_weight.copy()
+        w[dealt] = 0
+        out[i, len(dealt):] = rng.choice(n, size=batch_size - len(dealt), p=w / w.sum(), replace=False)
     return out
 
 
@@ -206,10 +207,15 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
         return out
 
     if not args.do_batching:   # scripts/transfer.py:243-262 pads to a multiple of 128 for XLA; no need here
-        return predict(target_surface_form_matrix)
-    n_embd = hypernet.config.n_embd
-    return batched_inference(predict, target_surface_form_matrix, n_embd, args.batch_size, args.sample_batches,
-                             target_priors, args.min_k, args.n_samples, rng)
+        out = predict(target_surface_form_matrix)
+    else:
+        out = batched_inference(predict, target_surface_form_matrix, hypernet.config.n_embd, args.batch_size, args.sample_batches,
+                                target_priors, args.min_k, args.n_samples, rng)
+    # bf16 / f32 forwards are asynchronous and unguarded (ZettHypernet._guarded_forward): ask once, here, whether the last
+    # forward's outputs were finite (warns; the f16 path has asked after every call)
+    if hasattr(hypernet, "check_outputs"):
+        hypernet.check_outputs()
+    return out
 
 
 def _lib_range_error(msg: str):
@@ -318,6 +324,7 @@ def main(argv=None):
     from zett_amd.surface_forms import surface_form_matrix_device
 
     (args,) = HfArgumentParser([Args]).parse_args_into_dataclasses(argv)
+    zett_amd.configure_hw_queues()          # (torchrun: before the HIP runtime initialises)
     if not torch.cuda.is_available():
         raise SystemExit("scripts/transfer.py needs an MI355X: torch.cuda.is_available() is False")
     device = init_distributed()          # one process per GPU under torchrun; a single process otherwise
