@@ -140,7 +140,7 @@ def measure_traffic_live(args, timeout_s=240):
             out_dir = os.path.join(work, counter)
             cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "t", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--workload", args.workload, "--precision", args.precision,
-                   "--no-cpu-baseline", "--no-alt-precision", "--no-live-traffic"]
+                   "--no-cpu-baseline", "--no-alt-precision", "--no-live-traffic", "--no-side-configs"]
             env = dict(os.environ, TMPDIR=work)
             res = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=timeout_s)
             files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)

@@ -26,9 +26,10 @@
 extern "C" {
 #endif
 
-#define ZETT_ABI_VERSION 5      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range;
+#define ZETT_ABI_VERSION 6      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range;
                                    4: ZETT_RETOK_WORDPIECE (zett_retok_model gained piece_continuing, max_input_chars_per_word);
-                                   5: zett_forward_prepare, zett_retokenize_async / zett_retok_result */
+                                   5: zett_forward_prepare, zett_retokenize_async / zett_retok_result;
+                                   6: zett_retokenize_async takes NUL-separated text (offsets == NULL); options gemm_tail_split */
 
 enum zett_status {
     ZETT_OK = 0,
@@ -232,7 +233,11 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
  * operands and K >= "gemm4d_min_k", default 512), 8 = as 7 with the generic epilogue drain; all produce
  * identical bits; a forced variant falls back to 2 where its preconditions do not
  * hold), "gemm_tile_order" (A/B only: 0 = the order in which gemm4d walks column
- * tiles first, default; 1 = row tiles first; same bits). */
+ * tiles first, default; 1 = row tiles first; same bits), "gemm_tail_split" (0/1/2/3, default 1: a 256x256-tile launch whose
+ * tiles fill R whole rounds of the 256 CUs and part of one more is cut into 256x256 tiles on the rows of the whole rounds and
+ * 128x256 tiles — twice as many workgroups of half the work — on the rest, when that is cheaper (a rank's 4 096-row shard at
+ * 8 GPUs: M = 9 682, N = 4096 is 2.375 rounds); 0 = never, 2 = cut every launch in the middle, 3 = 128x256 tiles only (tests);
+ * same bits). */
 int zett_set_option(zett_hypernet* h, const char* key, int64_t value);
 
 /* ---- retokenizer ------------------------------------------------------------
@@ -298,6 +303,10 @@ int zett_retokenize(zett_retok* r, const uint8_t* token_chars, const int32_t* of
  * previous query goes to *bad_call and whose token index to *bad_token (both nullable; -1 when nothing failed).  The id
  * matrices of the calls before the failing one are complete.  A synchronous zett_retokenize in between discards what the
  * asynchronous calls before it reported; at most 2^20 calls may be outstanding between two queries (ZETT_E_STATE beyond).
+ * offsets == NULL (ABI 6): token_chars holds the n_tokens tokens NUL-SEPARATED (n_text bytes, n_tokens - 1 of them NUL — exactly
+ * what "\0".join(tokens).encode() gives; no byte-level token holds a NUL, byte 0 being written U+0100): the token boundaries
+ * are found on the device by the scan that numbers the characters, so the host does no per-token work at all.  A text with
+ * another number of separators is reported as ZETT_E_INVALID by zett_retok_result.
  * LIFETIME: `offsets` of every outstanding call must stay allocated and unchanged until zett_retok_result returns — on a
  * ZETT_E_KEY it is read back to name the failing token (zett_amd.surface_forms.DeviceRetokenizer holds the tensors).  A call
  * that fails while it enqueues is taken back (it does not count as outstanding).  The reference has no counterpart (its loop is host code). */

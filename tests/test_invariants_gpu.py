@@ -104,6 +104,31 @@ def test_gemm_tile_variants_bit_identical(precision, name, rows):
             eng.set_option("gemm_variant", bad)
 
 
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("name,rows", [("tinyllama_neox", 1500), ("tinyllama_neox", 37), ("mistral_gpt2_32k", 700)])
+def test_gemm_tail_split_bit_identical(precision, name, rows):
+    """gemm4d's 128x256 HALF tile (r5: the partly filled last round of a launch, gemm4d.hip.h) runs the K order and the epilogue
+    arithmetic of the 256x256 tile: with the split off (0), chosen per launch (1, default), forced in the middle of every launch
+    (2) and with half tiles only (3) the outputs are the same bits — on the default path (LayerNorm fold, 16-bit residual
+    stream in f16: the LN16 / LO_FOLD / LO_LN / F32_SCALE_FOLD epilogues) and with the fold off (F32 / F32_LN-free path: LO,
+    BOTH, F32 with residual, F32_SCALE)."""
+    cfg, _, src_dtype, hist = synth.workload(name)
+    eng = _engine(cfg, 5, precision)
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 5, dtype=src_dtype)).cuda()
+    ids = synth.make_surface_forms(cfg, rows, seed=5, hist=hist, n_special=2)
+    lang = 1 if cfg.get("hn_embed_lang_id") else -1
+    for fold in (1, 0):
+        eng.set_option("ln_fold", fold)
+        eng.set_option("gemm_tail_split", 0)
+        base = _run(eng, ids, src, lang)
+        assert all(t is None or bool(torch.isfinite(t).all()) for t in base)
+        for mode in (1, 2, 3):
+            eng.set_option("gemm_tail_split", mode)
+            assert _eq(_run(eng, ids, src, lang), base), f"gemm_tail_split {mode}, ln_fold {fold}"
+    with pytest.raises(ValueError):
+        eng.set_option("gemm_tail_split", 4)
+
+
 def test_repeated_launches_identical_bits_small_grids():
     """Race screen: few workgroups and long K (a 32-row batch of the TinyLlama-shape hypernet) leave
     the waves of a workgroup free to drift apart; a missing barrier in a K loop shows up as runs

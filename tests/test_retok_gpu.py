@@ -201,3 +201,45 @@ def test_byt5_hn_tokenizer_branch():
         got, n_tr = get_surface_form_matrix(g["tokens"], int(maxlen), hn)
         np.testing.assert_array_equal(got, np.array(case["expected"], dtype=np.int32))
         assert n_tr == case["n_truncated"]
+
+
+def test_separator_mode_equals_offsets_mode():
+    """ABI 6: zett_retokenize_async with offsets == NULL takes the tokens NUL-separated and finds their boundaries on the
+    device (what __call__ / get_surface_form_matrix now send); the offsets mode (encode() + run(): what bench.py and
+    zett_retokenize use) must give the same matrix — empty tokens at the head, in the middle and at the end, two-byte
+    characters straddling the 16-byte spans of the byte-table kernel's threads and its 4 096-byte blocks, one token, and a
+    list long enough for several blocks."""
+    import torch
+    from zett_amd.surface_forms import DeviceRetokenizer
+    g = json.load(open(os.path.join(util.GOLDEN, "retok_bytebpe.json")))
+    rt = DeviceRetokenizer(_spec(g), torch.device("cuda", 0))
+    rng = random.Random(7)
+    alphabet = "abcdefghijklmnopqrstuvwxyzĠĊčĉ0123456789"
+    cases = [["a"], [""], ["", "a"], ["a", ""], ["", "", "Ġ", ""], ["Ġ"] * 5000,
+             ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 23))) for _ in range(20000)]]
+    for tokens in cases:
+        d_text, d_off, n = rt.encode_joined(tokens)
+        assert d_off is None
+        sep = rt.run_async(d_text, d_off, n, 9)
+        assert isinstance(rt.result(), int)
+        off, n_tr = rt.run(*rt.encode(tokens), 9)
+        assert torch.equal(sep, off), len(tokens)
+        called, n_tr2 = rt(tokens, 9)
+        assert torch.equal(called, off) and n_tr2 == n_tr
+    # a bad character is reported with its token, in either mode (the reference raises KeyError(<character>))
+    tokens = ["fine"] * 4500 + ["not▁byte"] + ["x"] * 10
+    with pytest.raises(KeyError) as e:
+        rt(tokens, 9)
+    assert e.value.args[0] == "▁"
+    # a token holding a NUL cannot be sent separator-joined: the offsets path takes it and reports the NUL itself
+    with pytest.raises(KeyError) as e:
+        rt(["a", "b\0c"], 9)
+    assert e.value.args[0] == "\0"
+    # the C ABI refuses a NUL-separated text with the wrong number of separators
+    from zett_amd import _lib
+    d_text, _, _ = rt.encode_joined(["a", "b", "c"])
+    rt.run_async(d_text, None, 5, 9)
+    with pytest.raises(Exception) as e:
+        rt.result()
+    assert "separators" in str(e.value)
+    rt.close()

@@ -3,7 +3,7 @@
 # Each flag set runs twice, interleaved; prints ms_per_step (instrumented / uninstrumented), GEMM fraction, GEMM ms.
 for rep in 1 2; do
   for flags in "$@"; do
-    python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-alt-precision --no-live-traffic $flags 2>/dev/null | tail -1 | FLAGS="$flags" python -c '
+    python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-alt-precision --no-live-traffic --no-side-configs $flags 2>/dev/null | tail -1 | FLAGS="$flags" python -c '
 import json, os, sys
 d = json.loads(sys.stdin.read())
 r = d["roofline"]

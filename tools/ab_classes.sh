@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: as tools/ab.sh, but prints the per-class GEMM table of each flag set (one run each).
 for flags in "$@"; do
-  python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-alt-precision --no-live-traffic $flags 2>/dev/null | tail -1 | FLAGS="$flags" python -c '
+  python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-alt-precision --no-live-traffic --no-side-configs $flags 2>/dev/null | tail -1 | FLAGS="$flags" python -c '
 import json, os, sys
 d = json.loads(sys.stdin.read())
 r = d["roofline"]

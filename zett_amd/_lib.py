@@ -40,7 +40,7 @@ class ZettConfig(C.Structure):
         ("ln_eps_encoder", C.c_float), ("ln_eps_projector", C.c_float)]
 
 
-ABI_VERSION = 5      # ZETT_ABI_VERSION of include/zett_hip.h
+ABI_VERSION = 6      # ZETT_ABI_VERSION of include/zett_hip.h
 
 
 class ZettStats(C.Structure):

@@ -306,6 +306,8 @@ struct GemmArgs {
     GemmEpilogue<T> epi;
     int tile_order = 0;     // gemm4d only: 0 = column-tile-major groups (default), 1 = row-tile-major groups (A/B option)
     int group = 0;          // gemm4d only: column tiles per group (order 0) / row tiles per group (order 1); 0 = the default (4)
+    int row0 = 0;           // gemm4d only.  To the launcher: -1 = cut a partly filled last round into 128x256 tiles (gemm4d_row_split), 0 = 256x256
+                            // tiles only, > 0 = the caller's cut, -2 = 128x256 tiles only.  To the kernel: the first row its tiles cover
 };
 
 constexpr int GEMM_BM = 128;

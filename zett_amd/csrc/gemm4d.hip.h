@@ -43,6 +43,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "gemm_tile.hip.h"
@@ -96,12 +97,35 @@ constexpr int G4D_EPI_REGION = 64 * G4D_EPI_STRIDE * 4;               // bytes p
 constexpr int G4D_LDS_BYTES = 4 * G4D_EPI_REGION;                     // 132 KiB (the K loop uses the first 128)
 static_assert(G4D_LDS_BYTES >= G256_LDS_BYTES && G4D_LDS_BYTES <= 160 * 1024, "LDS budget");
 
-template <typename T, int ACT = ACT_NONE, bool RES = false, int EPI = G4D_EPI_GENERIC>
+// Geometry of the two tiles.  NOTE for whoever edits this kernel: local arrays whose BOUND depends on HALF (a_voff[AREQ],
+// acc[MI][8], fa[2][MI]) made clang's HOST pass silently drop the kernel's stub (no diagnostic; the objects then carry every
+// gemm4d kernel as an undefined symbol and the library does not load) — the arrays therefore keep the full tile's bounds and the
+// HALF tile uses their first half.  `hipcc --cuda-host-only -S -emit-llvm` + grep "define.*__device_stub__" shows it in a second.
+template <bool HALF> struct G4dGeom {
+    static constexpr int BM = HALF ? 128 : G256_BM;      // rows of the tile
+    static constexpr int WROWS = BM / 2;                 // rows of a wave's quadrant
+    static constexpr int MI = WROWS / 16;                // 16-row MFMA blocks per wave
+    static constexpr int AREQ = BM / 32;                 // LDS-DMA requests per wave, K step and A image (8 rows each)
+    static constexpr int NREQ = AREQ + 8;                // ... and per K step in all
+    static constexpr int NPASS = WROWS / 64;             // epilogue passes of 64 rows
+};
+
+// HALF (r5): the same kernel on a 128x256 tile — four waves of 64x128 each (128 accumulators), covering rows [g.row0, g.M) only.
+// It exists for ONE purpose: the partly filled last round of a launch.  A launch whose 256x256 tiles fill R whole rounds of the
+// 256 CUs and a fraction of one more is cut by the launcher (gemm4d_row_split) into full tiles on rows [0, row0) — whole rounds —
+// and HALF tiles on the rest: twice as many workgroups of half the work each, so the last round's tiles spread over the idle CUs
+// (M = 9 682 at N = 4096, a rank's shard at 8 GPUs: 608 tiles = 2.375 rounds -> 512 tiles + 192 half tiles).  A HALF tile's
+// K step is 64 MFMAs against 12 LDS-DMA requests and 12 + 12 fragment reads (the full tile: 128 against 16 and 16 + 16), so its
+// K loop is slower per FLOP (NOTEBOOK R3.1 measured 28 % for two half tiles per CU) — it only ever replaces idle CUs.  Same K
+// order per accumulator, same epilogue arithmetic: identical bits (tests/test_invariants_gpu.py).
+template <typename T, int ACT = ACT_NONE, bool RES = false, int EPI = G4D_EPI_GENERIC, bool HALF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4d_tn_kernel(GemmArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = GEMM_ROW_BYTES / (int)sizeof(T);
+    typedef G4dGeom<HALF> GEO;          // (static members, not constexpr locals: see G4dGeom)
+    static_assert(!HALF || EPI != G4D_EPI_GENERIC, "the half tile carries the streamlined epilogues only");
 
-    const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
+    const int tiles_m = (g.M - g.row0 + GEO::BM - 1) / GEO::BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     const int nwg = tiles_m * tiles_n;
     int wg = blockIdx.x;
@@ -130,7 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         tm = first_m + (wg % group_size) % gm;
         tn = (wg % group_size) / gm;
     }
-    const int m0 = tm * G256_BM, n0 = tn * G256_BN;
+    const int m0 = g.row0 + tm * GEO::BM, n0 = tn * G256_BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -141,21 +165,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // chunk lane%8 of its row, which holds source chunk (lane%8) ^ swz(row).  Rows past the edge are clamped.
     const unsigned char* a_base = (const unsigned char*)(g.A + (size_t)m0 * g.lda);
     const unsigned char* w_base = (const unsigned char*)(g.W + (size_t)n0 * g.ldw);
-    uint32_t a_voff[8], w_voff[8];
+    // (HALF: the A image is 128 rows — request r (0..3) of a wave moves rows wave*32 + r*8 + lane/8)
+    uint32_t a_voff[8], w_voff[8];          // (HALF uses a_voff[0..3]; arrays whose bound depends on HALF make clang drop the host stub, see G4dGeom)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int row = wave * 64 + r * 8 + (lane >> 3);
         const int chunk = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
-        int ar = row; ar = m0 + ar < g.M ? ar : g.M - 1 - m0;
         int wr = row; wr = n0 + wr < g.N ? wr : g.N - 1 - n0;
-        a_voff[r] = (uint32_t)ar * (uint32_t)g.lda * (uint32_t)sizeof(T) + chunk;
         w_voff[r] = (uint32_t)wr * (uint32_t)g.ldw * (uint32_t)sizeof(T) + chunk;
+    }
+#pragma unroll
+    for (int r = 0; r < GEO::AREQ; ++r) {
+        const int row = wave * (GEO::AREQ * 8) + r * 8 + (lane >> 3);
+        const int chunk = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
+        int ar = row; ar = m0 + ar < g.M ? ar : g.M - 1 - m0;
+        a_voff[r] = (uint32_t)ar * (uint32_t)g.lda * (uint32_t)sizeof(T) + chunk;
     }
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, (short)0, 0x7fffffff, G4R_RSRC_WORD3);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, (short)0, 0x7fffffff, G4R_RSRC_WORD3);
     unsigned char* const my_rows = smem + wave * 64 * GEMM_ROW_BYTES;
+    unsigned char* const my_a_rows = smem + wave * (GEO::AREQ * 8) * GEMM_ROW_BYTES;
     auto dma_a = [&](int kt, int r) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(my_rows + (kt & 1) * G256_STAGE_BYTES + r * 8 * GEMM_ROW_BYTES), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(my_a_rows + (kt & 1) * G256_STAGE_BYTES + r * 8 * GEMM_ROW_BYTES), 16,
                                                  a_voff[r], kt * GEMM_ROW_BYTES, 0, 0);
     };
     auto dma_w = [&](int kt, int r) {
@@ -163,9 +194,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                  w_voff[r], kt * GEMM_ROW_BYTES, 0, 0);
     };
 
-    f32x4 acc[8][8];                 // 128x128 per wave as 8x8 tiles of 16x16
+    f32x4 acc[8][8];                // 128x128 (HALF: 64x128) per wave as GEO::MI x 8 tiles of 16x16
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < GEO::MI; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -180,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int c = ((kb * 4 + kq) ^ swz) << 4;
-            a_off[kb] = (wm * 128 + l15) * GEMM_ROW_BYTES + c;
+            a_off[kb] = (wm * GEO::WROWS + l15) * GEMM_ROW_BYTES + c;
             w_off[kb] = G256_OPERAND_BYTES + (wn * 128 + l15) * GEMM_ROW_BYTES + c;
         }
     }
@@ -203,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // row t*4 + lane/16 of pass p of this wave, columns (lane%16)*8 .. +7; rows / columns past the edge are clamped (their values are never stored)
     auto res16_request = [&](int p, int t) __attribute__((always_inline)) {
         if constexpr (LN16K) {
-            int grow = m0 + wm * 128 + p * 64 + t * 4 + (lane >> 4);
+            int grow = m0 + wm * GEO::WROWS + p * 64 + t * 4 + (lane >> 4);
             grow = grow < g.M ? grow : g.M - 1;
             int gc = n0 + wn * 128 + (lane & 15) * 8;
             gc = gc < g.N ? gc : 0;
@@ -214,13 +245,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int r = 0; r < 8; ++r) dma_w(0, r);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) dma_a(0, r);
+    for (int r = 0; r < GEO::AREQ; ++r) dma_a(0, r);
     if (nk > 1) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) dma_w(1, r);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) dma_a(1, r);
-        __builtin_amdgcn_s_waitcnt(g4d_wait_vm(16));
+        for (int r = 0; r < GEO::AREQ; ++r) dma_a(1, r);
+        __builtin_amdgcn_s_waitcnt(g4d_wait_vm(GEO::NREQ));
     } else {
         __builtin_amdgcn_s_waitcnt(g4d_wait_vm(0));
     }
@@ -229,7 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int j = 0; j < 8; ++j) read_w(0, 0, j);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) read_a(0, 0, i);
+    for (int i = 0; i < GEO::MI; ++i) read_a(0, 0, i);
 
     // more: step kt+1 exists (its block-0 fragments are read here); more2: step kt+2 exists (requested here);
     // WV: the wave this copy of the loop belongs to (its request slots).  One MFMA per scheduling region.
@@ -237,33 +268,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
         constexpr int WV = decltype(wave_c)::value;
         const int cur = kt & 1;
+        // Slots of the K step (p = the MFMA a piece of work is issued behind).  Full tile: the header's schedule.  HALF tile: 64
+        // MFMAs — block-1 fragments 0..22, barrier 26, the 12 requests of step t+2 at 27..50 (two waves per slot), vmcnt +
+        // barrier 52, block-0 fragments of step t+1 at 53..63.
+        constexpr int P_BAR1 = HALF ? 26 : 36, P_BAR2 = HALF ? 52 : 102;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < GEO::MI; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int p = kb * 64 + i * 8 + j;
+            const int p = kb * (GEO::MI * 8) + i * 8 + j;
             // (last step, streamlined epilogues: the barrier every wave passes after its last fragment read, so that
             //  staging the accumulators over the operand images needs no barrier behind the loop)
-            if (p == 36 && (more2 || (!more && EPI != G4D_EPI_GENERIC))) {         // this wave has every fragment of stage cur in registers
+            if (p == P_BAR1 && (more2 || (!more && EPI != G4D_EPI_GENERIC))) {         // this wave has every fragment of stage cur in registers
                 __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (p == 102 && more) {         // the 16 requests of this step may be in flight, those of the previous one not
-                __builtin_amdgcn_s_waitcnt(g4d_wait_vm(more2 ? 16 : 0));
+            if (p == P_BAR2 && more) {         // the requests of this step may be in flight, those of the previous one not
+                __builtin_amdgcn_s_waitcnt(g4d_wait_vm(more2 ? GEO::NREQ : 0));
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
             mfma16_agpr<T>(acc[i][j], fa[kb][i], fw[kb][j]);
             if (p < 16 && (p & 1) == 0) read_w(cur, 1, p >> 1);
-            if (p >= 16 && p <= 30 && (p & 1) == 0) read_a(cur, 1, (p - 16) >> 1);
-            if (more2 && p >= 38 && p < 70 && WV == ((p - 38) & 3)) dma_w(kt + 2, (p - 38) >> 2);
-            if (more2 && p >= 70 && p < 102 && WV == ((p - 70) & 3)) dma_a(kt + 2, (p - 70) >> 2);
-            if (more && p >= 103 && p <= 110) read_w(cur ^ 1, 0, p - 103);
-            if (more && p >= 111 && p <= 125 && (p & 1) == 1) read_a(cur ^ 1, 0, (p - 111) >> 1);
-            if constexpr (LN16K) { if (!more && p >= 40 && p < 104 && (p & 3) == 0 && res16_early) res16_request(0, (p - 40) >> 2); }
+            if constexpr (!HALF) {
+                if (p >= 16 && p <= 30 && (p & 1) == 0) read_a(cur, 1, (p - 16) >> 1);
+                if (more2 && p >= 38 && p < 70 && WV == ((p - 38) & 3)) dma_w(kt + 2, (p - 38) >> 2);
+                if (more2 && p >= 70 && p < 102 && WV == ((p - 70) & 3)) dma_a(kt + 2, (p - 70) >> 2);
+                if (more && p >= 103 && p <= 110) read_w(cur ^ 1, 0, p - 103);
+                if (more && p >= 111 && p <= 125 && (p & 1) == 1) read_a(cur ^ 1, 0, (p - 111) >> 1);
+                if constexpr (LN16K) { if (!more && p >= 40 && p < 104 && (p & 3) == 0 && res16_early) res16_request(0, (p - 40) >> 2); }
+            } else {
+                if (p >= 16 && p <= 22 && (p & 1) == 0) read_a(cur, 1, (p - 16) >> 1);
+                if (more2 && p >= 27 && p < 43 && (WV & 1) == ((p - 27) & 1)) dma_w(kt + 2, (p - 27) >> 1);
+                if (more2 && p >= 43 && p < 51 && (WV & 1) == ((p - 43) & 1)) dma_a(kt + 2, (p - 43) >> 1);
+                if (more && p >= 53 && p <= 60) read_w(cur ^ 1, 0, p - 53);
+                if (more && p >= 60 && p <= 63) read_a(cur ^ 1, 0, p - 60);
+                if constexpr (LN16K) { if (!more && p >= 24 && p < 56 && (p & 1) == 0 && res16_early) res16_request(0, (p - 24) >> 1); }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -343,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int idx = lane_e % LPR, rsub = lane_e / LPR;
         const int gcol = n0 + wn * 128 + idx * CPL;
         const bool col_ok = gcol < g.N;
-        const int grow0 = m0 + wm * 128 + rsub;    // the lane's row in instruction t of pass p: grow0 + p*64 + t*RPI
+        const int grow0 = m0 + wm * GEO::WROWS + rsub;    // the lane's row in instruction t of pass p: grow0 + p*64 + t*RPI
         float bias[CPL], sc[CPL], sh[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) { bias[c] = 0.f; sc[c] = 1.f; sh[c] = 0.f; }
@@ -377,8 +421,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    int srow = m0 + wm * 128 + p * 64 + lane_e; srow = srow < g.M ? srow : g.M - 1;
+                for (int p = 0; p < GEO::NPASS; ++p) {
+                    int srow = m0 + wm * GEO::WROWS + p * 64 + lane_e; srow = srow < g.M ? srow : g.M - 1;
                     if (e.res_index) srow = e.res_index[srow];
                     pst[p] = *(const float2*)(e.res_stats + 2 * (size_t)srow);
                 }
@@ -391,8 +435,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (RES) {
             if (res_ix) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    int srow = m0 + wm * 128 + p * 64 + lane_e; srow = srow < g.M ? srow : g.M - 1;
+                for (int p = 0; p < GEO::NPASS; ++p) {
+                    int srow = m0 + wm * GEO::WROWS + p * 64 + lane_e; srow = srow < g.M ? srow : g.M - 1;
                     rix[p] = e.res_index[srow];
                 }
             }
@@ -412,8 +456,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                int srow = m0 + wm * 128 + p * 64 + lane_e; srow = srow < g.M ? srow : g.M - 1;
+            for (int p = 0; p < GEO::NPASS; ++p) {
+                int srow = m0 + wm * GEO::WROWS + p * 64 + lane_e; srow = srow < g.M ? srow : g.M - 1;
                 fst[p] = *(const float2*)(e.fold_stats + 2 * (size_t)srow);
             }
         }
@@ -607,21 +651,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
                 // LN16: the first half of pass 0's residual registers is free once its first two groups are through — pass 1's rows move in
-                if constexpr (LN16) { if (p == 0 && t0 == GROUP) load_res16(1, 0, NIT / 2); }
+                if constexpr (LN16 && GEO::NPASS == 2) { if (p == 0 && t0 == GROUP) load_res16(1, 0, NIT / 2); }
             }
-            if constexpr (LN16) { if (p == 0) load_res16(1, NIT / 2, NIT); }      // (the second half of pass 1's residual rows)
+            if constexpr (LN16 && GEO::NPASS == 2) { if (p == 0) load_res16(1, NIT / 2, NIT); }      // (the second half of pass 1's residual rows)
             if constexpr (LNP) {
                 // the lane holds row ((4 * (idx & 7) + 2 * b4 + b3) * 2 + rsub) of the pass: 64 lanes, 64 rows, one 512-byte store
                 // (LN16: row ((4 * (idx & 3) + 2 * b3 + b2) * 4 + rsub))
                 const int rp = LN16 ? (((4 * (idx & 3) + 2 * ((idx >> 3) & 1) + ((idx >> 2) & 1)) << 2) + rsub)
                                     : (((4 * (idx & 7) + 2 * ((idx >> 4) & 1) + ((idx >> 3) & 1)) << 1) + rsub);
-                const int grow = m0 + wm * 128 + p * 64 + rp;
+                const int grow = m0 + wm * GEO::WROWS + p * 64 + rp;
                 if (grow < g.M && n0 + wn * 128 < g.N)
                     e.stats_part[(size_t)((n0 + wn * 128) >> 7) * e.ld_part + grow] = make_float2(acc_s, acc_q);
             }
         };
         auto drain_pass = [&](int p) {
-            const bool full = m0 + wm * 128 + p * 64 + 64 <= g.M && n0 + wn * 128 + 128 <= g.N;
+            const bool full = m0 + wm * GEO::WROWS + p * 64 + 64 <= g.M && n0 + wn * 128 + 128 <= g.N;
             if (full) drain(p, std::integral_constant<bool, true>{});
             else drain(p, std::integral_constant<bool, false>{});
         };
@@ -629,12 +673,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else load_res(0);
         stage(0);
         __builtin_amdgcn_sched_barrier(0);         // (pass 1's residual registers only exist once pass 0's accumulators are staged)
-        if constexpr (!LNP) load_res(1);
+        if constexpr (!LNP && GEO::NPASS == 2) load_res(1);
         __builtin_amdgcn_sched_barrier(0);
         drain_pass(0);
-        if constexpr (LNP && !LN16) { __builtin_amdgcn_sched_barrier(0); load_res(1); __builtin_amdgcn_sched_barrier(0); }
-        stage(1);
-        drain_pass(1);
+        if constexpr (GEO::NPASS == 2) {          // (the HALF tile is one pass of 64 rows per wave)
+            if constexpr (LNP && !LN16) { __builtin_amdgcn_sched_barrier(0); load_res(1); __builtin_amdgcn_sched_barrier(0); }
+            stage(1);
+            drain_pass(1);
+        }
         range_report(e.range_flag, bad, W16 ? ZETT_RANGE_BIT_ACTIVATION : ZETT_RANGE_BIT_OUTPUT);
     }
 }
@@ -675,52 +721,104 @@ inline int gemm4d_epi_mode(const GemmArgs<T>& g) {
     return G4D_EPI_GENERIC;
 }
 
-template <typename T, int ACT, bool RES, int EPI>
+template <typename T, int ACT, bool RES, int EPI, bool HALF = false>
 inline hipError_t launch_gemm4d_inst(const GemmArgs<T>& g, hipStream_t stream) {
     constexpr int lds = EPI == G4D_EPI_GENERIC ? G256_LDS_BYTES : G4D_LDS_BYTES;
     static DeviceFlags attr;
     bool* done = attr.current();
     if (!done || !*done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm4d_tn_kernel<T, ACT, RES, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm4d_tn_kernel<T, ACT, RES, EPI, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         if (done) *done = true;
     }
-    const int tiles_m = (g.M + G256_BM - 1) / G256_BM;
+    constexpr int BM = HALF ? 128 : G256_BM;
+    const int tiles_m = (g.M - g.row0 + BM - 1) / BM;
     const int tiles_n = (g.N + G256_BN - 1) / G256_BN;
     if (tiles_m <= 0 || tiles_n <= 0) return hipSuccess;
-    hipLaunchKernelGGL((gemm4d_tn_kernel<T, ACT, RES, EPI>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL((gemm4d_tn_kernel<T, ACT, RES, EPI, HALF>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, g);
     return hipGetLastError();
 }
 
-template <typename T, int ACT>
+// The instantiation a launch gets; HALF: the 128x256 tile on rows [g.row0, g.M) (streamlined epilogues only: a launch whose
+// epilogue is the generic drain is never split).
+template <typename T, int ACT, bool HALF>
 inline hipError_t launch_gemm4d_act(const GemmArgs<T>& g, hipStream_t stream, int mode) {
     const bool res = g.epi.residual != nullptr;
     switch (mode) {
-        case G4D_EPI_LO: return launch_gemm4d_inst<T, ACT, false, G4D_EPI_LO>(g, stream);
-        case G4D_EPI_LO_FOLD: return launch_gemm4d_inst<T, ACT, false, G4D_EPI_LO_FOLD>(g, stream);
+        case G4D_EPI_LO: return launch_gemm4d_inst<T, ACT, false, G4D_EPI_LO, HALF>(g, stream);
+        case G4D_EPI_LO_FOLD: return launch_gemm4d_inst<T, ACT, false, G4D_EPI_LO_FOLD, HALF>(g, stream);
         case G4D_EPI_F32:
-            if constexpr (ACT == ACT_NONE) return res ? launch_gemm4d_inst<T, ACT, true, G4D_EPI_F32>(g, stream) : launch_gemm4d_inst<T, ACT, false, G4D_EPI_F32>(g, stream);
-            else if constexpr (ACT == ACT_GELU_TANH) { if (res) return launch_gemm4d_inst<T, ACT, true, G4D_EPI_F32>(g, stream); }
+            if constexpr (ACT == ACT_NONE) return res ? launch_gemm4d_inst<T, ACT, true, G4D_EPI_F32, HALF>(g, stream) : launch_gemm4d_inst<T, ACT, false, G4D_EPI_F32, HALF>(g, stream);
+            else if constexpr (ACT == ACT_GELU_TANH) { if (res) return launch_gemm4d_inst<T, ACT, true, G4D_EPI_F32, HALF>(g, stream); }
             [[fallthrough]];
-        default: return res ? launch_gemm4d_inst<T, ACT, true, G4D_EPI_GENERIC>(g, stream) : launch_gemm4d_inst<T, ACT, false, G4D_EPI_GENERIC>(g, stream);
+        default:
+            if constexpr (HALF) return hipErrorInvalidValue;
+            else return res ? launch_gemm4d_inst<T, ACT, true, G4D_EPI_GENERIC>(g, stream) : launch_gemm4d_inst<T, ACT, false, G4D_EPI_GENERIC>(g, stream);
     }
 }
+
+template <typename T, bool HALF>
+inline hipError_t launch_gemm4d_mode(const GemmArgs<T>& g, hipStream_t stream, int mode) {
+    if (mode == G4D_EPI_F32_LN) return launch_gemm4d_inst<T, ACT_NONE, true, G4D_EPI_F32_LN, HALF>(g, stream);
+    if (mode == G4D_EPI_LN16) return launch_gemm4d_inst<T, ACT_NONE, true, G4D_EPI_LN16, HALF>(g, stream);
+    if (mode == G4D_EPI_LO_LN) return launch_gemm4d_inst<T, ACT_GELU_TANH, true, G4D_EPI_LO_LN, HALF>(g, stream);
+    if (mode == G4D_EPI_F32_SCALE_FOLD) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE_FOLD, HALF>(g, stream);
+    if (mode == G4D_EPI_F32_SCALE) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE, HALF>(g, stream);
+    if (mode == G4D_EPI_BOTH) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_BOTH, HALF>(g, stream);
+    switch (g.epi.act) {
+        case ACT_GELU_TANH: return launch_gemm4d_act<T, ACT_GELU_TANH, HALF>(g, stream, mode);
+        case ACT_GELU_ERF: return launch_gemm4d_act<T, ACT_GELU_ERF, HALF>(g, stream, mode);
+        default: return launch_gemm4d_act<T, ACT_NONE, HALF>(g, stream, mode);
+    }
+}
+
+// true when `mode` (gemm4d_epi_mode) has a HALF instantiation for this launch
+template <typename T>
+inline bool gemm4d_half_ok(const GemmArgs<T>& g, int mode) {
+    if (mode <= G4D_EPI_GENERIC) return false;
+    if (mode == G4D_EPI_F32) return g.epi.act == ACT_NONE || (g.epi.act == ACT_GELU_TANH && g.epi.residual);
+    return true;
+}
+
+// Rows [0, row0) of a launch go to 256x256 tiles, rows [row0, M) to 128x256 tiles (see the kernel's header): row0 = M (no
+// split) unless the full tiles leave a partly filled last round of `cus` workgroups that the half tiles fill more cheaply.  A
+// half tile is priced at 0.64 of a full one (half the MFMAs at ~0.78 of the rate).
+inline int gemm4d_row_split(int M, int N, int cus = 256, double half_cost = 0.64) {
+    const long tn = (N + G256_BN - 1) / G256_BN, tm = (M + G256_BM - 1) / G256_BM;
+    const long T = tm * tn;
+    if (T % cus == 0) return M;
+    const long rounds = (T + cus - 1) / cus;
+    // full tiles for as many row tiles as fit into R = rounds - 1 whole rounds
+    const long tm_full = std::min<long>(tm, ((rounds - 1) * cus) / tn);
+    const long row0 = tm_full * G256_BM;
+    if (row0 >= M) return M;
+    const long th = ((M - row0 + 127) / 128) * tn;
+    const double cost = (double)((tm_full * tn + cus - 1) / cus) + half_cost * (double)((th + cus - 1) / cus);
+    return cost < (double)rounds - 0.05 ? (int)row0 : M;
+}
+
+hipError_t launch_gemm_4d_half(const GemmArgs<f16_t>& g, hipStream_t stream, int mode);
+hipError_t launch_gemm_4d_half(const GemmArgs<bf16_t>& g, hipStream_t stream, int mode);
 
 template <typename T>
 inline hipError_t launch_gemm4d(const GemmArgs<T>& g, hipStream_t stream, bool force_generic = false) {
     const int mode = (force_generic && !g.epi.stats_part && !g.epi.fold_stats) ? G4D_EPI_GENERIC : gemm4d_epi_mode(g);
     if (mode < 0) return hipErrorInvalidValue;       // a LayerNorm-fold launch whose outputs no instantiation carries
-    if (mode == G4D_EPI_F32_LN) return launch_gemm4d_inst<T, ACT_NONE, true, G4D_EPI_F32_LN>(g, stream);
-    if (mode == G4D_EPI_LN16) return launch_gemm4d_inst<T, ACT_NONE, true, G4D_EPI_LN16>(g, stream);
-    if (mode == G4D_EPI_LO_LN) return launch_gemm4d_inst<T, ACT_GELU_TANH, true, G4D_EPI_LO_LN>(g, stream);
-    if (mode == G4D_EPI_F32_SCALE_FOLD) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE_FOLD>(g, stream);
-    if (mode == G4D_EPI_F32_SCALE) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_F32_SCALE>(g, stream);
-    if (mode == G4D_EPI_BOTH) return launch_gemm4d_inst<T, ACT_NONE, false, G4D_EPI_BOTH>(g, stream);
-    switch (g.epi.act) {
-        case ACT_GELU_TANH: return launch_gemm4d_act<T, ACT_GELU_TANH>(g, stream, mode);
-        case ACT_GELU_ERF: return launch_gemm4d_act<T, ACT_GELU_ERF>(g, stream, mode);
-        default: return launch_gemm4d_act<T, ACT_NONE>(g, stream, mode);
+    // g.row0 on entry: -1 = let the launcher cut the launch (gemm4d_row_split), 0 = full tiles only, > 0 = the caller's cut (a multiple
+    // of 256), -2 = half tiles only (tests and A/Bs)
+    int split = g.row0 == -1 ? gemm4d_row_split(g.M, g.N) : (g.row0 == -2 ? 0 : (g.row0 > 0 ? std::min(g.row0, g.M) : g.M));
+    if (split < g.M && (!gemm4d_half_ok(g, mode) || split % G256_BM != 0)) split = g.M;
+    GemmArgs<T> full = g;
+    full.row0 = 0;
+    if (split < g.M) {
+        full.M = split;
+        if (split > 0)
+            if (hipError_t e = launch_gemm4d_mode<T, false>(full, stream, mode); e != hipSuccess) return e;
+        GemmArgs<T> rest = g;
+        rest.row0 = split;
+        return launch_gemm_4d_half(rest, stream, mode);          // (the HALF instantiations live in their own translation units: gemm4dh_<type>.hip)
     }
+    return launch_gemm4d_mode<T, false>(full, stream, mode);
 }
 
 }  // namespace zett

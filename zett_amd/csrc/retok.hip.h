@@ -140,14 +140,23 @@ __device__ inline int block_excl_scan_256(int v, int* total, int* lds /* [4] */)
 }
 
 // MODE 0: count character starts per block.  MODE 1: decode + compact.
-template <int MODE>
+// SEP (r5): the text holds the tokens NUL-SEPARATED instead of coming with an offsets array (zett_retokenize_async with
+// offsets == nullptr: what one "\0".join(tokens).encode() on the host produces — no per-token work there at all).  A NUL is
+// then not a character: it emits no byte, and the k-th one marks the start of token k + 1 — the same block scan that numbers the
+// characters numbers the separators, and raw_off[] (first raw byte of every token, what stage 2 consumes) is written HERE
+// instead of by token_raw_offsets_kernel.  blk_count then holds two arrays of n_blocks + 1 ints ... see the launcher.  A bad
+// character is reported with its TOKEN index (the separators before it) instead of its text position.
+template <int MODE, bool SEP>
 __global__ __launch_bounds__(256) void chars_to_bytes_kernel(const uint8_t* __restrict__ text, int64_t n_text,
                                                              const int16_t* __restrict__ cp_to_byte,
                                                              int32_t* __restrict__ blk_count,      // MODE 0 out / MODE 1 in (scanned)
                                                              uint8_t* __restrict__ raw, uint32_t* __restrict__ raw_pos,
-                                                             unsigned long long* __restrict__ err_pos, uint32_t call) {
+                                                             unsigned long long* __restrict__ err_pos, uint32_t call,
+                                                             int32_t* __restrict__ sep_count = nullptr,   // SEP: MODE 0 out / MODE 1 in (scanned)
+                                                             int32_t* __restrict__ raw_off = nullptr, int64_t n_tokens = 0) {
     __shared__ int16_t s_tab[324];
     __shared__ int s_red[4];
+    __shared__ int s_red2[4];
     __shared__ uint8_t s_next[256];        // first byte of the following thread's span
     if (MODE == 1)
         for (int i = threadIdx.x; i < 324; i += 256) s_tab[i] = cp_to_byte[i];
@@ -166,29 +175,52 @@ __global__ __launch_bounds__(256) void chars_to_bytes_kernel(const uint8_t* __re
         if (threadIdx.x < 255) b[CH_PER_THREAD] = s_next[threadIdx.x + 1];
         else b[CH_PER_THREAD] = (base + CH_PER_THREAD < n_text) ? text[base + CH_PER_THREAD] : 0;
     }
-    int cnt = 0;
+    int cnt = 0, nsep = 0;
 #pragma unroll
-    for (int i = 0; i < CH_PER_THREAD; ++i) cnt += (base + i < n_text) && ((b[i] & 0xC0) != 0x80);
-    int total = 0;
+    for (int i = 0; i < CH_PER_THREAD; ++i) {
+        const bool in = base + i < n_text;
+        cnt += in && ((b[i] & 0xC0) != 0x80) && !(SEP && b[i] == 0);
+        if (SEP) nsep += in && b[i] == 0;
+    }
+    int total = 0, total_sep = 0;
     const int excl = block_excl_scan_256(cnt, &total, s_red);
+    int tok = 0;
+    if (SEP) tok = block_excl_scan_256(nsep, &total_sep, s_red2);
     if (MODE == 0) {
-        if (threadIdx.x == 0) blk_count[blockIdx.x] = total;
+        if (threadIdx.x == 0) { blk_count[blockIdx.x] = total; if (SEP) sep_count[blockIdx.x] = total_sep; }
         return;
     }
     uint32_t pos = (uint32_t)blk_count[blockIdx.x] + (uint32_t)excl;
+    bool sep_ok = true;
+    if (SEP) {
+        tok += sep_count[blockIdx.x];                              // separators before this thread's span = index of the token it starts in
+        // n_tokens tokens are n_tokens - 1 separators: a text that holds another number is refused (raw_off stays all zero — the
+        // launcher cleared it — so stage 2 sees empty tokens, and the result query reports ZETT_E_INVALID)
+        sep_ok = sep_count[gridDim.x] == (int32_t)(n_tokens - 1);
+        if (!sep_ok && base == 0) atomicMin(err_pos, ((unsigned long long)call << 32) | 0xfffffffeull);
+    }
 #pragma unroll
     for (int i = 0; i < CH_PER_THREAD; ++i) {
         if (base + i >= n_text) break;
-        raw_pos[base + i] = pos;                                   // characters before text[base+i]
+        if (!SEP) raw_pos[base + i] = pos;                         // characters before text[base+i]
         const uint8_t c = b[i];
+        if (SEP) {
+            if (c == 0) {                                              // token `tok` starts behind this separator
+                ++tok;
+                if (sep_ok) { raw_off[tok] = (int32_t)pos; if (base + i == n_text - 1) raw_off[n_tokens] = (int32_t)pos; }      // (a last, empty token)
+                continue;
+            }
+            if (sep_ok && base + i == n_text - 1 && (c & 0xC0) == 0x80) raw_off[n_tokens] = (int32_t)pos;      // (text ends in a continuation byte)
+        }
         if ((c & 0xC0) == 0x80) continue;                          // continuation byte
         int cp = -1;
         if (c < 0x80) cp = c;
         else if (c >= 0xC2 && c <= 0xDF && (b[i + 1] & 0xC0) == 0x80 && base + i + 1 < n_text) cp = ((c & 0x1F) << 6) | (b[i + 1] & 0x3F);
         const int byte = (cp >= 0 && cp < 324) ? s_tab[cp] : -1;
-        if (byte < 0) atomicMin(err_pos, ((unsigned long long)call << 32) | (uint32_t)(base + i < 0x7fffffff ? base + i : 0x7ffffffe));      // earliest call, then earliest position
+        if (byte < 0) atomicMin(err_pos, ((unsigned long long)call << 32) | (SEP ? (uint32_t)tok : (uint32_t)(base + i < 0x7fffffff ? base + i : 0x7ffffffe)));      // earliest call, then earliest position (SEP: token)
         raw[pos] = (uint8_t)(byte < 0 ? 0 : byte);
         ++pos;
+        if (SEP && sep_ok && base + i == n_text - 1) raw_off[n_tokens] = (int32_t)pos;      // end of the last token
     }
 }
 
@@ -697,8 +729,10 @@ int zett_retokenize_async(zett_retok* r, const uint8_t* token_chars, const int32
     if (!r) return fail(ZETT_E_INVALID, "null argument");
     if (n_tokens < 0 || maxlen < 1 || n_text < 0 || n_text >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "bad shape");
     if (n_tokens == 0) return 0;
-    if (!offsets || !out) return fail(ZETT_E_INVALID, "null argument");
+    if (!out) return fail(ZETT_E_INVALID, "null argument");
     if (n_text > 0 && !token_chars) return fail(ZETT_E_INVALID, "token_chars is null");
+    const bool sep = offsets == nullptr;      // NUL-separated text: the token boundaries are found on the device
+    if (sep && n_text < n_tokens - 1) return fail(ZETT_E_INVALID, "NUL-separated text of %lld tokens needs at least %lld bytes", (long long)n_tokens, (long long)(n_tokens - 1));
     ZETT_ON_DEVICE(r->device);
     hipStream_t st = (hipStream_t)stream;
     if (!r->words_ready) { if (int rc = retok_reset_words(r, st)) return rc; }
@@ -707,10 +741,12 @@ int zett_retokenize_async(zett_retok* r, const uint8_t* token_chars, const int32
     if (int rc = r->raw.reserve((size_t)n_text + 16)) return rc;
     if (int rc = r->raw_pos.reserve(((size_t)n_text + 1) * 4)) return rc;
     if (int rc = r->raw_off.reserve(((size_t)n_tokens + 1) * 4)) return rc;
-    if (int rc = r->blk.reserve(((size_t)n_blocks + 2) * 2 * 4)) return rc;
+    if (int rc = r->blk.reserve(((size_t)n_blocks + 2) * 4 * 4)) return rc;
     if (int rc = r->scratch.reserve(((size_t)n_text * SCR_PER_BYTE + (size_t)n_tokens * SCR_FIXED + 64) * 4)) return rc;
     int32_t* blk_count = r->blk.as<int32_t>();
     int32_t* blk_scan = blk_count + n_blocks + 1;
+    int32_t* sep_count = blk_scan + n_blocks + 2;          // (separator mode: the same pair for the NUL counts)
+    int32_t* sep_scan = sep_count + n_blocks + 1;
     unsigned long long* words = r->misc.as<unsigned long long>();
     const uint32_t call = r->calls++;
     r->recent.push_back({offsets, n_tokens});          // (the caller keeps `offsets` alive until zett_retok_result: include/zett_hip.h)
@@ -718,17 +754,26 @@ int zett_retokenize_async(zett_retok* r, const uint8_t* token_chars, const int32
     // and the words (which kernels of this call may already have touched) start afresh with the next call
     auto enqueue = [&]() -> int {
         hipLaunchKernelGGL(fill_i32_kernel, dim3(1024), dim3(256), 0, st, out, n_tokens * (int64_t)maxlen, pad_id);   // :662-666
-        if (n_blocks > 0) {
-            hipLaunchKernelGGL((chars_to_bytes_kernel<0>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
+        if (sep) HIP_TRY(hipMemsetAsync(r->raw_off.p, 0, ((size_t)n_tokens + 1) * 4, st));
+        if (n_blocks > 0 && sep) {
+            hipLaunchKernelGGL((chars_to_bytes_kernel<0, true>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
+                               blk_count, (uint8_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, call, sep_count, (int32_t*)nullptr, n_tokens);
+            hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, blk_count, blk_scan, (int64_t)n_blocks);
+            hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, sep_count, sep_scan, (int64_t)n_blocks);
+            hipLaunchKernelGGL((chars_to_bytes_kernel<1, true>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
+                               blk_scan, r->raw.as<uint8_t>(), (uint32_t*)nullptr, words, call, sep_scan, r->raw_off.as<int32_t>(), n_tokens);
+        } else if (n_blocks > 0) {
+            hipLaunchKernelGGL((chars_to_bytes_kernel<0, false>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
                                blk_count, (uint8_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, call);
             hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, blk_count, blk_scan, (int64_t)n_blocks);
-            hipLaunchKernelGGL((chars_to_bytes_kernel<1>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
+            hipLaunchKernelGGL((chars_to_bytes_kernel<1, false>), dim3(n_blocks), dim3(256), 0, st, token_chars, n_text, r->t.cp_to_byte,
                                blk_scan, r->raw.as<uint8_t>(), r->raw_pos.as<uint32_t>(), words, call);
         } else {
             HIP_TRY(hipMemsetAsync(blk_scan, 0, 8, st));
         }
-        hipLaunchKernelGGL(token_raw_offsets_kernel, dim3((unsigned)((n_tokens + 1 + 255) / 256)), dim3(256), 0, st, offsets, n_tokens,
-                           n_text, r->raw_pos.as<uint32_t>(), blk_scan, n_blocks, r->raw_off.as<int32_t>());
+        if (!sep)
+            hipLaunchKernelGGL(token_raw_offsets_kernel, dim3((unsigned)((n_tokens + 1 + 255) / 256)), dim3(256), 0, st, offsets, n_tokens,
+                               n_text, r->raw_pos.as<uint32_t>(), blk_scan, n_blocks, r->raw_off.as<int32_t>());
         hipLaunchKernelGGL(retok_tokens_kernel, dim3((unsigned)((n_tokens + 63) / 64)), dim3(64), 0, st, r->t, r->raw.as<uint8_t>(),
                            r->raw_off.as<int32_t>(), n_tokens, maxlen, pad_id, out, r->scratch.as<int32_t>(), words + 2, words + 1, call);
         HIP_TRY(hipGetLastError());
@@ -765,7 +810,13 @@ int zett_retok_result(zett_retok* r, int64_t* n_truncated, int64_t* bad_call, in
         const uint32_t call = (uint32_t)(w[0] >> 32);
         const int32_t pos = (int32_t)(w[0] & 0xffffffffu);
         int64_t lo = -1;
-        if (call < recent.size()) {
+        if (call < recent.size() && recent[call].offsets == nullptr && (w[0] & 0xffffffffu) == 0xfffffffeu) {
+            if (bad_call) *bad_call = call;
+            return fail(ZETT_E_INVALID, "call %u: the NUL-separated text does not hold n_tokens - 1 separators", call);
+        }
+        if (call < recent.size() && recent[call].offsets == nullptr) {
+            lo = pos;                                          // NUL-separated text: the kernel reported the token index itself
+        } else if (call < recent.size()) {
             const auto& cl = recent[call];
             std::vector<int32_t> ho((size_t)cl.n_tokens + 1);
             HIP_TRY(hipMemcpy(ho.data(), cl.offsets, ((size_t)cl.n_tokens + 1) * 4, hipMemcpyDeviceToHost));
@@ -775,7 +826,8 @@ int zett_retok_result(zett_retok* r, int64_t* n_truncated, int64_t* bad_call, in
         }
         if (bad_call) *bad_call = call;
         if (bad_token) *bad_token = lo;
-        return fail(ZETT_E_KEY, "token %lld holds a character outside the byte-level table (text offset %d)", (long long)lo, pos);
+        return fail(ZETT_E_KEY, "token %lld holds a character outside the byte-level table (%s %d)", (long long)lo,
+                    (call < recent.size() && recent[call].offsets == nullptr) ? "token" : "text offset", pos);
     }
     if (w[1] != ~0ull) {
         const int64_t tok = (int64_t)(w[1] & 0xffffffffu);
