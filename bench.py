@@ -207,15 +207,20 @@ def class_table(classes, steps, peak):
     return out
 
 
-def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0):
+def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0, partition="contiguous"):
     """One more workload of BASELINE.json on this GPU, measured AFTER the timed region of the main line and reported under
     `configs` (never `value`): the same step — surface forms resident in HBM -> GPU retokenization -> hypernet forward — with
     per-launch HIP events, `steps` steps.  shard_of = P > 0: the rows are what rank 0 of P ranks computes of the workload's
-    vocabulary (zett_amd.sharding.plan_blocks: the single-GPU proxy of the P-GPU step, exchange excluded)."""
+    vocabulary (zett_amd.sharding.plan_blocks: the single-GPU proxy of the P-GPU step, exchange excluded).  partition =
+    "affinity": the rank's rows are chosen by zett_amd.sharding.affinity_order instead of being a contiguous range — then every
+    step retokenizes the WHOLE vocabulary (each rank needs every row's ids to compute the same order), runs the partition kernel,
+    gathers its rows and runs the forward; the indexed copy that puts the gathered matrices back into vocabulary order is timed
+    on full-size buffers and reported beside it (`unpermute_ms`: local HBM traffic, the same on 8 GPUs)."""
     from zett_amd.hypernet import HipEngine
-    from zett_amd.sharding import plan_blocks
+    from zett_amd.sharding import affinity_order, plan_blocks
     from zett_amd.surface_forms import DeviceRetokenizer, HnTokenizerSpec
 
+    affinity = bool(shard_of) and partition == "affinity"
     cfg, default_rows, src_dtype, hist = synth.workload(workload)
     vocab_rows = rows or default_rows
     dims = HypernetDims.from_config(cfg)
@@ -227,10 +232,11 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
     ids_all = synth.make_surface_forms(cfg, vocab_rows, seed=0, hist=hist)
     if shard_of:
         blocks = plan_blocks(vocab_rows, shard_of, 0, 1)
-        ids_np = np.concatenate([ids_all[b.lo:b.hi] for b in blocks])
+        ids_np = ids_all if affinity else np.concatenate([ids_all[b.lo:b.hi] for b in blocks])
     else:
         ids_np = ids_all
-    n = int(ids_np.shape[0])
+    n = int(sum(b.hi - b.lo for b in blocks)) if shard_of else int(ids_np.shape[0])
+    n_ids = dims.original_vocab_size + dims.n_extra
     seq_len = int(ids_np.shape[1])
     hn_model, piece_of_id = synth.make_hn_model(workload, cfg)
     spec = HnTokenizerSpec.from_model_json(hn_model, ["<unk>", "<s>", "</s>"], [0, 1, 2], dims.pad_token_id)
@@ -246,7 +252,11 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
     classes, acc = {}, {"gemm_ms": 0.0, "gemm_flops_timed": 0.0, "gemm_launches": 0}
 
     def one():
-        out = engine.forward(retok.run_async(d_text, d_off, n_tok, seq_len), src, lang)
+        sfm = retok.run_async(d_text, d_off, n_tok, seq_len)
+        if affinity:          # the whole vocabulary's ids -> the order every rank computes -> this rank's rows
+            order = affinity_order(sfm, shard_of, dims.pad_token_id, n_ids, chunks=1)
+            sfm = sfm.index_select(0, torch.cat([order[b.lo:b.hi] for b in blocks]))
+        out = engine.forward(sfm, src, lang)
         st_k = engine.stats()
         for key in acc:
             acc[key] += st_k[key]
@@ -273,7 +283,23 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
     tf = acc["gemm_flops_timed"] / (acc["gemm_ms"] * 1e-3) / 1e12 if acc["gemm_ms"] > 0 else 0.0
     by = sum(v[3] for v in classes.values())
     tbs = by / (acc["gemm_ms"] * 1e-3) / 1e12 if acc["gemm_ms"] > 0 else 0.0
-    res = {"workload": workload + (f" (rank 0 of {shard_of}: {n} of {vocab_rows} rows)" if shard_of else ""), "rows": n, "dtype": precision,
+    unpermute_ms = None
+    if affinity:
+        # what follows the exchange: one indexed copy per output over the WHOLE vocabulary (local HBM traffic)
+        order = affinity_order(retok.run_async(d_text, d_off, n_tok, seq_len), shard_of, dims.pad_token_id, n_ids, chunks=1)
+        bufs = [torch.empty((vocab_rows, dims.n_embd), device=device) for _ in range(2 if dims.separate_out else 1)] + [torch.empty((vocab_rows,), device=device)]
+        for _ in range(2):
+            outs = [torch.empty_like(t).index_copy_(0, order, t) for t in bufs]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            outs = [torch.empty_like(t).index_copy_(0, order, t) for t in bufs]
+        torch.cuda.synchronize()
+        unpermute_ms = (time.perf_counter() - t1) / 5 * 1e3
+        retok.result()
+        del bufs, outs
+    res = {"workload": workload + (f" (rank 0 of {shard_of}: {n} of {vocab_rows} rows, {partition} shards)" if shard_of else ""), "rows": n, "dtype": precision,
+           "partition": partition if shard_of else None, "unpermute_ms": unpermute_ms,
            "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "value": n * steps / dt, "unit": "token-embeddings/s",
            "packed_tokens": st["packed_tokens"], "distinct_source_ids": st["distinct_ids"], "distinct_id_position_pairs": st["distinct_positions"],
            "range_flags": flags,
@@ -386,6 +412,10 @@ def main():
                     "(RowGather: all_gather_into_tensor on RCCL's stream, side-stream early start) exactly as N > 1 does — the nccl code path on a 1-GPU box")
     ap.add_argument("--gather-mode", default="auto", choices=["auto", "allgather", "fanout"],
                     help="N > 1: transport of the row exchange (zett_amd/sharding.py RowGather): RCCL all-gather, or direct fan-out (every rank sends its shard to all peers at once, one xGMI link each)")
+    ap.add_argument("--partition", default="contiguous", choices=["contiguous", "affinity"],
+                    help="N > 1: which rows a rank computes — contiguous ranges of the vocabulary, or the id-affinity order of zett_amd.sharding.affinity_order "
+                         "(zett_partition_rows: rows that share source ids share a rank; every step then retokenizes the whole vocabulary on every rank, runs the "
+                         "partition kernel, and ends with the indexed copy that puts the gathered matrices back into vocabulary order)")
     ap.add_argument("--no-early-gather", action="store_true", help="N > 1, A/B: start the exchange of pred_in / bias behind the whole forward instead of behind their own completion point")
     args = ap.parse_args()
 
@@ -490,16 +520,20 @@ def main():
     # (checked below, untimed).
     retok = None
     texts = []
+    affinity = exchange and args.partition == "affinity"
+    if affinity and args.no_retokenize:
+        raise SystemExit("--partition affinity orders the rows by the retokenized ids: it cannot be combined with --no-retokenize")
     seq_len = int(ids_all.shape[1])
     if not args.no_retokenize:
         from zett_amd.surface_forms import DeviceRetokenizer, HnTokenizerSpec
         hn_model, piece_of_id = synth.make_hn_model(args.workload, cfg)
         spec = HnTokenizerSpec.from_model_json(hn_model, ["<unk>", "<s>", "</s>"], [0, 1, 2], dims.pad_token_id)
         retok = DeviceRetokenizer(spec, device)
-        for b, ids_b in zip(blocks, ids_blocks):
-            d_text, d_off, n_tok = retok.encode(synth.tokens_for_surface_forms(cfg, ids_all[b.lo:b.hi], piece_of_id))
+        # (affinity order: every rank retokenizes the WHOLE vocabulary — it needs every row's ids to compute the same order)
+        for lo, hi in ([(0, rows)] if affinity else [(b.lo, b.hi) for b in blocks]):
+            d_text, d_off, n_tok = retok.encode(synth.tokens_for_surface_forms(cfg, ids_all[lo:hi], piece_of_id))
             sfm0, n_trunc0 = retok.run(d_text, d_off, n_tok, seq_len)
-            if n_trunc0 != 0 or not torch.equal(sfm0, ids_b):
+            if n_trunc0 != 0 or not torch.equal(sfm0.cpu(), torch.from_numpy(ids_all[lo:hi])):
                 raise SystemExit("the retokenized surface forms differ from the workload's id matrix")
             texts.append((d_text, d_off, n_tok))
     src = torch.from_numpy(synth.make_source_embeddings(cfg, seed=0, dtype=src_dtype)).to(device)
@@ -515,7 +549,15 @@ def main():
         outs = None
         # the step's id matrices: every block retokenized at the head of the step, without a host round trip
         # (zett_retokenize_async; the truncation count of all steps is asked for once, after the timed region)
-        sfms = ids_blocks if retok is None else [retok.run_async(*texts[k], seq_len) for k in range(len(blocks))]
+        order = None
+        if affinity:
+            from zett_amd.sharding import affinity_order
+            sfm_all = retok.run_async(*texts[0], seq_len)
+            order = affinity_order(sfm_all, world, dims.pad_token_id, dims.original_vocab_size + dims.n_extra, chunks=chunks)
+            step.order = order
+            sfms = [sfm_all.index_select(0, order[b.lo:b.hi]) for b in blocks]
+        else:
+            sfms = ids_blocks if retok is None else [retok.run_async(*texts[k], seq_len) for k in range(len(blocks))]
         if len(blocks) > 1:
             ahead.wait_stream(torch.cuda.current_stream(device))      # behind this step's retokenization
         for k, b in enumerate(blocks):
@@ -535,6 +577,8 @@ def main():
             return outs
         full = gather.finish(rows, timed=True)
         exposed.append(gather.exposed_ms)
+        if order is not None:          # back into vocabulary order: one indexed copy per output
+            full = tuple(None if t is None else torch.empty_like(t).index_copy_(0, order, t) for t in full)
         return full
 
     gemm_ms = gemm_fl = 0.0
@@ -569,10 +613,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # untimed: the gathered matrix must hold this rank's rows bit for bit (rows are shard-independent)
+        ids_dev = torch.from_numpy(ids_all).to(device) if affinity else None
         for b, ids_b in zip(blocks, ids_blocks):
-            chk = engine.forward(ids_b, src, lang_arg)          # `ids_b` == the retokenized matrix (checked above)
+            mine = step.order[b.lo:b.hi] if affinity else None
+            chk = engine.forward(ids_dev.index_select(0, mine) if affinity else ids_b, src, lang_arg)          # `ids_b` == the retokenized matrix (checked above)
             for full, loc in zip(out, chk):
-                if full is not None and not torch.equal(full[b.lo:b.hi], loc):
+                if full is not None and not torch.equal(full.index_select(0, mine) if affinity else full[b.lo:b.hi], loc):
                     raise SystemExit(f"rank {rank}: all-gathered rows [{b.lo}, {b.hi}) differ from the local forward")
     st = engine.stats()
 
@@ -613,6 +659,7 @@ def main():
                                f"H={dims.hidden} I={dims.intermediate} heads={dims.heads} layers={dims.layers} "
                                f"L={ids_all.shape[1]}, source_embeddings {src_dtype}",
                    "rows": rows, "rows_per_gpu": sum(b.hi - b.lo for b in blocks),
+                   "partition": args.partition if exchange else None,
                    "parallelism": f"vocab-row shards x{world} + RCCL all-gather" + ("" if world == 1 else (" (after the forward)" if chunks == 1 else f" ({len(blocks)} row blocks per step: the all-gather of a block runs on the RCCL stream under the next block's forward; nothing overlaps across steps)")),
                    "precision": f"{args.precision} MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision != "f32" else "fp32 MFMA",
                    "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"],
@@ -718,9 +765,10 @@ def main():
         engine.close()
         torch.cuda.empty_cache()
         result["configs"] = []
-        for name, shard_of in (("xlmr_gpt2", 0), ("tinyllama_neox", 0), ("mistral_gpt2_32k", 8)):
+        for name, shard_of, part in (("xlmr_gpt2", 0, "contiguous"), ("tinyllama_neox", 0, "contiguous"), ("mistral_gpt2_32k", 8, "contiguous"),
+                                     ("mistral_gpt2_32k", 8, "affinity")):
             try:
-                result["configs"].append(side_config(name, 0, args.precision, device, steps=3, warmup=1, shard_of=shard_of))
+                result["configs"].append(side_config(name, 0, args.precision, device, steps=5, warmup=2, shard_of=shard_of, partition=part))
             except Exception as e:          # a side line that cannot run must not take the benchmark line with it
                 result["configs"].append({"workload": name, "error": f"{type(e).__name__}: {e}"})
         result["api_path"] = []

@@ -240,6 +240,21 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
  * same bits). */
 int zett_set_option(zett_hypernet* h, const char* key, int64_t value);
 
+/* ---- id-affinity row partition (ABI 6) ----------------------------------------------
+ * Replaces: the ORDER in which the reference hands target-vocabulary rows to its devices — a random permutation cut into
+ * device shards (scripts/transfer.py:54-67, 90-91; zett/utils.py:26).  Rows are independent, so which rank computes which row
+ * is free; it decides how many DISTINCT source ids (hoisted input projection) and distinct (id, position) pairs (layer 0's
+ * Q/K/V) a rank's shard holds.  zett_partition_rows assigns the n_rows rows of a device-resident surface-form matrix to
+ * `world` <= 8 ranks with the given capacities (caps: host array, sum = n_rows) so that rows sharing ids share a rank, and
+ * writes to perm_out (device, int32 [n_rows]) the row indices grouped by rank — rank r's rows at [sum(caps[:r]), + caps[r]),
+ * ascending.  Deterministic: every rank runs it on the same matrix and gets the same permutation (no communication).  One
+ * workgroup, ~4 us per 1024 rows, enqueued on `stream`; `workspace` = zett_partition_workspace_bytes(n_rows, n_ids) device
+ * bytes, n_ids = the exclusive upper bound of the ids that count (original_vocab_size + n_extra; others and pad_id are ignored).
+ * csrc/partition.hip.h has the algorithm. */
+int zett_partition_workspace_bytes(int64_t n_rows, int32_t n_ids, int64_t* out_bytes);
+int zett_partition_rows(const int32_t* surface_forms, int64_t n_rows, int32_t seq, int32_t pad_id, int32_t n_ids, int32_t world,
+                        const int32_t* caps, int32_t* perm_out, void* workspace, int64_t workspace_bytes, int32_t device, void* stream);
+
 /* ---- retokenizer ------------------------------------------------------------
  * Replaces: zett.utils.get_surface_form_matrix (zett/utils.py:651-689) and the
  * tokenizers-library Model.tokenize it calls per token (zett/utils.py:681): BPE, Unigram and WordPiece models. */

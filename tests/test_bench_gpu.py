@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [[], ["--serial-allgather"], ["--gather-mode", "fanout"], ["--serial-allgather", "--no-early-gather"]],
-                         ids=["two-blocks", "serial", "fanout", "serial-late"])
+@pytest.mark.parametrize("extra", [[], ["--serial-allgather"], ["--gather-mode", "fanout"], ["--serial-allgather", "--no-early-gather"],
+                                   ["--partition", "affinity"], ["--partition", "affinity", "--serial-allgather", "--gather-mode", "fanout"]],
+                         ids=["two-blocks", "serial", "fanout", "serial-late", "affinity", "affinity-serial-fanout"])
 def test_two_ranks_on_one_device(extra):
     env = dict(os.environ, ZETT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -27,6 +28,7 @@ def test_two_ranks_on_one_device(extra):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["rows"] == 20001 and d["config"]["rows_per_gpu"] == 10001
     assert d["value"] > 0 and "TEST HOOK" in d["data"]
     # the exchange is accounted for: transport, early start of pred_in / bias, and what of it the compute stream waited for
+    assert d["config"]["partition"] == ("affinity" if "affinity" in extra else "contiguous")
     assert d["exchange"]["mode"] == ("fanout" if "fanout" in extra else "allgather")
     assert d["exchange"]["early_start_of_pred_in_and_bias"] == ("--no-early-gather" not in extra)
     assert d["exchange_exposed_ms_per_step"] is not None and 0 <= d["exchange_exposed_ms_per_step"] < d["ms_per_step"]

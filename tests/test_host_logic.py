@@ -298,6 +298,17 @@ try:
     predict_sharded(fake, big, mode="ring"); ok = False
 except ValueError:
     pass
+# rows sharded in another ORDER (zett_amd.sharding.affinity_order on the GPU; any permutation here) and put back: same result
+g = torch.Generator(); g.manual_seed(5)
+for chunks in (1, 3):
+    order = torch.randperm(big.shape[0], generator=g)
+    for mode in ("allgather", "fanout"):
+        f_perm = predict_sharded(fake2, big, chunks=chunks, mode=mode, order=order)
+        ok = ok and all(torch.equal(a, b) for a, b in zip(f_perm, fake2(big)))
+try:
+    predict_sharded(fake, big, order=torch.arange(3)); ok = False
+except ValueError:
+    pass
 shapes = [tuple(t.shape) for t in full]
 if rank == 0:
     json.dump({{"ok": ok, "shapes": shapes}}, open({out!r}, "w"))

@@ -108,6 +108,13 @@ template <bool HALF> struct G4dGeom {
     static constexpr int AREQ = BM / 32;                 // LDS-DMA requests per wave, K step and A image (8 rows each)
     static constexpr int NREQ = AREQ + 8;                // ... and per K step in all
     static constexpr int NPASS = WROWS / 64;             // epilogue passes of 64 rows
+    // LDS stages of the K loop.  The full tile double-buffers (2 x 64 KiB); the HALF tile's K step is half as long (64 MFMAs), so
+    // a request issued one step ahead has half the time to land — measured: the half tiles of a launch's last round took 0.88 of
+    // a full round instead of ~0.55 — and its stage is 48 KiB (A 16 + W 32): it runs THREE stages, requests two steps ahead
+    static constexpr int STAGES = HALF ? 3 : 2;
+    static constexpr int A_BYTES = BM * GEMM_ROW_BYTES;                     // A image of a stage (W image behind it)
+    static constexpr int STAGE_BYTES = A_BYTES + G256_OPERAND_BYTES;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
 };
 
 // HALF (r5): the same kernel on a 128x256 tile — four waves of 64x128 each (128 accumulators), covering rows [g.row0, g.M) only.
@@ -185,12 +192,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, (short)0, 0x7fffffff, G4R_RSRC_WORD3);
     unsigned char* const my_rows = smem + wave * 64 * GEMM_ROW_BYTES;
     unsigned char* const my_a_rows = smem + wave * (GEO::AREQ * 8) * GEMM_ROW_BYTES;
-    auto dma_a = [&](int kt, int r) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(my_a_rows + (kt & 1) * G256_STAGE_BYTES + r * 8 * GEMM_ROW_BYTES), 16,
+    auto dma_a = [&](int stage, int kt, int r) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(my_a_rows + stage * GEO::STAGE_BYTES + r * 8 * GEMM_ROW_BYTES), 16,
                                                  a_voff[r], kt * GEMM_ROW_BYTES, 0, 0);
     };
-    auto dma_w = [&](int kt, int r) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(my_rows + (kt & 1) * G256_STAGE_BYTES + G256_OPERAND_BYTES + r * 8 * GEMM_ROW_BYTES), 16,
+    auto dma_w = [&](int stage, int kt, int r) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(my_rows + stage * GEO::STAGE_BYTES + GEO::A_BYTES + r * 8 * GEMM_ROW_BYTES), 16,
                                                  w_voff[r], kt * GEMM_ROW_BYTES, 0, 0);
     };
 
@@ -212,15 +219,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int kb = 0; kb < 2; ++kb) {
             const int c = ((kb * 4 + kq) ^ swz) << 4;
             a_off[kb] = (wm * GEO::WROWS + l15) * GEMM_ROW_BYTES + c;
-            w_off[kb] = G256_OPERAND_BYTES + (wn * 128 + l15) * GEMM_ROW_BYTES + c;
+            w_off[kb] = GEO::A_BYTES + (wn * 128 + l15) * GEMM_ROW_BYTES + c;
         }
     }
     u32x4 fa[2][8], fw[2][8];
     auto read_a = [&](int stage, int kb, int i) {
-        fa[kb][i] = *(const u32x4*)(smem + stage * G256_STAGE_BYTES + a_off[kb] + i * 16 * GEMM_ROW_BYTES);
+        fa[kb][i] = *(const u32x4*)(smem + stage * GEO::STAGE_BYTES + a_off[kb] + i * 16 * GEMM_ROW_BYTES);
     };
     auto read_w = [&](int stage, int kb, int j) {
-        fw[kb][j] = *(const u32x4*)(smem + stage * G256_STAGE_BYTES + w_off[kb] + j * 16 * GEMM_ROW_BYTES);
+        fw[kb][j] = *(const u32x4*)(smem + stage * GEO::STAGE_BYTES + w_off[kb] + j * 16 * GEMM_ROW_BYTES);
     };
 
     const int nk = g.K / BK;
@@ -241,19 +248,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             res16[t] = *(const uint4*)(g.epi.residual_lo + (size_t)grow * g.epi.ld_res_lo + gc);
         }
     };
-    // ---- prologue: steps 0 and 1 requested, step 0 landed, its block-0 fragments read
+    // ---- prologue: the first STAGES steps requested, step 0 landed, its block-0 fragments read
 #pragma unroll
-    for (int r = 0; r < 8; ++r) dma_w(0, r);
+    for (int st = 0; st < GEO::STAGES; ++st) {
+        if (st < nk) {
 #pragma unroll
-    for (int r = 0; r < GEO::AREQ; ++r) dma_a(0, r);
-    if (nk > 1) {
+            for (int r = 0; r < 8; ++r) dma_w(st, st, r);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) dma_w(1, r);
-#pragma unroll
-        for (int r = 0; r < GEO::AREQ; ++r) dma_a(1, r);
-        __builtin_amdgcn_s_waitcnt(g4d_wait_vm(GEO::NREQ));
-    } else {
-        __builtin_amdgcn_s_waitcnt(g4d_wait_vm(0));
+            for (int r = 0; r < GEO::AREQ; ++r) dma_a(st, st, r);
+        }
+    }
+    {
+        const int ahead = (nk < GEO::STAGES ? nk : GEO::STAGES) - 1;      // requested steps behind step 0
+        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(g4d_wait_vm(2 * GEO::NREQ));
+        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(g4d_wait_vm(GEO::NREQ));
+        else __builtin_amdgcn_s_waitcnt(g4d_wait_vm(0));
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -262,16 +271,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < GEO::MI; ++i) read_a(0, 0, i);
 
-    // more: step kt+1 exists (its block-0 fragments are read here); more2: step kt+2 exists (requested here);
+    // more: step kt+1 exists (its block-0 fragments are read here); more2: step kt+2 exists; moreA: step kt+STAGES exists (requested
+    // here, into the stage this step computes on: free once every wave has its block-1 fragments);
     // WV: the wave this copy of the loop belongs to (its request slots).  One MFMA per scheduling region.
-    auto step = [&](int kt, auto more_c, auto more2_c, auto wave_c) {
-        constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
+    auto step = [&](int kt, int cur, auto more_c, auto more2_c, auto moreA_c, auto wave_c) {
+        constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value, moreA = decltype(moreA_c)::value;
         constexpr int WV = decltype(wave_c)::value;
-        const int cur = kt & 1;
+        const int nxt = cur + 1 == GEO::STAGES ? 0 : cur + 1;
         // Slots of the K step (p = the MFMA a piece of work is issued behind).  Full tile: the header's schedule.  HALF tile: 64
-        // MFMAs — block-1 fragments 0..22, barrier 26, the 12 requests of step t+2 at 27..50 (two waves per slot), vmcnt +
+        // MFMAs — block-1 fragments 0..22, barrier 26, the 12 requests of step t+3 at 27..50 (two waves per slot), vmcnt +
         // barrier 52, block-0 fragments of step t+1 at 53..63.
         constexpr int P_BAR1 = HALF ? 26 : 36, P_BAR2 = HALF ? 52 : 102;
+        // requests that may still be in flight when step kt+1's must have landed: those of the later steps that exist
+        constexpr int INFLIGHT = HALF ? ((more2 ? 1 : 0) + (moreA ? 1 : 0)) * GEO::NREQ : (moreA ? GEO::NREQ : 0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -281,13 +293,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int p = kb * (GEO::MI * 8) + i * 8 + j;
             // (last step, streamlined epilogues: the barrier every wave passes after its last fragment read, so that
             //  staging the accumulators over the operand images needs no barrier behind the loop)
-            if (p == P_BAR1 && (more2 || (!more && EPI != G4D_EPI_GENERIC))) {         // this wave has every fragment of stage cur in registers
+            if (p == P_BAR1 && (moreA || (!more && EPI != G4D_EPI_GENERIC))) {         // this wave has every fragment of stage cur in registers
                 __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (p == P_BAR2 && more) {         // the requests of this step may be in flight, those of the previous one not
-                __builtin_amdgcn_s_waitcnt(g4d_wait_vm(more2 ? GEO::NREQ : 0));
+            if (p == P_BAR2 && more) {         // the requests of the later steps may be in flight, those of step kt+1 not
+                __builtin_amdgcn_s_waitcnt(g4d_wait_vm(INFLIGHT));
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -295,17 +307,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (p < 16 && (p & 1) == 0) read_w(cur, 1, p >> 1);
             if constexpr (!HALF) {
                 if (p >= 16 && p <= 30 && (p & 1) == 0) read_a(cur, 1, (p - 16) >> 1);
-                if (more2 && p >= 38 && p < 70 && WV == ((p - 38) & 3)) dma_w(kt + 2, (p - 38) >> 2);
-                if (more2 && p >= 70 && p < 102 && WV == ((p - 70) & 3)) dma_a(kt + 2, (p - 70) >> 2);
-                if (more && p >= 103 && p <= 110) read_w(cur ^ 1, 0, p - 103);
-                if (more && p >= 111 && p <= 125 && (p & 1) == 1) read_a(cur ^ 1, 0, (p - 111) >> 1);
+                if (moreA && p >= 38 && p < 70 && WV == ((p - 38) & 3)) dma_w(cur, kt + 2, (p - 38) >> 2);
+                if (moreA && p >= 70 && p < 102 && WV == ((p - 70) & 3)) dma_a(cur, kt + 2, (p - 70) >> 2);
+                if (more && p >= 103 && p <= 110) read_w(nxt, 0, p - 103);
+                if (more && p >= 111 && p <= 125 && (p & 1) == 1) read_a(nxt, 0, (p - 111) >> 1);
                 if constexpr (LN16K) { if (!more && p >= 40 && p < 104 && (p & 3) == 0 && res16_early) res16_request(0, (p - 40) >> 2); }
             } else {
                 if (p >= 16 && p <= 22 && (p & 1) == 0) read_a(cur, 1, (p - 16) >> 1);
-                if (more2 && p >= 27 && p < 43 && (WV & 1) == ((p - 27) & 1)) dma_w(kt + 2, (p - 27) >> 1);
-                if (more2 && p >= 43 && p < 51 && (WV & 1) == ((p - 43) & 1)) dma_a(kt + 2, (p - 43) >> 1);
-                if (more && p >= 53 && p <= 60) read_w(cur ^ 1, 0, p - 53);
-                if (more && p >= 60 && p <= 63) read_a(cur ^ 1, 0, p - 60);
+                if (moreA && p >= 27 && p < 43 && (WV & 1) == ((p - 27) & 1)) dma_w(cur, kt + 3, (p - 27) >> 1);
+                if (moreA && p >= 43 && p < 51 && (WV & 1) == ((p - 43) & 1)) dma_a(cur, kt + 3, (p - 43) >> 1);
+                if (more && p >= 53 && p <= 60) read_w(nxt, 0, p - 53);
+                if (more && p >= 60 && p <= 63) read_a(nxt, 0, p - 60);
                 if constexpr (LN16K) { if (!more && p >= 24 && p < 56 && (p & 1) == 0 && res16_early) res16_request(0, (p - 24) >> 1); }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -314,10 +326,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     typedef std::integral_constant<bool, true> yes_t;
     typedef std::integral_constant<bool, false> no_t;
     auto k_loop = [&](auto wave_c) {
-        int kt = 0;
-        for (; kt + 2 < nk; ++kt) step(kt, yes_t{}, yes_t{}, wave_c);
-        if (kt + 1 < nk) { step(kt, yes_t{}, no_t{}, wave_c); ++kt; }
-        step(kt, no_t{}, no_t{}, wave_c);
+        int kt = 0, cur = 0;
+        auto next = [&]() { ++kt; cur = cur + 1 == GEO::STAGES ? 0 : cur + 1; };
+        for (; kt + GEO::STAGES < nk; next()) step(kt, cur, yes_t{}, yes_t{}, yes_t{}, wave_c);
+        if constexpr (HALF) {
+            if (kt + 2 < nk) { step(kt, cur, yes_t{}, yes_t{}, no_t{}, wave_c); next(); }
+        }
+        if (kt + 1 < nk) { step(kt, cur, yes_t{}, no_t{}, no_t{}, wave_c); next(); }
+        step(kt, cur, no_t{}, no_t{}, no_t{}, wave_c);
     };
     if (wave == 0) k_loop(std::integral_constant<int, 0>{});
     else if (wave == 1) k_loop(std::integral_constant<int, 1>{});
@@ -723,7 +739,8 @@ inline int gemm4d_epi_mode(const GemmArgs<T>& g) {
 
 template <typename T, int ACT, bool RES, int EPI, bool HALF = false>
 inline hipError_t launch_gemm4d_inst(const GemmArgs<T>& g, hipStream_t stream) {
-    constexpr int lds = EPI == G4D_EPI_GENERIC ? G256_LDS_BYTES : G4D_LDS_BYTES;
+    constexpr int lds = EPI == G4D_EPI_GENERIC ? G256_LDS_BYTES : (G4dGeom<HALF>::LDS_BYTES > G4D_LDS_BYTES ? G4dGeom<HALF>::LDS_BYTES : G4D_LDS_BYTES);
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static DeviceFlags attr;
     bool* done = attr.current();
     if (!done || !*done) {
@@ -783,7 +800,7 @@ inline bool gemm4d_half_ok(const GemmArgs<T>& g, int mode) {
 // Rows [0, row0) of a launch go to 256x256 tiles, rows [row0, M) to 128x256 tiles (see the kernel's header): row0 = M (no
 // split) unless the full tiles leave a partly filled last round of `cus` workgroups that the half tiles fill more cheaply.  A
 // half tile is priced at 0.64 of a full one (half the MFMAs at ~0.78 of the rate).
-inline int gemm4d_row_split(int M, int N, int cus = 256, double half_cost = 0.64) {
+inline int gemm4d_row_split(int M, int N, int cus = 256, double half_cost = 0.62) {
     const long tn = (N + G256_BN - 1) / G256_BN, tm = (M + G256_BM - 1) / G256_BM;
     const long T = tm * tn;
     if (T % cus == 0) return M;

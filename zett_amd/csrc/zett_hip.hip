@@ -33,6 +33,7 @@
 #include "gemm_launch.hip.h"
 #include "rowops.hip.h"
 #include "retok.hip.h"
+#include "partition.hip.h"
 
 using namespace zett;
 
@@ -654,6 +655,37 @@ int zett_check_range(zett_hypernet* h, void* stream, int32_t* flags) {
                 (w & ZETT_RANGE_ACTIVATION) ? " a 16-bit activation (Q/K/V, FFN intermediate or the operand copy of the residual sum) beyond the half range;" : "",
                 (w & ZETT_RANGE_OUTPUT) ? " non-finite predicted embeddings;" : "",
                 h->precision == ZETT_PREC_F16 ? "f16: re-run with ZETT_PREC_BF16" : h->precision == ZETT_PREC_BF16 ? "bf16" : "f32");
+}
+
+int zett_partition_workspace_bytes(int64_t n_rows, int32_t n_ids, int64_t* out_bytes) {
+    if (!out_bytes || n_rows < 0 || n_ids < 1) return fail(ZETT_E_INVALID, "bad argument");
+    *out_bytes = (int64_t)partition_workspace_bytes(n_rows, n_ids);
+    return 0;
+}
+
+int zett_partition_rows(const int32_t* surface_forms, int64_t n_rows, int32_t seq, int32_t pad_id, int32_t n_ids, int32_t world,
+                        const int32_t* caps, int32_t* perm_out, void* workspace, int64_t workspace_bytes, int32_t device, void* stream) {
+    if (n_rows < 0 || seq < 1 || n_ids < 1) return fail(ZETT_E_INVALID, "bad surface-form shape [%lld, %d] / id range %d", (long long)n_rows, seq, n_ids);
+    if (world < 1 || world > PART_MAX_RANKS) return fail(ZETT_E_INVALID, "zett_partition_rows handles 1..%d ranks (one node), got %d", PART_MAX_RANKS, world);
+    if (n_rows == 0) return 0;
+    if (!surface_forms || !caps || !perm_out || !workspace) return fail(ZETT_E_INVALID, "null argument");
+    if (n_rows >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many rows for one call");
+    int64_t total = 0;
+    for (int r = 0; r < world; ++r) { if (caps[r] < 0) return fail(ZETT_E_INVALID, "negative capacity"); total += caps[r]; }
+    if (total != n_rows) return fail(ZETT_E_INVALID, "the ranks' capacities sum to %lld, the matrix has %lld rows", (long long)total, (long long)n_rows);
+    if ((size_t)workspace_bytes < partition_workspace_bytes(n_rows, n_ids)) return fail(ZETT_E_INVALID, "workspace too small (zett_partition_workspace_bytes)");
+    ZETT_ON_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t have_bytes = ((size_t)(n_ids + 3) / 4) * 4 + 64;
+    uint32_t* have = (uint32_t*)workspace;
+    int8_t* rank_of = (int8_t*)workspace + have_bytes;
+    int32_t* d_caps = (int32_t*)((char*)workspace + have_bytes + (((size_t)n_rows + 63) / 64) * 64);
+    HIP_TRY(hipMemsetAsync(have, 0, have_bytes, st));
+    HIP_TRY(hipMemcpyAsync(d_caps, caps, (size_t)world * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(partition_rows_kernel, dim3(1), dim3(PART_THREADS), 0, st, surface_forms, n_rows, (int)seq, (int)pad_id, (int)n_ids, (int)world,
+                       (const int32_t*)d_caps, have, rank_of, perm_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int zett_forward_prepare(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq, void* input_stream) {

@@ -71,6 +71,67 @@ def padded_rows(blocks: Sequence[Block], world: int) -> int:
     return sum(b.per * world for b in blocks)
 
 
+def rank_row_counts(n_rows: int, world: int, chunks: int = 2, min_rows_per_shard: int = 4096) -> List[int]:
+    """Rows plan_blocks hands to each rank over all its blocks (sums to n_rows)."""
+    return [sum(b.hi - b.lo for b in plan_blocks(n_rows, world, r, chunks, min_rows_per_shard)) for r in range(int(world))]
+
+
+def affinity_order(surface_forms: torch.Tensor, world: int, pad_token_id: int, n_ids: int, chunks: int = 2,
+                   min_rows_per_shard: int = 4096) -> torch.Tensor:
+    """Row order for the vocabulary-sharded path in which rows that share source ids land on the same rank (int64 [n_rows] on the
+    device: `surface_forms.index_select(0, order)` is the matrix predict_sharded should then shard CONTIGUOUSLY, and
+    `out.index_copy_(0, order, gathered)` undoes it).  zett_partition_rows (csrc/partition.hip.h) groups the rows by rank —
+    capacities = the row counts plan_blocks gives each rank — and the groups are laid out block by block, rank by rank, exactly
+    where plan_blocks(…, rank) will look for them.  Deterministic and communication-free: every rank computes the same order
+    from the same matrix.  Why: a rank's forward runs the hoisted input projection once per DISTINCT source id of its shard and
+    layer 0's Q/K/V once per distinct (id, position) pair; the reference hands its devices the rows in random order
+    (scripts/transfer.py:54-67, 90-91), contiguous shards are no better, and at 8 ranks the headline vocabulary then carries
+    8 340 ids per rank where this order leaves ~5 970 and gives the pair lever its repeats back."""
+    import ctypes as C
+
+    from . import _lib
+    if not surface_forms.is_cuda:
+        raise RuntimeError("zett_amd computes on MI355X only: affinity_order takes the surface-form matrix on a cuda (ROCm) device")
+    world = int(world)
+    sfm = surface_forms.to(torch.int32).contiguous()
+    n, seq = sfm.shape
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=sfm.device)
+    lib = _lib.load()
+    caps = rank_row_counts(n, world, chunks, min_rows_per_shard)
+    ws_bytes = C.c_int64(0)
+    _lib.check(lib.zett_partition_workspace_bytes(n, int(n_ids), C.byref(ws_bytes)), "zett_partition_workspace_bytes")
+    ws = torch.empty((ws_bytes.value,), dtype=torch.uint8, device=sfm.device)
+    perm = torch.empty((n,), dtype=torch.int32, device=sfm.device)
+    index = sfm.device.index if sfm.device.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(sfm.device):
+        stream = torch.cuda.current_stream(sfm.device).cuda_stream
+        _lib.check(lib.zett_partition_rows(C.c_void_p(sfm.data_ptr()), n, seq, int(pad_token_id), int(n_ids), world, (C.c_int32 * world)(*caps),
+                                           C.c_void_p(perm.data_ptr()), C.c_void_p(ws.data_ptr()), ws_bytes.value, index, C.c_void_p(stream)),
+                   "zett_partition_rows")
+    # where plan_blocks looks for rank r's rows: per block [lo, hi).  src[i] = position in `perm` (grouped by rank) of the row that
+    # goes to place i of the sharded order — pure arithmetic on the block plan, cached per (n, world, chunks)
+    key = (n, world, int(chunks), int(min_rows_per_shard), str(sfm.device))
+    src = _ORDER_CACHE.get(key)
+    if src is None:
+        import numpy as np
+        src_np = np.empty(n, dtype=np.int64)
+        base = 0
+        for r in range(world):
+            taken = 0
+            for b in plan_blocks(n, world, r, chunks, min_rows_per_shard):
+                src_np[b.lo:b.hi] = np.arange(base + taken, base + taken + (b.hi - b.lo))
+                taken += b.hi - b.lo
+            base += caps[r]
+        src = torch.from_numpy(src_np).to(sfm.device)
+        if len(_ORDER_CACHE) > 16:
+            _ORDER_CACHE.clear()
+        _ORDER_CACHE[key] = src
+    return perm.long().index_select(0, src)
+
+
+_ORDER_CACHE = {}
+
 GATHER_MODES = ("allgather", "fanout")
 
 
@@ -198,7 +259,8 @@ def all_gather_rows(local: torch.Tensor, n_rows: int, per: int, group=None) -> t
 
 
 def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group=None, chunks: int = 2,
-                    ready: Optional[Callable] = None, mode: str = "auto", prepare: Optional[Callable] = None):
+                    ready: Optional[Callable] = None, mode: str = "auto", prepare: Optional[Callable] = None,
+                    order: Optional[torch.Tensor] = None):
     """Run `predict(rows) -> (pred_in, pred_out | None, bias)` on this rank's rows and return the full result on every
     rank.  The vocabulary is processed in `chunks` row blocks whose exchange overlaps the next block's forward (module
     docstring); chunks = 1 is the plain shard-then-gather.  `ready` (RowGather: early start of pred_in / bias) and `mode`
@@ -206,6 +268,10 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
 
     `predict` is typically ``lambda rows: engine.forward(rows, source_embeddings, lang)`` with
     ``ready=engine.stream_wait_output``.  Without an initialised process group this is just ``predict(target_surface_forms)``.
+
+    `order` (``affinity_order(...)``: int64 [n] on the device) — shard the rows in THAT order instead of vocabulary order: rank r
+    computes rows order[lo:hi] of every block, and the gathered matrices are put back into vocabulary order by one indexed copy
+    per output behind the exchange.  Same rows, same bits.
 
     `prepare(rows, stream)` (``engine.prepare``: zett_forward_prepare) — with more than one block per rank, the plan of block
     k + 1 is enqueued as soon as block k's forward is, on the engine's own stream behind a side stream that holds nothing but
@@ -220,6 +286,11 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
     if not blocks:
         return predict(target_surface_forms)
     gather = RowGather(blocks, group, mode)
+    if order is not None:
+        if order.shape[0] != n:
+            raise ValueError("order must hold one entry per row")
+        vocabulary_order = target_surface_forms
+        target_surface_forms = vocabulary_order.index_select(0, order)
 
     def rows_of(b):
         # (more ranks than rows in the block: compute one dummy row, contribute none)
@@ -237,4 +308,7 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
         if b.hi - b.lo == 0:
             outs = tuple(None if t is None else t[:0] for t in outs)
         gather.add(b, outs, ready)
-    return gather.finish(n)
+    full = gather.finish(n)
+    if order is None:
+        return full
+    return tuple(None if t is None else torch.empty_like(t).index_copy_(0, order, t) for t in full)
