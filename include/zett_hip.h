@@ -233,7 +233,8 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
  * operands and K >= "gemm4d_min_k", default 512), 8 = as 7 with the generic epilogue drain; all produce
  * identical bits; a forced variant falls back to 2 where its preconditions do not
  * hold), "gemm_tile_order" (A/B only: 0 = the order in which gemm4d walks column
- * tiles first, default; 1 = row tiles first; same bits), "gemm_tail_split" (0/1/2/3, default 1: a 256x256-tile launch whose
+ * tiles first, default; 1 = row tiles first; same bits), "gemm_group" (A/B only: column — or, order 1, row — tiles per group of that
+ * walk, 0 = the default of 4; same bits), "gemm_tail_split" (0/1/2/3, default 1: a 256x256-tile launch whose
  * tiles fill R whole rounds of the 256 CUs and part of one more is cut into 256x256 tiles on the rows of the whole rounds and
  * 128x256 tiles — twice as many workgroups of half the work — on the rest, when that is cheaper (a rank's 4 096-row shard at
  * 8 GPUs: M = 9 682, N = 4096 is 2.375 rounds); 0 = never, 2 = cut every launch in the middle, 3 = 128x256 tiles only (tests);

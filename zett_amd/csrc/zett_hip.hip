@@ -85,6 +85,7 @@ struct zett_hypernet {
     int gemm_tail_split = 1;          // gemm4d: a launch's partly filled last round of 256 CUs as 128x256 tiles (gemm4d.hip.h gemm4d_row_split): 0 never,
                                       // 1 when the split is cheaper (default), 2 = cut every launch in the middle, 3 = half tiles only (tests: same bits)
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
+    int gemm_group = 0;               // gemm4d: column (order 0) / row (order 1) tiles per group; 0 = the kernel's default, 4 (A/B)
     int gemm4d_min_k = 512;           // 16-bit launches with K >= this take the four-wave direct-to-LDS tile (r2: with the streamlined epilogues it is ahead of gemm8r down to K = 768: +1.8 % on the XLM-R workload)
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
                                       // 7 = 256x256 four-wave direct-to-LDS, 8 = as 7 with the generic epilogue drain
@@ -587,6 +588,9 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "gemm_tail_split") {
         if (value < 0 || value > 3) return fail(ZETT_E_INVALID, "gemm_tail_split must be 0 (never), 1 (auto), 2 (cut every gemm4d launch in the middle) or 3 (128x256 tiles only)");
         h->gemm_tail_split = (int)value;
+    } else if (k == "gemm_group") {
+        if (value < 0 || value > 64) return fail(ZETT_E_INVALID, "gemm_group must be 0 (default: 4) .. 64");
+        h->gemm_group = (int)value;
     } else if (k == "gemm_tile_order") {
         if (value < 0 || value > 1) return fail(ZETT_E_INVALID, "gemm_tile_order must be 0 or 1");
         h->gemm_tile_order = (int)value;
@@ -778,6 +782,7 @@ struct Runner {
         if (rc || M <= 0) return;
         GemmArgs<T> g{A, lda, Wp, ldw, M, N, K, e};
         g.tile_order = h->gemm_tile_order;
+        g.group = h->gemm_group;
         g.row0 = h->gemm_tail_split == 1 ? -1 : h->gemm_tail_split == 2 ? ((M / 2 + 255) / 256) * 256 : h->gemm_tail_split == 3 ? -2 : 0;
         const double fl = 2.0 * (double)M * (double)N * (double)K;
         hipEvent_t e0 = nullptr, e1 = nullptr;
