@@ -50,6 +50,15 @@
 
 namespace zett {
 
+// Ablation hook for tools/gemm4d_ablate.hip ONLY (the library never defines it: level 5 = the product kernel, every condition
+// below folds away).  Levels, cumulative, on REAL operands (the LDS stages keep the random tiles the prologue loaded, so the
+// MFMAs toggle real data at every level): 1 = the MFMAs of the K loop alone, 2 = + the fragment reads (ds_read_b128), 3 = + the
+// LDS-DMA requests, 4 = + the waits and barriers (= the whole K loop), 5 = + the epilogue.
+#ifndef G4D_ABLATE
+#define G4D_ABLATE 5
+#endif
+constexpr int G4D_ABL = G4D_ABLATE;
+
 // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt = simm16[15:14]:[3:0], expcnt [6:4], lgkmcnt [11:8])
 constexpr int g4d_wait_vm(int n) { return ((n >> 4) << 14) | 0x0F70 | (n & 15); }
 
@@ -270,6 +279,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = 0; j < 8; ++j) read_w(0, 0, j);
 #pragma unroll
     for (int i = 0; i < GEO::MI; ++i) read_a(0, 0, i);
+    if constexpr (G4D_ABL < 2) {          // (ablation: no fragment reads in the loop — both K blocks' fragments are read once, here)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) read_w(0, 1, j);
+#pragma unroll
+        for (int i = 0; i < GEO::MI; ++i) read_a(0, 1, i);
+        __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
+    }
 
     // more: step kt+1 exists (its block-0 fragments are read here); more2: step kt+2 exists; moreA: step kt+STAGES exists (requested
     // here, into the stage this step computes on: free once every wave has its block-1 fragments);
@@ -293,24 +309,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int p = kb * (GEO::MI * 8) + i * 8 + j;
             // (last step, streamlined epilogues: the barrier every wave passes after its last fragment read, so that
             //  staging the accumulators over the operand images needs no barrier behind the loop)
-            if (p == P_BAR1 && (moreA || (!more && EPI != G4D_EPI_GENERIC))) {         // this wave has every fragment of stage cur in registers
+            if (G4D_ABL >= 4 && p == P_BAR1 && (moreA || (!more && EPI != G4D_EPI_GENERIC))) {         // this wave has every fragment of stage cur in registers
                 __builtin_amdgcn_s_waitcnt(G4R_WAIT_LGKM0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (p == P_BAR2 && more) {         // the requests of the later steps may be in flight, those of step kt+1 not
+            if (G4D_ABL >= 4 && p == P_BAR2 && more) {         // the requests of the later steps may be in flight, those of step kt+1 not
                 __builtin_amdgcn_s_waitcnt(g4d_wait_vm(INFLIGHT));
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
             mfma16_agpr<T>(acc[i][j], fa[kb][i], fw[kb][j]);
-            if (p < 16 && (p & 1) == 0) read_w(cur, 1, p >> 1);
+            constexpr bool RD = G4D_ABL >= 2, DMA = G4D_ABL >= 3;          // (ablation hook: always true in the library)
+            if (RD && p < 16 && (p & 1) == 0) read_w(cur, 1, p >> 1);
             if constexpr (!HALF) {
-                if (p >= 16 && p <= 30 && (p & 1) == 0) read_a(cur, 1, (p - 16) >> 1);
-                if (moreA && p >= 38 && p < 70 && WV == ((p - 38) & 3)) dma_w(cur, kt + 2, (p - 38) >> 2);
-                if (moreA && p >= 70 && p < 102 && WV == ((p - 70) & 3)) dma_a(cur, kt + 2, (p - 70) >> 2);
-                if (more && p >= 103 && p <= 110) read_w(nxt, 0, p - 103);
-                if (more && p >= 111 && p <= 125 && (p & 1) == 1) read_a(nxt, 0, (p - 111) >> 1);
+                if (RD && p >= 16 && p <= 30 && (p & 1) == 0) read_a(cur, 1, (p - 16) >> 1);
+                if (DMA && moreA && p >= 38 && p < 70 && WV == ((p - 38) & 3)) dma_w(cur, kt + 2, (p - 38) >> 2);
+                if (DMA && moreA && p >= 70 && p < 102 && WV == ((p - 70) & 3)) dma_a(cur, kt + 2, (p - 70) >> 2);
+                if (RD && more && p >= 103 && p <= 110) read_w(nxt, 0, p - 103);
+                if (RD && more && p >= 111 && p <= 125 && (p & 1) == 1) read_a(nxt, 0, (p - 111) >> 1);
                 if constexpr (LN16K) { if (!more && p >= 40 && p < 104 && (p & 3) == 0 && res16_early) res16_request(0, (p - 40) >> 2); }
             } else {
                 if (p >= 16 && p <= 22 && (p & 1) == 0) read_a(cur, 1, (p - 16) >> 1);
@@ -341,6 +358,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else k_loop(std::integral_constant<int, 3>{});
 
     asm volatile("s_nop 15\n\ts_nop 15");     // last MFMA (8 passes) -> first accumulator read
+    if constexpr (G4D_ABL < 5) {          // (ablation: no epilogue — one value per lane keeps the accumulators alive)
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < GEO::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 123.456f) g.epi.out_lo[threadIdx.x] = (T)0;
+        return;
+    }
     // the lane-derived indices of the epilogue are recomputed from an opaque copy of the thread id: kept alive
     // across the K loop (the compiler shares them with the prologue's) they are what no longer fits in 256 VGPRs
     int tid_e = tid;
