@@ -287,15 +287,28 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
     if affinity:
         # what follows the exchange: one indexed copy per output over the WHOLE vocabulary (local HBM traffic)
         order = affinity_order(retok.run_async(d_text, d_off, n_tok, seq_len), shard_of, dims.pad_token_id, n_ids, chunks=1)
-        bufs = [torch.empty((vocab_rows, dims.n_embd), device=device) for _ in range(2 if dims.separate_out else 1)] + [torch.empty((vocab_rows,), device=device)]
+        bufs = [torch.randn((vocab_rows, dims.n_embd), device=device) for _ in range(2 if dims.separate_out else 1)] + [torch.randn((vocab_rows,), device=device)]
+        import ctypes as C
+        from zett_amd import _lib
+        lib = _lib.load()
+        outs = [torch.empty_like(t) for t in bufs]
+
+        def scatter_all():
+            st = torch.cuda.current_stream(device).cuda_stream
+            for t, o in zip(bufs, outs):
+                rb = t[0].numel() * 4 if t.dim() > 1 else 4
+                _lib.check(lib.zett_scatter_rows(C.c_void_p(t.data_ptr()), C.c_void_p(o.data_ptr()), C.c_void_p(order.data_ptr()), vocab_rows, rb,
+                                                 device.index or 0, C.c_void_p(st)), "zett_scatter_rows")
         for _ in range(2):
-            outs = [torch.empty_like(t).index_copy_(0, order, t) for t in bufs]
+            scatter_all()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(5):
-            outs = [torch.empty_like(t).index_copy_(0, order, t) for t in bufs]
+            scatter_all()
         torch.cuda.synchronize()
         unpermute_ms = (time.perf_counter() - t1) / 5 * 1e3
+        if not all(torch.equal(o.index_select(0, order), t) for t, o in zip(bufs, outs)):
+            raise SystemExit("zett_scatter_rows: rows landed in the wrong place")
         retok.result()
         del bufs, outs
     res = {"workload": workload + (f" (rank 0 of {shard_of}: {n} of {vocab_rows} rows, {partition} shards)" if shard_of else ""), "rows": n, "dtype": precision,
@@ -544,7 +557,7 @@ def main():
     classes = {}          # launch class -> [launches, ms, flops, algorithmic bytes] over the timed steps (zett_get_gemm_log)
 
     def step():
-        gather = RowGather(blocks, mode=gather_mode) if exchange else None
+        gather = None
         ready = None if args.no_early_gather else engine.stream_wait_output
         outs = None
         # the step's id matrices: every block retokenized at the head of the step, without a host round trip
@@ -558,6 +571,8 @@ def main():
             sfms = [sfm_all.index_select(0, order[b.lo:b.hi]) for b in blocks]
         else:
             sfms = ids_blocks if retok is None else [retok.run_async(*texts[k], seq_len) for k in range(len(blocks))]
+        if exchange:
+            gather = RowGather(blocks, mode=gather_mode, order=order)          # (affinity: every block is scattered to its vocabulary rows behind its exchange)
         if len(blocks) > 1:
             ahead.wait_stream(torch.cuda.current_stream(device))      # behind this step's retokenization
         for k, b in enumerate(blocks):
@@ -577,8 +592,6 @@ def main():
             return outs
         full = gather.finish(rows, timed=True)
         exposed.append(gather.exposed_ms)
-        if order is not None:          # back into vocabulary order: one indexed copy per output
-            full = tuple(None if t is None else torch.empty_like(t).index_copy_(0, order, t) for t in full)
         return full
 
     gemm_ms = gemm_fl = 0.0

@@ -249,12 +249,16 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value);
  * `world` <= 8 ranks with the given capacities (caps: host array, sum = n_rows) so that rows sharing ids share a rank, and
  * writes to perm_out (device, int32 [n_rows]) the row indices grouped by rank — rank r's rows at [sum(caps[:r]), + caps[r]),
  * ascending.  Deterministic: every rank runs it on the same matrix and gets the same permutation (no communication).  One
- * workgroup, ~4 us per 1024 rows, enqueued on `stream`; `workspace` = zett_partition_workspace_bytes(n_rows, n_ids) device
+ * workgroup, ~2 us per 1024 rows, enqueued on `stream`; `workspace` = zett_partition_workspace_bytes(n_rows, n_ids) device
  * bytes, n_ids = the exclusive upper bound of the ids that count (original_vocab_size + n_extra; others and pad_id are ignored).
  * csrc/partition.hip.h has the algorithm. */
 int zett_partition_workspace_bytes(int64_t n_rows, int32_t n_ids, int64_t* out_bytes);
 int zett_partition_rows(const int32_t* surface_forms, int64_t n_rows, int32_t seq, int32_t pad_id, int32_t n_ids, int32_t world,
                         const int32_t* caps, int32_t* perm_out, void* workspace, int64_t workspace_bytes, int32_t device, void* stream);
+/* dst[order[i]] = src[i] for i < n_rows, rows of row_bytes bytes (4, or a multiple of 16; device pointers; order: int64, < 0 =
+ * skip): puts an exchanged block of predicted rows back into vocabulary order — the counterpart of the reference's
+ * `preds[indices] += ...` scatter (scripts/transfer.py:96-111).  An HBM stream on `stream`. */
+int zett_scatter_rows(const void* src, void* dst, const int64_t* order, int64_t n_rows, int64_t row_bytes, int32_t device, void* stream);
 
 /* ---- retokenizer ------------------------------------------------------------
  * Replaces: zett.utils.get_surface_form_matrix (zett/utils.py:651-689) and the

@@ -43,10 +43,6 @@ def test_kernel_equals_its_specification(name, rows, world):
     again = _partition(ids, pad, n_ids, caps)
     np.testing.assert_array_equal(got, again)                                   # deterministic
     assert sorted(got.tolist()) == list(range(rows))                            # a permutation
-    off = np.concatenate([[0], np.cumsum(caps)])
-    for r in range(world):
-        g = got[off[r]:off[r + 1]]
-        assert (np.diff(g) > 0).all()                                           # ascending within a rank
     np.testing.assert_array_equal(got, partition_ref.partition_rows(ids, pad, n_ids, caps))
     # uneven capacities (what plan_blocks hands out when the rows do not divide)
     if rows >= 4 * world:
@@ -64,9 +60,9 @@ def test_partition_lowers_distinct_ids_per_rank():
     perm = _partition(ids, pad, n_ids, caps)
     aff = partition_ref.shard_statistics(ids, pad, np.split(perm, 8))
     con = partition_ref.shard_statistics(ids, pad, np.split(np.arange(rows), 8))
-    assert max(s[2] for s in aff) < 0.75 * min(s[2] for s in con), (aff, con)            # 8 370 -> ~5 970 distinct ids per rank
+    assert max(s[2] for s in aff) < 0.72 * min(s[2] for s in con), (aff, con)            # 8 370 -> ~5 790 distinct ids per rank
     assert max(s[3] / s[1] for s in aff) < 0.85 < min(s[3] / s[1] for s in con)           # the pair lever's threshold is met again
-    assert max(s[1] for s in aff) < 1.08 * min(s[1] for s in aff)                        # packed positions stay within a few percent (9 454 .. 10 024)
+    assert max(s[1] for s in aff) < 1.03 * min(s[1] for s in aff)                        # packed positions within ~2 % of each other (the balance term)
 
 
 def test_bad_arguments():

@@ -56,6 +56,18 @@ for chunks in (1, 2, 3):
 full = predict_sharded(predict, ids, chunks=2, ready=eng.stream_wait_output)
 torch.cuda.synchronize()
 ok = ok and all(torch.equal(a, b) for a, b in zip(full, single))
+# the id-affinity order (zett_partition_rows) through the same exchange: every block scattered to its vocabulary rows behind
+# its all-gather / fan-out, on the side streams (zett_scatter_rows) — early start or not, one block or three
+from zett_amd.sharding import affinity_order
+for chunks in (1, 3):
+    order = affinity_order(ids, 1, cfg["pad_token_id"], cfg["original_vocab_size"] + cfg["hn_n_extra_tokens"], chunks=chunks, min_rows_per_shard=1024)
+    order = order[torch.randperm(order.shape[0], device=dev)] if chunks == 3 else order          # (one rank: the partition is the identity; any order must work)
+    for mode in ("allgather", "fanout"):
+        for ready in (None, eng.stream_wait_output):
+            full = predict_sharded(predict, ids, chunks=chunks, ready=ready, mode=mode, order=order)
+            torch.cuda.synchronize()
+            ok = ok and all(torch.equal(a, b) for a, b in zip(full, single))
+            runs += 1
 # the flag-word reduction of the sharded CLI (MAX per bit: RCCL refuses ReduceOp.BOR)
 ok = ok and reduce_flag_word(5, dev) == 5 and reduce_flag_word(0, dev) == 0
 try:
@@ -79,7 +91,7 @@ def test_row_gather_over_a_one_rank_rccl_group(tmp_path):
     res = subprocess.run([sys.executable, script], cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     d = json.load(open(out))
-    assert d["ok"] and d["runs"] == 18, d
+    assert d["ok"] and d["runs"] == 26, d
     assert d["rccl"], "no RCCL library mapped into the process: the nccl backend did not run"
 
 

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "zett_finalize", "zett_forward", "zett_get_stats", "zett_workspace_bytes", "zett_set_option",
     "zett_retok_create", "zett_retok_destroy", "zett_retokenize", "zett_check_range", "zett_get_gemm_log",
     "zett_stream_wait_output", "zett_forward_prepare", "zett_retokenize_async", "zett_retok_result",
-    "zett_partition_rows", "zett_partition_workspace_bytes",
+    "zett_partition_rows", "zett_partition_workspace_bytes", "zett_scatter_rows",
     # training primitives (zett_amd/autograd.py)
     "zett_op_gemm_f32", "zett_op_transpose_f32", "zett_op_colsum_f32", "zett_op_elementwise_f32", "zett_op_rowdot_f32",
     "zett_op_layernorm_fwd_f32", "zett_op_layernorm_bwd_f32", "zett_op_gelu_fwd_f32", "zett_op_gelu_bwd_f32",
@@ -114,6 +114,7 @@ def load():
         lib.zett_retok_result.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.zett_forward_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         lib.zett_partition_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
+        lib.zett_scatter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
         lib.zett_partition_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                             C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float

@@ -686,8 +686,37 @@ int zett_partition_rows(const int32_t* surface_forms, int64_t n_rows, int32_t se
     int32_t* d_caps = (int32_t*)((char*)workspace + have_bytes + (((size_t)n_rows + 63) / 64) * 64);
     HIP_TRY(hipMemsetAsync(have, 0, have_bytes, st));
     HIP_TRY(hipMemcpyAsync(d_caps, caps, (size_t)world * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(partition_rows_kernel, dim3(1), dim3(PART_THREADS), 0, st, surface_forms, n_rows, (int)seq, (int)pad_id, (int)n_ids, (int)world,
-                       (const int32_t*)d_caps, have, rank_of, perm_out);
+    // the rank bytes live in LDS when the id range fits (a byte per id beside ~1 KiB of counters), else in the workspace
+    const size_t lds_have = ((size_t)(n_ids + 3) / 4) * 4;
+    if (lds_have <= 150 * 1024) {
+        static bool attr_set[64] = {};          // (per device: the attribute belongs to the device's copy of the kernel)
+        if (device >= 64 || !attr_set[device]) {
+            HIP_TRY(hipFuncSetAttribute((const void*)partition_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            if (device < 64) attr_set[device] = true;
+        }
+        hipLaunchKernelGGL(partition_rows_kernel<true>, dim3(1), dim3(PART_THREADS), lds_have, st, surface_forms, n_rows, (int)seq, (int)pad_id, (int)n_ids,
+                           (int)world, (const int32_t*)d_caps, have, rank_of, perm_out);
+    } else {
+        hipLaunchKernelGGL(partition_rows_kernel<false>, dim3(1), dim3(PART_THREADS), 0, st, surface_forms, n_rows, (int)seq, (int)pad_id, (int)n_ids,
+                           (int)world, (const int32_t*)d_caps, have, rank_of, perm_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int zett_scatter_rows(const void* src, void* dst, const int64_t* order, int64_t n_rows, int64_t row_bytes, int32_t device, void* stream) {
+    if (n_rows < 0 || row_bytes < 1) return fail(ZETT_E_INVALID, "bad shape");
+    if (n_rows == 0) return 0;
+    if (!src || !dst || !order) return fail(ZETT_E_INVALID, "null argument");
+    if (row_bytes != 4 && row_bytes % 16 != 0) return fail(ZETT_E_INVALID, "row_bytes must be 4 or a multiple of 16, got %lld", (long long)row_bytes);
+    if (((uintptr_t)src | (uintptr_t)dst) % (row_bytes == 4 ? 4 : 16)) return fail(ZETT_E_INVALID, "misaligned buffer");
+    ZETT_ON_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    if (row_bytes == 4)
+        hipLaunchKernelGGL(scatter_words_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, order, n_rows);
+    else
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)std::min<int64_t>(n_rows, 65535 * 16)), dim3(256), 0, st, (const unsigned char*)src, (unsigned char*)dst,
+                           order, n_rows, row_bytes);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -170,8 +170,16 @@ class RowGather:
     exchange is issued on a side stream behind that point instead of behind the whole forward; pred_out follows in stream
     order.  This is what hides half of the exchange when a rank has ONE block (8 GPUs on the headline vocabulary)."""
 
-    def __init__(self, blocks: Sequence[Block], group=None, mode: str = "auto"):
+    def __init__(self, blocks: Sequence[Block], group=None, mode: str = "auto", order: Optional[torch.Tensor] = None):
         self.blocks = list(blocks)
+        # `order` (affinity_order: int64 [n_rows], place in the sharded order -> vocabulary row): the blocks are gathered in the
+        # sharded order and every block is scattered into vocabulary order as soon as ITS exchange has completed — on a side
+        # stream, under whatever the compute stream does next (the next block's forward; for pred_in / bias of an early start,
+        # the second output head): only the last block's pred_out scatter is exposed.
+        self.order = order
+        self.out: Optional[List[Optional[torch.Tensor]]] = None
+        self._late: Optional[torch.cuda.Stream] = None
+        self._pending = []           # CPU tensors (gloo tests): (tensor index, lo, hi) scattered in finish()
         self.group = group
         self.world = dist.get_world_size(group)
         self.mode = resolve_gather_mode(mode, self.world)
@@ -183,7 +191,8 @@ class RowGather:
         self._side: Optional[torch.cuda.Stream] = None
         self.exposed_ms: Optional[float] = None        # set by finish(timed=True): how long the compute stream waited for the exchange
 
-    def _exchange(self, block: Block, t: torch.Tensor, full: torch.Tensor) -> None:
+    def _exchange(self, block: Block, t: torch.Tensor, full: torch.Tensor) -> list:
+        first_work = len(self._works)
         t = t[: block.hi - block.lo]
         if t.shape[0] != block.per:                  # short shard (end of the vocabulary, or a surplus rank): pad
             pad = torch.zeros((block.per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -205,10 +214,49 @@ class RowGather:
             if ops:
                 self._works.extend(dist.batch_isend_irecv(ops))
         self._keep.append(t)
+        return self._works[first_work:]
+
+    def _scatter(self, i: int, block: Block, works: list, early: bool) -> None:
+        """Rows [block.start, block.start + world * per) of the gathered buffer i -> their vocabulary rows of self.out[i], behind
+        the block's exchange, on a side stream (zett_scatter_rows)."""
+        n = int(self.order.shape[0])
+        lo, hi = block.start, min(block.start + self.world * block.per, n)
+        if hi <= lo:
+            return
+        full, out = self.full[i], self.out[i]
+        if not full.is_cuda:
+            self._pending.append((i, lo, hi))
+            return
+        import ctypes as C
+
+        from . import _lib
+        cur = torch.cuda.current_stream(full.device)
+        if early:
+            side = self._side                       # (the exchange was issued from it)
+        else:
+            if self._late is None:
+                self._late = torch.cuda.Stream(device=full.device)
+            side = self._late
+            side.wait_stream(cur)                   # behind the local copy / the point the exchange was issued from
+        row_bytes = full[0].numel() * full.element_size() if full.dim() > 1 else full.element_size()
+        with torch.cuda.stream(side):
+            for w in works:
+                w.wait()                            # the side stream waits for the collective; nobody else does yet
+            index = full.device.index if full.device.index is not None else torch.cuda.current_device()
+            _lib.check(_lib.load().zett_scatter_rows(C.c_void_p(full.data_ptr() + lo * row_bytes), C.c_void_p(out.data_ptr()),
+                                                     C.c_void_p(self.order.data_ptr() + lo * 8), hi - lo, row_bytes, index,
+                                                     C.c_void_p(side.cuda_stream)), "zett_scatter_rows")
+        full.record_stream(side)
+        out.record_stream(side)
 
     def add(self, block: Block, tensors: Sequence[Optional[torch.Tensor]], ready: Optional[Callable] = None) -> None:
         if self.full is None:
             self.full = [None if t is None else torch.empty((self.total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in tensors]
+            if self.order is not None:
+                if self.order.dtype != torch.int64 or not self.order.is_contiguous():
+                    raise ValueError("order must be a contiguous int64 tensor")
+                n = int(self.order.shape[0])
+                self.out = [None if t is None else torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in tensors]
         early = ()
         first = next(t for t in tensors if t is not None)
         if ready is not None and first.is_cuda and len(tensors) == 3 and tensors[1] is not None:
@@ -219,13 +267,17 @@ class RowGather:
             ready("in", self._side)
             with torch.cuda.stream(self._side):
                 for i in (0, 2):
-                    self._exchange(block, tensors[i], self.full[i])
+                    works = self._exchange(block, tensors[i], self.full[i])
                     tensors[i].record_stream(self._side)
+                    if self.order is not None:
+                        self._scatter(i, block, works, early=True)
             early = (0, 2)
         for i, (t, full) in enumerate(zip(tensors, self.full)):
             if t is None or i in early:
                 continue
-            self._exchange(block, t, full)
+            works = self._exchange(block, t, full)
+            if self.order is not None:
+                self._scatter(i, block, works, early=False)
 
     def finish(self, n_rows: int, timed: bool = False):
         ev0 = ev1 = None
@@ -236,6 +288,11 @@ class RowGather:
             w.wait()           # the compute stream waits for the collective; the host does not block (nccl)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+        if self._late is not None:
+            torch.cuda.current_stream().wait_stream(self._late)
+        for i, lo, hi in self._pending:              # (CPU tensors: the exchange above has completed)
+            self.out[i].index_copy_(0, self.order[lo:hi], self.full[i][lo:hi])
+        self._pending.clear()
         if ev1 is not None:
             ev1.record()
             ev1.synchronize()
@@ -243,6 +300,8 @@ class RowGather:
         self._works.clear()
         self._keep.clear()
         assert self.full is not None
+        if self.order is not None:
+            return tuple(self.out)
         return tuple(None if f is None else f[:n_rows] for f in self.full)
 
 
@@ -270,8 +329,8 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
     ``ready=engine.stream_wait_output``.  Without an initialised process group this is just ``predict(target_surface_forms)``.
 
     `order` (``affinity_order(...)``: int64 [n] on the device) — shard the rows in THAT order instead of vocabulary order: rank r
-    computes rows order[lo:hi] of every block, and the gathered matrices are put back into vocabulary order by one indexed copy
-    per output behind the exchange.  Same rows, same bits.
+    computes rows order[lo:hi] of every block, and every gathered block is scattered to its vocabulary rows behind ITS exchange, on a
+    side stream (RowGather, zett_scatter_rows).  Same rows, same bits.
 
     `prepare(rows, stream)` (``engine.prepare``: zett_forward_prepare) — with more than one block per rank, the plan of block
     k + 1 is enqueued as soon as block k's forward is, on the engine's own stream behind a side stream that holds nothing but
@@ -285,12 +344,13 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
     blocks = plan_blocks(n, world, rank, chunks)
     if not blocks:
         return predict(target_surface_forms)
-    gather = RowGather(blocks, group, mode)
     if order is not None:
         if order.shape[0] != n:
             raise ValueError("order must hold one entry per row")
+        order = order.to(torch.int64).contiguous()
         vocabulary_order = target_surface_forms
         target_surface_forms = vocabulary_order.index_select(0, order)
+    gather = RowGather(blocks, group, mode, order=order)
 
     def rows_of(b):
         # (more ranks than rows in the block: compute one dummy row, contribute none)
@@ -308,7 +368,4 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
         if b.hi - b.lo == 0:
             outs = tuple(None if t is None else t[:0] for t in outs)
         gather.add(b, outs, ready)
-    full = gather.finish(n)
-    if order is None:
-        return full
-    return tuple(None if t is None else torch.empty_like(t).index_copy_(0, order, t) for t in full)
+    return gather.finish(n)
