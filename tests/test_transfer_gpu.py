@@ -147,3 +147,43 @@ def test_transfer_cli_two_processes_match_one(tmp_path):
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert torch.equal(load_file(os.path.join(one, "bias.safetensors"))["bias"], load_file(os.path.join(two, "bias.safetensors"))["bias"])
+
+
+def test_transfer_cli_tears_down_on_a_rank_failure(tmp_path):
+    """A rank that dies in the middle of the sharded prediction must not leave the job hanging: under torchrun the CLI's other
+    rank sits in a collective with a two-hour timeout (zett_amd/transfer.py init_distributed), so the launcher — which kills
+    the surviving workers when one fails — is what ends it.  Rank 1 raises inside predict_vocabulary (injected here through a
+    wrapper script, no hook in the product); the command must exit non-zero within the time a normal run takes, write no
+    model, and leave no worker behind.  Reference: the device sharding of scripts/transfer.py:90-91 (one process there)."""
+    import subprocess
+    import sys
+    import time
+
+    dirs, *_ = _make_checkpoints(tmp_path, "pt")
+    out = str(tmp_path / "out_fail")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    wrapper = tmp_path / "transfer_with_a_failing_rank.py"
+    wrapper.write_text(f"""
+import os, sys
+sys.path.insert(0, {repo!r})
+import zett_amd.transfer as T
+real = T.predict_vocabulary
+def failing(*a, **k):
+    if int(os.environ.get("RANK", "0")) == 1:
+        raise RuntimeError("injected failure on rank 1")
+    return real(*a, **k)
+T.predict_vocabulary = failing
+T.main()
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 2:
+        env["ZETT_ONE_DEVICE_TEST"] = "1"
+    t0 = time.time()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29720 + os.getpid() % 100), str(wrapper)] + _cli_args(dirs, out),
+                         cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    elapsed = time.time() - t0
+    assert res.returncode != 0, "a failed rank must fail the command"
+    assert "injected failure on rank 1" in res.stderr
+    assert elapsed < 300, f"the surviving rank kept the job alive for {elapsed:.0f} s"
+    assert not os.path.exists(os.path.join(out, "model.safetensors"))

@@ -7,7 +7,7 @@ tag=${1:-rX}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-bench="python $GRAFT_REPO_ROOT/bench.py --no-live-traffic"      # (the PMC passes below are the profile set; the default line measures its own)
+bench="python $GRAFT_REPO_ROOT/bench.py --no-live-traffic --no-side-configs"      # (the PMC passes below are the profile set; the default line measures its own traffic and carries the side lines)
 python $GRAFT_REPO_ROOT/bench.py 2>/dev/null | tail -1 > $out/bench_default.json
 for w in xlmr_gpt2 tinyllama_neox mistral_neox llama3_256k; do $bench --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_$w.json; done
 $bench --precision f32 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_default_f32.json
