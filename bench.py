@@ -394,6 +394,66 @@ def api_path(workload, precision, device, reps=3):
     return res
 
 
+def train_step_line(workload, rows, precision, device, steps=2, warmup=1):
+    """Training-time use of the path (reference call sites train.py:1007-1013, 1191-1197): one step = the
+    differentiable forward of `rows` rows + the backward to every hypernetwork parameter, through zett_amd/autograd.py (packed
+    schedule, `precision` MFMA operands with fp32 accumulation, everything else fp32).  A side measurement after the timed region;
+    never `value`.  tools/train_bench.py is the same measurement as a command."""
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+
+    cfg, _, src_dtype, hist = synth.workload(workload)
+    dims = HypernetDims.from_config(cfg)
+    with torch.device(device):
+        model = ZettHypernet(ZettHypernetConfig(**cfg))
+    model.load_state_dict(device_weights(cfg, device, seed=0))
+    model = model.to(device)
+    model.requires_grad_(True).train()
+    model.train_packed = True
+    model.train_precision = precision
+    g = torch.Generator(device=device)
+    g.manual_seed(1)
+    src = (0.02 * torch.randn((dims.original_vocab_size, dims.n_in_embd), device=device, generator=g)).to(getattr(torch, src_dtype))
+    ids = torch.from_numpy(synth.make_surface_forms(cfg, rows, seed=0, hist=hist)).to(device)
+    lang = torch.tensor(3) if dims.embed_lang else None
+    cot = None
+    t_f = t_b = 0.0
+
+    def step():
+        nonlocal cot, t_f, t_b
+        model.zero_grad(set_to_none=True)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        out = model(ids, source_embeddings=src, lang_index=lang)
+        e1.record()
+        if cot is None:
+            cot = [None if o is None else torch.randn(o.shape, device=device, generator=g) for o in out]
+        sum((o * c).sum() for o, c in zip(out, cot) if o is not None).backward()
+        e2.record()
+        torch.cuda.synchronize()
+        t_f += e0.elapsed_time(e1)
+        t_b += e1.elapsed_time(e2)
+
+    torch.cuda.reset_peak_memory_stats(device)
+    for _ in range(warmup):
+        step()
+    t_f = t_b = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    finite = all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for n, p in model.named_parameters() if n != "model.embeddings.word_embeddings.weight")
+    res = {"workload": workload, "rows": rows, "dtype": precision, "schedule": "packed (levers 1-3)", "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "forward_ms": t_f / steps, "backward_ms": t_b / steps, "rows_per_s": rows * steps / dt,
+           "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9, "all_parameter_gradients_finite": finite,
+           "what": "differentiable forward + backward to every hypernetwork parameter (zett_amd/autograd.py), HIP events around the two halves"}
+    model._drop_engines()
+    del model, src, ids, cot
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -794,6 +854,10 @@ def main():
                 result["api_path"].append(r)
             except Exception as e:
                 result["api_path"].append({"workload": name, "error": f"{type(e).__name__}: {e}"})
+        try:          # N4, the training use of the path: 16 384 rows of the headline shape, bf16 contractions (the arithmetic to train in)
+            result["train_step"] = train_step_line(args.workload, 16384, "bf16", device)
+        except Exception as e:
+            result["train_step"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not exchange and not args.no_live_traffic and not args.rows:
         # roofline.traffic measured HERE: same build, same box, same workload, right after the timed region
         live, info = measure_traffic_live(args)
