@@ -125,6 +125,19 @@ def test_gemm_tail_split_bit_identical(precision, name, rows):
         for mode in (1, 2, 3):
             eng.set_option("gemm_tail_split", mode)
             assert _eq(_run(eng, ids, src, lang), base), f"gemm_tail_split {mode}, ln_fold {fold}"
+    # the pair lever on (layer 0's attention-output epilogue then fetches INDEXED residual rows: `res_index` in the HALF tile's LN16 /
+    # F32_LN epilogues): ids folded into a small range so that (id, position) pairs repeat
+    folded = np.where(ids == cfg["pad_token_id"], ids, 3 + ids % 257).astype(np.int32)
+    assert cfg["pad_token_id"] < 3          # (3 + id % 257 never collides with the pad id of these workloads)
+    eng.set_option("ln_fold", 1)
+    eng.set_option("gemm_tail_split", 0)
+    base = _run(eng, folded, src, lang)
+    st = eng.stats()
+    if rows >= 700:
+        assert st["distinct_positions"] < st["packed_tokens"], st           # the lever is taken
+    for mode in (2, 3):
+        eng.set_option("gemm_tail_split", mode)
+        assert _eq(_run(eng, folded, src, lang), base), f"pair lever, gemm_tail_split {mode}"
     with pytest.raises(ValueError):
         eng.set_option("gemm_tail_split", 4)
 
