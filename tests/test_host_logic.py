@@ -497,3 +497,52 @@ def test_training_primitives_refuse_bad_arguments_before_touching_the_device():
     # and nothing to do is not an error
     assert lib.zett_op_gemm_f32(a, 32, a, 32, 0, 4, 32, null, 0, null, 0, a, 4, null) == 0
     assert lib.zett_op_gelu_fwd_f32(a, a, 0, 1, null) == 0
+
+
+# ---- round 5: host pieces of the NUL-separated retokenizer input and of the row partition --------------------------
+def test_flatten_tokens_equals_the_per_token_walk():
+    """DeviceRetokenizer.flatten_tokens (one join / encode + numpy offsets) == encoding every token by itself, including empty
+    tokens, two-byte characters, a token that holds the separator itself (falls back to the walk) and the empty list."""
+    import numpy as np
+
+    from zett_amd.surface_forms import DeviceRetokenizer as D
+
+    def walk(tokens):
+        enc = [t.encode("utf-8") for t in tokens]
+        off = np.zeros(len(enc) + 1, dtype=np.int32)
+        if enc:
+            np.cumsum([len(e) for e in enc], out=off[1:])
+        return np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8), off
+
+    for tokens in (["Ġhello", "", "wörld", "a", "", ""], ["a"], [""], [], ["", ""], ["x\0y", "z"], ["ĠĊč"] * 1000):
+        text, off = D.flatten_tokens(tokens)
+        want_text, want_off = walk(tokens)
+        assert off.dtype == np.int32 and np.array_equal(off, want_off), tokens[:3]
+        assert np.array_equal(text[:off[-1]], want_text[:want_off[-1]])
+
+
+def test_partition_specification_properties():
+    """oracle/partition_ref.py (the specification zett_partition_rows is held to on the GPU): a permutation with the requested
+    group sizes, deterministic, fewer distinct ids per rank than contiguous shards and balanced packed positions — and
+    rank_row_counts hands it exactly the rows plan_blocks gives each rank."""
+    import numpy as np
+
+    from oracle import partition_ref
+    from zett_amd import synth
+    from zett_amd.sharding import plan_blocks, rank_row_counts
+    cfg, _, _, hist = synth.workload("mistral_gpt2_32k")
+    rows = 12000
+    ids = synth.make_surface_forms(cfg, rows, seed=3, hist=hist, n_special=2)
+    pad, n_ids = cfg["pad_token_id"], cfg["original_vocab_size"] + cfg["hn_n_extra_tokens"]
+    for world, chunks in ((8, 1), (4, 2), (3, 1)):
+        caps = rank_row_counts(rows, world, chunks, min_rows_per_shard=512)
+        assert sum(caps) == rows and caps == [sum(b.hi - b.lo for b in plan_blocks(rows, world, r, chunks, 512)) for r in range(world)]
+        perm = partition_ref.partition_rows(ids, pad, n_ids, caps)
+        assert sorted(perm.tolist()) == list(range(rows))
+        assert np.array_equal(perm, partition_ref.partition_rows(ids, pad, n_ids, caps))
+        off = np.concatenate([[0], np.cumsum(caps)])
+        aff = partition_ref.shard_statistics(ids, pad, [perm[off[r]:off[r + 1]] for r in range(world)])
+        con = partition_ref.shard_statistics(ids, pad, [np.arange(off[r], off[r + 1]) for r in range(world)])
+        assert [s[0] for s in aff] == caps
+        assert sum(s[2] for s in aff) < 0.93 * sum(s[2] for s in con)                 # fewer table rows in all
+        assert max(s[1] for s in aff) < 1.05 * (sum(s[1] for s in aff) / world)       # positions near the mean

@@ -49,7 +49,6 @@ template <bool LDS_HAVE>
 __global__ __launch_bounds__(PART_THREADS) void partition_rows_kernel(const int32_t* __restrict__ sfm, int64_t n_rows, int seq, int pad,
                                                                      int n_ids, int world, const int32_t* __restrict__ caps,
                                                                      uint32_t* __restrict__ have_global /* ceil(n_ids / 4) words, zeroed (unused with LDS_HAVE) */,
-                                                                     int8_t* __restrict__ rank_of /* unused (kept in the workspace layout) */,
                                                                      int32_t* __restrict__ perm /* [n_rows] */) {
     extern __shared__ uint32_t s_have[];                               // LDS_HAVE: the rank bytes, ceil(n_ids / 4) words
     __shared__ int s_cnt[PART_MAX_RANKS], s_cap[PART_MAX_RANKS], s_base[PART_MAX_RANKS], s_pos[PART_MAX_RANKS];

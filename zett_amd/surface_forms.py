@@ -218,6 +218,7 @@ class DeviceRetokenizer:
         _lib.check(self.lib.zett_retok_create(C.byref(m), index, C.byref(handle)), "zett_retok_create")
         self.handle = handle
         self._outstanding = []          # (text, offsets) tensors of the asynchronous calls since the last result()
+        self._staging = {}              # element width -> pinned staging buffer + the event of its last transfer (_to_device)
 
     @staticmethod
     def flatten_tokens(tokens: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
@@ -248,46 +249,21 @@ class DeviceRetokenizer:
         return (text if len(text) else np.zeros(1, dtype=np.uint8)), offsets
 
     def _to_device(self, host: np.ndarray) -> torch.Tensor:
-        """Host array -> device through a pinned staging buffer (grow-only, one per retokenizer and dtype width): the copy is a
-        DMA from page-locked memory on the current stream instead of a blocking pageable copy."""
+        """Host array -> device through a pinned staging buffer (grow-only, one per element width): the copy is a DMA from
+        page-locked memory on the current stream instead of a blocking pageable copy."""
         nbytes = host.nbytes
-        key = "_pin%d" % host.dtype.itemsize
-        pin = self.__dict__.get(key)
-        if pin is None or pin.numel() < nbytes:
-            pin = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
-            self.__dict__[key] = pin
-            self.__dict__[key + "_ev"] = None
-        ev = self.__dict__.get(key + "_ev")
-        if ev is not None:
-            ev.synchronize()                     # the previous transfer out of this buffer has left
-        flat = np.ascontiguousarray(host).view(np.uint8).reshape(-1)
-        pin[:nbytes].numpy()[:] = flat
+        slot = self._staging.setdefault(host.dtype.itemsize, {"pin": None, "event": None})
+        if slot["pin"] is None or slot["pin"].numel() < nbytes:
+            slot["pin"] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
+            slot["event"] = None
+        if slot["event"] is not None:
+            slot["event"].synchronize()          # the previous transfer out of this buffer has left
+        slot["pin"][:nbytes].numpy()[:] = np.ascontiguousarray(host).view(np.uint8).reshape(-1)
         dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        dev.copy_(pin[:nbytes], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self.__dict__[key + "_ev"] = ev
+        dev.copy_(slot["pin"][:nbytes], non_blocking=True)
+        slot["event"] = torch.cuda.Event()
+        slot["event"].record(torch.cuda.current_stream(self.device))
         return dev.view(getattr(torch, str(host.dtype))).reshape(host.shape)
-
-    def encode_joined(self, tokens: Sequence[str]):
-        """Host side of __call__: ONE ``"\\0".join(tokens).encode()`` — the NUL-separated text zett_retokenize_async takes with
-        offsets == NULL (ABI 6): the token boundaries are found on the GPU by the scan that numbers the characters, the host
-        does no per-token work (50 k tokens: ~1.2 ms for the join itself, against ~2.8 ms with the offsets made in numpy and
-        ~9 ms with a Python-level ``.encode`` per token).  Returns (d_text, None, n); falls back to encode() — text + offsets —
-        when a token holds a NUL (the reference raises KeyError for it, which the offsets path reports) or is not a str."""
-        n = len(tokens)
-        if n == 0:
-            return self.encode(tokens)
-        try:
-            blob = "\0".join(tokens).encode("utf-8")
-        except TypeError:
-            return self.encode(tokens)
-        if blob.count(b"\0") != n - 1 or len(blob) >= 2 ** 31 - 1:
-            return self.encode(tokens)
-        with torch.cuda.device(self.device):
-            d_text = self._to_device(np.frombuffer(blob or b"\0", dtype=np.uint8))
-        d_text._zett_n_text = len(blob)
-        return d_text, None, n
 
     def encode(self, tokens: Sequence[str]) -> Tuple[torch.Tensor, torch.Tensor, int]:
         """Host side of a call: UTF-8 text of the byte-level token strings + int32 offsets, copied to the device."""
