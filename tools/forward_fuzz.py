@@ -42,6 +42,9 @@ def case(seed):
                 # r4: the 16-bit residual stream (1 = f16 only, 2 = bf16 too), the attention kernel's register-resident path,
                 # the call as two concurrent half-vocabulary chunks
                 residual_lo=int(rng.choice([0, 1, 1, 2])), attention_fast=int(rng.choice([0, 1, 1])), concurrent_lanes=int(rng.choice([0, 0, 2])))
+    # r5: the 128x256 HALF tile (0 never, 1 where the launcher finds it cheaper, 2 every launch cut in the middle, 3 half tiles only).
+    # Drawn from its own generator so that the cases of the earlier campaigns stay what they were.
+    opts["gemm_tail_split"] = int(np.random.default_rng(515000 + seed).choice([0, 1, 1, 2, 3]))
     if rng.random() < 0.3:
         opts["max_chunk_tokens"] = int(rng.choice([1024, 2048, 5000]))
     if rng.random() < 0.3:
