@@ -546,3 +546,20 @@ def test_partition_specification_properties():
         assert [s[0] for s in aff] == caps
         assert sum(s[2] for s in aff) < 0.93 * sum(s[2] for s in con)                 # fewer table rows in all
         assert max(s[1] for s in aff) < 1.05 * (sum(s[1] for s in aff) / world)       # positions near the mean
+
+
+def test_host_classes_call_only_methods_they_define():
+    """No GPU here, so the classes that only run on one are at least checked statically: every ``self.<name>(`` inside
+    DeviceRetokenizer / HipEngine / RowGather names a method (or callable attribute) the class defines — an edit that drops a
+    method (it happened: ``encode_joined``) fails here instead of on the GPU box."""
+    import inspect
+    import re
+
+    from zett_amd import hypernet, sharding, surface_forms
+    for cls, extra in ((surface_forms.DeviceRetokenizer, {"lib"}), (hypernet.HipEngine, {"lib"}), (sharding.RowGather, set())):
+        src = inspect.getsource(cls)
+        called = set(re.findall(r"self\.(\w+)\(", src))
+        defined = {n for n, _ in inspect.getmembers(cls)} | extra
+        for name in called - defined:
+            # attributes set in __init__ that are called (streams, events, the ctypes library) do not count
+            assert re.search(rf"self\.{name}\s*(:[^=]+)?=", src), f"{cls.__name__}.{name} is called but never defined"

@@ -265,6 +265,26 @@ class DeviceRetokenizer:
         slot["event"].record(torch.cuda.current_stream(self.device))
         return dev.view(getattr(torch, str(host.dtype))).reshape(host.shape)
 
+    def encode_joined(self, tokens: Sequence[str]):
+        """Host side of __call__: ONE ``"\\0".join(tokens).encode()`` — the NUL-separated text zett_retokenize_async takes with
+        offsets == NULL (ABI 6): the token boundaries are found on the GPU by the scan that numbers the characters, the host
+        does no per-token work (50 k tokens: ~1.2 ms for the join itself, against ~2.8 ms with the offsets made in numpy and
+        ~9 ms with a Python-level ``.encode`` per token).  Returns (d_text, None, n); falls back to encode() — text + offsets —
+        when a token holds a NUL (the reference raises KeyError for it, which the offsets path reports) or is not a str."""
+        n = len(tokens)
+        if n == 0:
+            return self.encode(tokens)
+        try:
+            blob = "\0".join(tokens).encode("utf-8")
+        except TypeError:
+            return self.encode(tokens)
+        if blob.count(b"\0") != n - 1 or len(blob) >= 2 ** 31 - 1:
+            return self.encode(tokens)
+        with torch.cuda.device(self.device):
+            d_text = self._to_device(np.frombuffer(blob or b"\0", dtype=np.uint8))
+        d_text._zett_n_text = len(blob)
+        return d_text, None, n
+
     def encode(self, tokens: Sequence[str]) -> Tuple[torch.Tensor, torch.Tensor, int]:
         """Host side of a call: UTF-8 text of the byte-level token strings + int32 offsets, copied to the device."""
         text, offsets = self.flatten_tokens(tokens)
