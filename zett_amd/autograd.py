@@ -75,6 +75,13 @@ class Ops:
         t = getattr(x, "_zett_lo", None)
         return t if t is not None and t.dtype == self.lo_dtype and t.shape[0] == x.shape[0] and t.shape[1] >= x.shape[1] and x.shape[1] % 64 == 0 else None
 
+    def keep(self, x):
+        """What the backward needs of an activation that is ONLY an operand there (the x of a Linear: its weight gradient
+        transposes it, nothing reads its fp32 values again): in 16-bit arithmetic the 16-bit twin the producing kernel wrote —
+        the fp32 tensor is then free as soon as the forward has passed it (r5: 7.5 GB of an 88 GB step at the full vocabulary)."""
+        t = self._twin(x)
+        return x if t is None else t
+
     # ---- dense contraction: y[M,N] = act(x[M,K] . w[N,K]^T + bias) + residual
     def to_lo(self, x):
         """fp32 [R, C] -> 16-bit [R, C'] (C' = C zero-padded to the 64-wide K step): an operand of zett_op_gemm_lo"""
@@ -345,7 +352,7 @@ def _projector_fwd(ops: Ops, P, prefix, x):
     h2 = ops.gelu(z2, GELU_TANH)
     s = ops.add(h2, x)
     y, st = ops.layernorm(s, P[prefix + "ln.weight"], P[prefix + "ln.bias"], PROJECTOR_LN_EPS)
-    return y, dict(x=x, z1=z1, h1=h1, z2=z2, s=s, st=st)
+    return y, dict(x=ops.keep(x), z1=z1, h1=h1, z2=z2, s=s, st=st)
 
 
 def _projector_bwd(ops: Ops, P, G, prefix, saved, dy):
@@ -359,7 +366,7 @@ def _heads_fwd(ops: Ops, dims: HypernetDims, P, S, cls, n, device):
     """CLS -> output heads, Rescalers, bias head (modeling_hypernet.py:231-267) -> (pred_in, pred_out | None, bias)"""
     e = dims.n_embd
     h_in, S["pb_out0"] = _projector_fwd(ops, P, "output_projection.0.", cls)
-    S["h_in"] = h_in
+    S["h_in"] = ops.keep(h_in)
     pred = ops.gemm(h_in, P["output_projection.1.weight"], P["output_projection.1.bias"])
     S["pred_raw"] = pred
     pred_out = None
@@ -374,7 +381,7 @@ def _heads_fwd(ops: Ops, dims: HypernetDims, P, S, cls, n, device):
         pred_in = ops.affine_cols(pred, P["scaler.w"].reshape(-1), P["scaler.b"].reshape(-1)) if dims.rescale else pred
         if dims.separate_out:
             h_out, S["pb_out1"] = _projector_fwd(ops, P, "output_projection_out.0.", cls)
-            S["h_out"] = h_out
+            S["h_out"] = ops.keep(h_out)
             po = ops.gemm(h_out, P["output_projection_out.1.weight"], P["output_projection_out.1.bias"])
             S["pred_out_raw"] = po
             pred_out = ops.affine_cols(po, P["out_scaler.w"].reshape(-1), P["out_scaler.b"].reshape(-1)) if dims.rescale else po
@@ -612,7 +619,7 @@ def forward_packed(ops: Ops, dims: HypernetDims, ln_eps: float, P, ids: torch.Te
         last = l == dims.layers - 1
         wqkv = torch.cat([P[a + "query.weight"], P[a + "key.weight"], P[a + "value.weight"]], 0)
         bqkv = torch.cat([P[a + "query.bias"], P[a + "key.bias"], P[a + "value.bias"]], 0)
-        A = dict(z=z, wqkv=wqkv)
+        A = dict(z=ops.keep(z), wqkv=wqkv)
         if not last:
             qkv = ops.gemm(z, wqkv, bqkv)
             ctx, probs = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], key, off, n, seq, dims.heads, H, operand=True)
@@ -632,7 +639,7 @@ def forward_packed(ops: Ops, dims: HypernetDims, ln_eps: float, P, ids: torch.Te
         g = ops.gelu(u, GELU_ERF, operand=True)
         s2 = ops.gemm(g, P[p + "output.dense.weight"], P[p + "output.dense.bias"], residual=z1)
         z, st2 = ops.layernorm(s2, P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], ln_eps)
-        A.update(probs=probs, ctx=ctx, s1=s1, st1=st1, z1=z1, u=u, g=g, s2=s2, st2=st2)
+        A.update(probs=probs, ctx=ctx, s1=s1, st1=st1, z1=ops.keep(z1), u=u, g=g, s2=s2, st2=st2)
         layers.append(A)
     S["layers"] = layers
     S["seq"] = seq
@@ -653,24 +660,39 @@ def backward_packed(ops: Ops, dims: HypernetDims, P, S, src, lang, d_in, d_out, 
     off = plan["row_offset"]
     dev = ids.device
     dz, dz_res = _heads_bwd(ops, dims, P, S, G, n, d_in, d_out, d_bias), None    # [n, H]: gradient of hidden[:, 0]
+    # (r5) what a stage saved is released as soon as its backward has run, and a gradient as soon as it has been consumed: the
+    # peak of a step is then the forward's activations plus ONE stage's temporaries, not plus every stage's
+    for key in ("pb_out0", "pb_out1", "h_in", "h_out", "pred_raw", "pred_out_raw"):
+        S.pop(key, None)
+    d_in = d_out = d_bias = None
     for l in reversed(range(dims.layers)):
         p = f"model.encoder.layer.{l}."
         a = p + "attention.self."
         A = S["layers"][l]
         last = l == dims.layers - 1
         ds2, G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = ops.layernorm_bwd(dz, A["s2"], A["st2"], P[p + "output.LayerNorm.weight"], dy2=dz_res)
+        dz = dz_res = None
         dg, G[p + "output.dense.weight"], G[p + "output.dense.bias"] = ops.linear_bwd(ds2, A["g"], P[p + "output.dense.weight"])
+        del A["s2"], A["g"]
         dz1, G[p + "intermediate.dense.weight"], G[p + "intermediate.dense.bias"] = ops.linear_bwd(dg, A["z1"], P[p + "intermediate.dense.weight"], A["u"], GELU_ERF)
+        dg = None
+        del A["u"], A["z1"]
         ds1, G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = \
             ops.layernorm_bwd(dz1, A["s1"], A["st1"], P[p + "attention.output.LayerNorm.weight"], dy2=ds2)        # + the residual of the FFN
+        dz1 = ds2 = None
+        del A["s1"]
         dctx, G[p + "attention.output.dense.weight"], G[p + "attention.output.dense.bias"] = ops.linear_bwd(ds1, A["ctx"], P[p + "attention.output.dense.weight"])
+        del A["ctx"]
         wqkv = A["wqkv"]
         if not last:
             qkv = A["qkv"]
             dqkv = ops.new(T, 3 * H)
             ops.attention_bwd(dctx, qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], A["probs"], off, n, seq, dims.heads, H,
                               dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:])
+            dctx = qkv = None
+            del A["qkv"], A["probs"]
             dzin, dwqkv, dbqkv = ops.linear_bwd(dqkv, A["z"], wqkv)
+            dqkv = None
             dz, dz_res = dzin, ds1                                              # (added inside the next LayerNorm backward)
         else:
             kv, qc = A["kv"], A["qc"]
@@ -685,6 +707,8 @@ def backward_packed(ops: Ops, dims: HypernetDims, P, S, src, lang, d_in, d_out, 
         for i, name in enumerate(("query", "key", "value")):
             G[a + name + ".weight"] = dwqkv[i * H:(i + 1) * H].clone()
             G[a + name + ".bias"] = dbqkv[i * H:(i + 1) * H].clone()
+        dwqkv = dbqkv = wqkv = None
+        A.clear()                                                               # this layer's activations are not needed again
     demb, G["model.embeddings.LayerNorm.weight"], G["model.embeddings.LayerNorm.bias"] = \
         ops.layernorm_bwd(dz, S["emb"], S["emb_st"], P["model.embeddings.LayerNorm.weight"], dy2=dz_res)
     per_pos = torch.zeros((Lp, H), dtype=torch.float32, device=dev)
