@@ -246,6 +246,10 @@ class RowGather:
             _lib.check(_lib.load().zett_scatter_rows(C.c_void_p(full.data_ptr() + lo * row_bytes), C.c_void_p(out.data_ptr()),
                                                      C.c_void_p(self.order.data_ptr() + lo * 8), hi - lo, row_bytes, index,
                                                      C.c_void_p(side.cuda_stream)), "zett_scatter_rows")
+        # finish() must not wait for these again: the compute stream gets them through wait_stream(side), and a SECOND wait() on a
+        # gloo send / recv work blocks for ever (its completion has been consumed: the two-ranks-on-one-device bench hung there)
+        done = {id(w) for w in works}
+        self._works = [w for w in self._works if id(w) not in done]
         full.record_stream(side)
         out.record_stream(side)
 
