@@ -33,8 +33,8 @@ def _torchrun(script_args, port, timeout=900):
 
 @needs_two_gpus
 @pytest.mark.parametrize("extra", [[], ["--serial-allgather"], ["--chunks", "3"], ["--gather-mode", "fanout"], ["--serial-allgather", "--gather-mode", "fanout"],
-                                   ["--serial-allgather", "--no-early-gather"]],
-                         ids=["two-blocks", "serial", "three-blocks", "fanout", "serial-fanout", "serial-late"])
+                                   ["--serial-allgather", "--no-early-gather"], ["--partition", "affinity", "--gather-mode", "fanout"]],
+                         ids=["two-blocks", "serial", "three-blocks", "fanout", "serial-fanout", "serial-late", "affinity-fanout"])
 def test_bench_two_gpus_nccl(extra):
     out = _torchrun([os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "tinyllama_neox",
                      "--rows", "30001", "--no-cpu-baseline"] + extra, 29541)
@@ -71,6 +71,20 @@ for chunks in (1, 2, 4):
     for mode in ("allgather", "fanout"):
         for ready in (None, eng.stream_wait_output):      # exchange behind the whole forward / pred_in and bias behind their own completion point
             full = predict_sharded(predict, ids, chunks=chunks, mode=mode, ready=ready)
+            torch.cuda.synchronize()
+            ok = ok and all((a is None and b is None) or torch.equal(a, b) for a, b in zip(full, single))
+# r5: the rows sharded in the id-affinity order (zett_partition_rows: every rank computes the same order, no communication) and
+# scattered back behind each block's exchange — over RCCL, both transports; the orders of all ranks must be identical
+from zett_amd.sharding import affinity_order
+n_ids = cfg["original_vocab_size"] + cfg["hn_n_extra_tokens"]
+for chunks in (1, 2):
+    order = affinity_order(ids, world, cfg["pad_token_id"], n_ids, chunks=chunks)
+    same = [torch.empty_like(order) for _ in range(world)]
+    dist.all_gather(same, order)
+    ok = ok and all(torch.equal(o, order) for o in same) and sorted(order.tolist()) == list(range(ids.shape[0]))
+    for mode in ("allgather", "fanout"):
+        for ready in (None, eng.stream_wait_output):
+            full = predict_sharded(predict, ids, chunks=chunks, mode=mode, ready=ready, order=order)
             torch.cuda.synchronize()
             ok = ok and all((a is None and b is None) or torch.equal(a, b) for a, b in zip(full, single))
 flag = torch.tensor([1 if ok else 0], device=dev)
