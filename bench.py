@@ -454,6 +454,146 @@ def train_step_line(workload, rows, precision, device, steps=2, warmup=1):
     return res
 
 
+LINE_LIMIT = 6000          # bytes of the ONE stdout line (the driver keeps an ~8 KB tail of stdout; round 5's 22 KB line was cut)
+SIDE_FILE = "bench_side.json"
+
+CLASS_CODE = (("LayerNorm-fold producer on the 16-bit residual stream", "ln16_producer"), ("LayerNorm-fold producer of an output head", "head_ln_producer"),
+              ("LayerNorm-fold producer", "ln_producer"), ("LayerNorm-fold consumer", "ln_consumer"), ("output head", "head_rescaler"),
+              ("fp32 residual, fp32 out", "f32_residual"), ("fp32 + 16-bit out", "f32_and_16"), ("16-bit out", "out16"), ("fp32 out", "out32"))
+
+
+def _short_class(name):
+    code = next((c for prefix, c in CLASS_CODE if name.startswith(prefix)), name[:24])
+    return code + ("+tanh" if "tanh-GELU" in name else "+erf" if "erf-GELU" in name else "")
+
+
+def _r(x, sig=5):
+    """Floats to `sig` significant digits (the line is a record, not an archive: the full floats are in bench_side.json)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{sig}g}")
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d}
+
+
+def _cached_cpu_baselines():
+    """Per-config CPU baselines (a >= 1 024-row slice per config) are measured once per round with
+    tools/cpu_baselines.py on a GPU box's host and cached in profiles/cpu_baselines.json, labelled with box and cores;
+    only the headline's is re-timed inside every bench run."""
+    try:
+        return json.load(open(os.path.join(REPO, "profiles", "cpu_baselines.json")))
+    except Exception:
+        return {}
+
+
+def compact_line(result, limit=LINE_LIMIT):
+    """The ONE stdout line from the full result object: every field the contract names, `roofline` and `cpu_baseline` whole in
+    their contract fields, and a few numbers per side measurement.  Prose (`what`, `note`, methods), per-class tables of the side
+    configs and full-precision floats go to bench_side.json only.  If the line is still over `limit` bytes, the optional parts are
+    dropped, least important first; the contract fields are never dropped."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: _r(result.get(k)) for k in top}
+    cfg = result.get("config") or {}
+    out["config"] = {k: (v if not isinstance(v, str) else v[:200]) for k, v in cfg.items() if k in
+                     ("workload", "rows", "rows_per_gpu", "partition", "parallelism", "precision", "packed_tokens_rank0", "distinct_source_ids_rank0",
+                      "distinct_id_position_pairs_rank0", "hn_tokenizer") and v is not None}
+    if isinstance(out["config"].get("parallelism"), str):
+        out["config"]["parallelism"] = out["config"]["parallelism"].split(" (")[0]
+    rf = result.get("roofline") or {}
+    out["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch",
+                                  "launches_per_step", "gemm_ms_per_step", "executed_tflop_per_step"))
+    out["roofline"]["kernel"] = "zett::gemm4d_tn_kernel (+gemm8r/384x256/128x128 tiles): all GEMM launches, FLOP-weighted"
+    ts = rf.get("traffic_source") or {}
+    out["roofline"]["traffic_live"] = bool(ts.get("live")) if ts else None
+    if ts.get("stale"):
+        out["roofline"]["traffic_stale"] = True
+    out["roofline"]["by_class"] = [{"class": _short_class(c["class"]), "n": _r(c.get("launches_per_step")), "ms": _r(c.get("ms_per_step"), 4),
+                                    "frac": _r(c.get("frac"), 3)} for c in rf.get("by_class") or []]
+    cb = result.get("cpu_baseline")
+    out["cpu_baseline"] = None if not cb else dict(_pick(cb, ("value", "unit", "cores", "kind", "levers_value")), sample=str(cb.get("sample", ""))[:160])
+    for k in ("parity_vs_cpu_port_rel_l2", "ms_per_step_uninstrumented", "value_uninstrumented", "range_flags", "as_written_tflops", "as_written_gflop_per_row",
+              "exchange_exposed_ms_per_step"):
+        if result.get(k) is not None:
+            out[k] = _r(result[k])
+    ex = result.get("exchange")
+    if ex:
+        out["exchange"] = _pick(ex, ("mode", "backend", "one_rank_group", "early_start_of_pred_in_and_bias", "bytes_received_per_rank_per_step"))
+        out["exchange"]["GPU_MAX_HW_QUEUES"] = os.environ.get("GPU_MAX_HW_QUEUES")
+    if result.get("alt_precision"):
+        out["alt_precision"] = _pick(result["alt_precision"], ("dtype", "value", "ms_per_step", "roofline_frac"))
+    if result.get("f32_mode"):
+        out["f32_mode"] = _pick(result["f32_mode"], ("dtype", "value", "ms_per_step", "roofline_frac", "peak"))
+    cached = _cached_cpu_baselines()
+    if result.get("configs") is not None:
+        out["configs"] = []
+        for c in result["configs"]:
+            if "error" in c:
+                out["configs"].append({"workload": c.get("workload"), "error": str(c["error"])[:120]})
+                continue
+            r = c.get("roofline") or {}
+            name = str(c.get("workload", "")).split(" (")[0]
+            e = {"workload": name, "rows": c.get("rows"), "ms_per_step": _r(c.get("ms_per_step"), 4), "frac": _r(r.get("frac"), 3), "hbm_frac": _r(r.get("hbm_frac"), 3),
+                 "gemm_ms": _r(r.get("gemm_ms_per_step"), 4)}
+            if c.get("partition"):
+                e["shard"] = f"rank 0 of 8, {c['partition']}"
+                if c.get("unpermute_ms") is not None:
+                    e["unpermute_ms"] = _r(c["unpermute_ms"], 3)
+            elif name in cached.get("configs", {}):
+                cc = cached["configs"][name]
+                e["cpu_baseline"] = {"value": _r(cc.get("value"), 4), "cores": cc.get("cores"), "kind": cc.get("kind"), "cached": cached.get("box", "profiles/cpu_baselines.json")[:60]}
+            out["configs"].append(e)
+    if result.get("api_path") is not None:
+        out["api_path"] = [({"workload": a.get("workload"), "error": str(a["error"])[:120]} if "error" in a else
+                            dict(_pick(a, ("workload", "ms", "ms_per_step_engine", "over_engine_step", "device_matrix_ms")))) for a in result["api_path"]]
+    if result.get("train_step") is not None:
+        t = result["train_step"]
+        out["train_step"] = {"error": str(t["error"])[:120]} if "error" in t else _pick(t, ("rows", "dtype", "ms_per_step", "forward_ms", "backward_ms", "peak_memory_gb"))
+    out["full"] = SIDE_FILE
+    for drop in (None, ("roofline", "by_class"), ("train_step",), ("api_path",), ("f32_mode",), ("alt_precision",), ("configs",), ("config", "hn_tokenizer"),
+                 ("config", "precision"), ("cpu_baseline", "sample")):
+        if drop:
+            node = out
+            for k in drop[:-1]:
+                node = node.get(k) or {}
+            node.pop(drop[-1], None)
+        line = json.dumps(out, separators=(",", ":"))
+        if len(line.encode()) <= limit:
+            break
+    return line
+
+
+def emit(result):
+    """Full object -> bench_side.json (stderr too with ZETT_BENCH_ECHO_FULL=1), compact line -> stdout (the only stdout line)."""
+    full = json.dumps(result)
+    try:
+        with open(os.path.join(os.environ.get("ZETT_BENCH_SIDE_DIR", REPO), SIDE_FILE), "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        print(f"bench.py: could not write {SIDE_FILE}: {e}", file=sys.stderr)
+    if os.environ.get("ZETT_BENCH_ECHO_FULL") == "1":
+        print(full, file=sys.stderr, flush=True)
+    print(compact_line(result), flush=True)
+
+
+def self_launch(gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` (one rank per GPU; rank 0 prints the line)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print("bench.py: --gpus %d without a launcher: re-executing under torch.distributed.run (port %d)" % (gpus, port), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -500,8 +640,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            self_launch(args.gpus)          # (does not return)
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     # ZETT_BENCH_ONE_DEVICE=1 (test hook): every rank uses cuda:0 and the collectives go through gloo, so
     # that the N > 1 control flow can be exercised on a 1-GPU box; never set for a measurement.
@@ -878,7 +1018,7 @@ def main():
     else:
         result["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     if exchange:
         dist.destroy_process_group()
 

@@ -513,6 +513,11 @@ def test_inference_after_an_optimizer_step_uses_the_new_weights():
         with torch.no_grad():
             shifted = model(ids, source_embeddings=src, lang_index=lang)
         assert float((shifted[2] - after[2]).mean()) == pytest.approx(1.0, abs=1e-4)
+        # a REPLACED Parameter object (module.bias = nn.Parameter(t): parametrize / PEFT-style swaps) is seen as well
+        model.bias_projection.bias = torch.nn.Parameter(p.detach().clone() + 2.0)
+        with torch.no_grad():
+            swapped = model(ids, source_embeddings=src, lang_index=lang)
+        assert float((swapped[2] - shifted[2]).mean()) == pytest.approx(2.0, abs=1e-4)
 
 
 def test_training_forward_validates_its_indices_like_the_inference_path():

@@ -14,12 +14,17 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("extra", [[], ["--serial-allgather"], ["--gather-mode", "fanout"], ["--serial-allgather", "--no-early-gather"],
                                    ["--partition", "affinity"], ["--partition", "affinity", "--serial-allgather", "--gather-mode", "fanout"]],
-                         ids=["two-blocks", "serial", "fanout", "serial-late", "affinity", "affinity-serial-fanout"])
+                         ids=["two-blocks-self-launched", "serial", "fanout", "serial-late", "affinity", "affinity-serial-fanout"])
 def test_two_ranks_on_one_device(extra):
     env = dict(os.environ, ZETT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--workload", "tiny", "--rows", "20001", "--no-cpu-baseline"] + extra
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533"]
+    if not extra:
+        # the form the driver uses for every N: `python bench.py --gpus N ...` with no launcher around it — bench.py re-executes
+        # itself under torch.distributed.run (bench.self_launch)
+        launcher = [sys.executable]
+        env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    cmd = launcher + [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                      "--workload", "tiny", "--rows", "20001", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -32,3 +37,31 @@ def test_two_ranks_on_one_device(extra):
     assert d["exchange"]["mode"] == ("fanout" if "fanout" in extra else "allgather")
     assert d["exchange"]["early_start_of_pred_in_and_bias"] == ("--no-early-gather" not in extra)
     assert d["exchange_exposed_ms_per_step"] is not None and 0 <= d["exchange_exposed_ms_per_step"] < d["ms_per_step"]
+    assert len(lines[0].encode()) < 6000
+
+
+def test_default_line_is_short_and_complete(tmp_path):
+    """The DEFAULT command (what the driver runs, with fewer steps): ONE `{` line on stdout, under 6 000 bytes (the driver keeps an
+    ~8 KB tail of stdout: round 5's 22 KB line was cut and its record did not parse), carrying the contract fields, `roofline`
+    and `cpu_baseline`, the compact side measurements — and the full objects in bench_side.json."""
+    env = dict(os.environ, ZETT_BENCH_SIDE_DIR=str(tmp_path))
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-budget-s", "8"], cwd=REPO, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-3000:]
+    assert len(lines[0].encode()) < 6000
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["steps"] == 2 and d["n_gpus"] == 1 and d["config"]["workload"].startswith("mistral_gpt2_32k")
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and 0.3 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "traffic" in rf and rf["gemm_ms_per_step"] <= d["ms_per_step"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["parity_vs_cpu_port_rel_l2"] < 2.5e-3
+    assert [c["workload"] for c in d["configs"]] == ["xlmr_gpt2", "tinyllama_neox", "mistral_gpt2_32k", "mistral_gpt2_32k"] and all("error" not in c for c in d["configs"])
+    assert len(d["api_path"]) == 2 and all("error" not in a for a in d["api_path"]) and "error" not in d["train_step"]
+    full = json.loads((tmp_path / "bench_side.json").read_text())
+    assert abs(full["value"] / d["value"] - 1) < 1e-3 and "by_class" in full["configs"][0]["roofline"]

@@ -563,3 +563,29 @@ def test_host_classes_call_only_methods_they_define():
         for name in called - defined:
             # attributes set in __init__ that are called (streams, events, the ctypes library) do not count
             assert re.search(rf"self\.{name}\s*(:[^=]+)?=", src), f"{cls.__name__}.{name} is called but never defined"
+
+
+def test_weights_stamp_sees_replaced_and_modified_parameters():
+    """The engine cache key (ZettHypernet._weights_stamp) is computed from the parameters the modules hold NOW: an in-place write
+    through the parameter, a new storage (p.data = t) and a REPLACED Parameter object (module.weight = nn.Parameter(t), the
+    parametrize / PEFT pattern) all change it; nothing else does."""
+    from zett_amd.config import ZettHypernetConfig
+    from zett_amd.hypernet import ZettHypernet
+    cfg, _, _, _ = synth.workload("tiny")
+    model = ZettHypernet(ZettHypernetConfig(**cfg))
+    s0 = model._weights_stamp()
+    assert model._weights_stamp() == s0
+    with torch.no_grad():
+        model.bias_projection.bias.add_(1.0)
+    s1 = model._weights_stamp()
+    assert s1 != s0 and model._weights_stamp() == s1
+    model.bias_projection.bias.data = model.bias_projection.bias.data.clone()
+    s2 = model._weights_stamp()
+    assert s2 != s1
+    old = model.scaler.w
+    model.scaler.w = torch.nn.Parameter(old.detach().clone() * 2)          # a new Parameter OBJECT in the same slot
+    s3 = model._weights_stamp()
+    assert s3 != s2 and model._weights_stamp() == s3
+    lin = model.get_submodule("output_projection.1")
+    lin.register_parameter("weight", torch.nn.Parameter(lin.weight.detach().clone()))
+    assert model._weights_stamp() != s3

@@ -34,22 +34,31 @@ def _torchrun(script_args, port, timeout=900):
 @needs_two_gpus
 @pytest.mark.parametrize("extra", [[], ["--serial-allgather"], ["--chunks", "3"], ["--gather-mode", "fanout"], ["--serial-allgather", "--gather-mode", "fanout"],
                                    ["--serial-allgather", "--no-early-gather"], ["--partition", "affinity", "--gather-mode", "fanout"]],
-                         ids=["two-blocks", "serial", "three-blocks", "fanout", "serial-fanout", "serial-late", "affinity-fanout"])
+                         ids=["two-blocks-self-launched", "serial", "three-blocks", "fanout", "serial-fanout", "serial-late", "affinity-fanout"])
 def test_bench_two_gpus_nccl(extra):
-    out = _torchrun([os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "tinyllama_neox",
-                     "--rows", "30001", "--no-cpu-baseline"] + extra, 29541)
+    bench_args = [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "tinyllama_neox",
+                  "--rows", "30001", "--no-cpu-baseline"] + extra
+    if not extra:
+        # the driver's form: `python bench.py --gpus N` with no launcher — bench.py re-executes itself under torch.distributed.run
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ZETT_BENCH_ONE_DEVICE")}
+        out = subprocess.run([sys.executable] + bench_args, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    else:
+        out = _torchrun(bench_args, 29541)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rows"] == 30001 and d["value"] > 0 and "TEST HOOK" not in d["data"]
     assert d["exchange"]["mode"] == ("fanout" if "fanout" in extra else "allgather") and d["exchange_exposed_ms_per_step"] is not None
+    assert d["exchange"]["GPU_MAX_HW_QUEUES"] == "8" and len(lines[0].encode()) < 6000
 
 
 _WORKER = r"""
 import os, sys, json
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {repo!r})
+import zett_amd
+zett_amd.configure_hw_queues()          # before the first CUDA call: the exchange overlaps the forward only on its own hardware queue
 from bench import device_weights
 from zett_amd import synth
 from zett_amd.dims import HypernetDims

@@ -52,6 +52,28 @@ def test_kernel_equals_its_specification(name, rows, world):
         np.testing.assert_array_equal(_partition(ids, pad, n_ids, caps2), partition_ref.partition_rows(ids, pad, n_ids, caps2))
 
 
+@pytest.mark.parametrize("seq,n_ids", [(16, 3000), (16, 200000), (70, 3000), (70, 200000)], ids=["seq16-lds", "seq16-global", "seq70-lds", "seq70-global"])
+def test_long_rows_equal_the_specification(seq, n_ids):
+    """Rows wider than the eight ids the kernel keeps in registers (PART_REG_IDS): the tail is read from memory un-prefetched, only a
+    row's first 63 usable ids count in its score and its packed-position term, every id is marked.  Both homes of the rank bytes
+    (LDS: n_ids <= 150 KiB; global memory beyond), rows with more than 63 usable ids included (seq 70)."""
+    rng = np.random.default_rng(seq * 7 + n_ids)
+    rows, pad, world = 5000, 1, 8
+    ids = rng.integers(0, min(n_ids, 1500), size=(rows, seq), dtype=np.int64).astype(np.int32)          # a narrow id range: rows really share ids
+    if n_ids > 1500:
+        far = rng.random((rows, seq)) < 0.2
+        ids[far] = rng.integers(1500, n_ids, size=int(far.sum()), dtype=np.int64).astype(np.int32)
+    length = rng.integers(1, seq + 1, size=rows)
+    length[rng.random(rows) < 0.1] = seq                                          # full-width rows (> 63 usable ids at seq 70)
+    ids[np.arange(seq)[None, :] >= length[:, None]] = pad
+    ids[rng.random((rows, seq)) < 0.02] = pad                                     # pads in the middle of a row
+    per = -(-rows // world)
+    caps = [max(0, min(per, rows - r * per)) for r in range(world)]
+    got = _partition(ids, pad, n_ids, caps)
+    assert sorted(got.tolist()) == list(range(rows))
+    np.testing.assert_array_equal(got, partition_ref.partition_rows(ids, pad, n_ids, caps))
+
+
 def test_partition_lowers_distinct_ids_per_rank():
     cfg, rows, _, hist = synth.workload("mistral_gpt2_32k")
     ids = synth.make_surface_forms(cfg, rows, seed=0, hist=hist)

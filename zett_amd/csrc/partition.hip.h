@@ -34,6 +34,8 @@ namespace zett {
 constexpr int PART_THREADS = 1024;
 constexpr int PART_MAX_RANKS = 8;
 
+struct PartCaps { int32_t v[PART_MAX_RANKS]; };          // the ranks' capacities travel by value in the kernel-argument segment (no copy, no host-buffer lifetime)
+
 constexpr int PART_REG_IDS = 8;          // ids of a row held in registers (and prefetched a round ahead); longer rows read the rest from memory
 
 // Barrier of the round loop: everything the rounds exchange lives in LDS, so only the LDS counter is waited for — __syncthreads()
@@ -47,7 +49,7 @@ __device__ __forceinline__ void part_barrier() {
 
 template <bool LDS_HAVE>
 __global__ __launch_bounds__(PART_THREADS) void partition_rows_kernel(const int32_t* __restrict__ sfm, int64_t n_rows, int seq, int pad,
-                                                                     int n_ids, int world, const int32_t* __restrict__ caps,
+                                                                     int n_ids, int world, const PartCaps caps,
                                                                      uint32_t* __restrict__ have_global /* ceil(n_ids / 4) words, zeroed (unused with LDS_HAVE) */,
                                                                      int32_t* __restrict__ perm /* [n_rows] */) {
     extern __shared__ uint32_t s_have[];                               // LDS_HAVE: the rank bytes, ceil(n_ids / 4) words
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(PART_THREADS) void partition_rows_kernel(const int3
     __shared__ int s_pen[PART_MAX_RANKS];                              // the rank's penalty this round (fill + lead in positions); a full rank: 1 << 28
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = world;
-    if (tid < PART_MAX_RANKS) { s_cnt[tid] = 0; s_pos[tid] = 0; s_cap[tid] = tid < P ? caps[tid] : 0; }
+    if (tid < PART_MAX_RANKS) { s_cnt[tid] = 0; s_pos[tid] = 0; s_cap[tid] = tid < P ? caps.v[tid] : 0; }
     if (LDS_HAVE)
         for (int i = tid; i < (n_ids + 3) / 4; i += PART_THREADS) s_have[i] = 0u;
     __syncthreads();

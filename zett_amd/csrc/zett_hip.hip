@@ -682,9 +682,9 @@ int zett_partition_rows(const int32_t* surface_forms, int64_t n_rows, int32_t se
     hipStream_t st = (hipStream_t)stream;
     const size_t have_bytes = ((size_t)(n_ids + 3) / 4) * 4 + 64;
     uint32_t* have = (uint32_t*)workspace;
-    int32_t* d_caps = (int32_t*)((char*)workspace + have_bytes + (((size_t)n_rows + 63) / 64) * 64);
+    PartCaps caps_arg = {};
+    for (int r = 0; r < world; ++r) caps_arg.v[r] = caps[r];
     HIP_TRY(hipMemsetAsync(have, 0, have_bytes, st));
-    HIP_TRY(hipMemcpyAsync(d_caps, caps, (size_t)world * 4, hipMemcpyHostToDevice, st));
     // the rank bytes live in LDS when the id range fits (a byte per id beside ~1 KiB of counters), else in the workspace
     const size_t lds_have = ((size_t)(n_ids + 3) / 4) * 4;
     if (lds_have <= 150 * 1024) {
@@ -694,10 +694,10 @@ int zett_partition_rows(const int32_t* surface_forms, int64_t n_rows, int32_t se
             if (device < 64) attr_set[device] = true;
         }
         hipLaunchKernelGGL(partition_rows_kernel<true>, dim3(1), dim3(PART_THREADS), lds_have, st, surface_forms, n_rows, (int)seq, (int)pad_id, (int)n_ids,
-                           (int)world, (const int32_t*)d_caps, have, perm_out);
+                           (int)world, caps_arg, have, perm_out);
     } else {
         hipLaunchKernelGGL(partition_rows_kernel<false>, dim3(1), dim3(PART_THREADS), 0, st, surface_forms, n_rows, (int)seq, (int)pad_id, (int)n_ids,
-                           (int)world, (const int32_t*)d_caps, have, perm_out);
+                           (int)world, caps_arg, have, perm_out);
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -275,7 +275,7 @@ class ZettHypernet(PreTrainedModel):
         for eng in self._engines.values():
             eng.close()
         self._engines.clear()
-        self.__dict__.pop("_param_list", None)
+        self.__dict__.pop("_param_slots", None)
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -319,17 +319,27 @@ class ZettHypernet(PreTrainedModel):
         return eng
 
     def _weights_stamp(self):
-        # (the list of Parameter objects is cached: _drop_engines — every path that can replace them: .to(), load_state_dict —
-        #  forgets it; named_parameters() walks ~40 modules and was most of this function's cost)
-        params = self.__dict__.get("_param_list")
-        if params is None:
-            params = self.__dict__["_param_list"] = list(self.parameters())
+        # What is cached is WHERE the parameters live — (owning module's _parameters dict, name) slots — not the Parameter objects:
+        # the slot is read on every call, so a parameter REPLACED after the first forward (`module.weight = nn.Parameter(t)`,
+        # register_parameter, parametrize / PEFT-style swaps) shows up as a new (id, version, pointer) and the engine is rebuilt.
+        # (named_parameters() walks ~40 modules and was most of this function's cost; the module tree itself is fixed after __init__;
+        #  _drop_engines forgets the slots anyway.)
+        slots = self.__dict__.get("_param_slots")
+        if slots is None:
+            slots = self.__dict__["_param_slots"] = [(m._parameters, n) for m in self.modules() for n, p in m._parameters.items() if p is not None]
         try:
-            return tuple([(p._version, p.data_ptr()) for p in params])
+            params = [d[n] for d, n in slots]
+            if any(p is None for p in params):
+                raise KeyError
+        except KeyError:          # a parameter was deleted or set to None: the slots are stale, walk the modules again
+            slots = self.__dict__["_param_slots"] = [(m._parameters, n) for m in self.modules() for n, p in m._parameters.items() if p is not None]
+            params = [d[n] for d, n in slots]
+        try:
+            return tuple([(id(p), p._version, p.data_ptr()) for p in params])
         except RuntimeError:
             # a model built under torch.inference_mode(): inference tensors have no version counter (and cannot be modified
-            # in place outside inference mode either); the storage pointers alone identify the upload
-            return tuple([(0, p.data_ptr()) for p in params])
+            # in place outside inference mode either); the objects and storage pointers alone identify the upload
+            return tuple([(id(p), 0, p.data_ptr()) for p in params])
 
     # ---- the forward ----------------------------------------------------------------------
     def forward(self, target_surface_forms, target_priors=None, source_embeddings=None, lang_index=None,

@@ -127,10 +127,26 @@ def affinity_order(surface_forms: torch.Tensor, world: int, pad_token_id: int, n
         if len(_ORDER_CACHE) > 16:
             _ORDER_CACHE.clear()
         _ORDER_CACHE[key] = src
-    return perm.long().index_select(0, src)
+    order = perm.long().index_select(0, src)
+    order.zett_plan = (n, world, int(chunks), int(min_rows_per_shard))          # the block plan the order was laid out for (predict_sharded checks it)
+    return order
 
 
 _ORDER_CACHE = {}
+_WARNED = set()
+
+
+def _warn_hw_queues(world: int, on_gpu: bool) -> None:
+    """One process per GPU without GPU_MAX_HW_QUEUES: the exchange and the plan-ahead then share the forward's hardware queue and
+    nothing overlaps (NOTEBOOK R4.9).  Launchers call zett_amd.configure_hw_queues() before the first CUDA call; a library user who
+    did not is told once."""
+    import os
+    import warnings
+    if world > 1 and on_gpu and "GPU_MAX_HW_QUEUES" not in os.environ and "hwq" not in _WARNED:
+        _WARNED.add("hwq")
+        warnings.warn("zett_amd: more than one rank and GPU_MAX_HW_QUEUES is unset: the row exchange will not overlap the forward "
+                      "(the HIP runtime's default 4 hardware queues are shared with RCCL). Call zett_amd.configure_hw_queues() before the "
+                      "first torch.cuda call of the process, or export GPU_MAX_HW_QUEUES=8.")
 
 GATHER_MODES = ("allgather", "fanout")
 
@@ -190,6 +206,7 @@ class RowGather:
         self._keep = []
         self._side: Optional[torch.cuda.Stream] = None
         self.exposed_ms: Optional[float] = None        # set by finish(timed=True): how long the compute stream waited for the exchange
+        _warn_hw_queues(self.world, torch.cuda.is_available() and dist.get_backend(group) == "nccl")
 
     def _exchange(self, block: Block, t: torch.Tensor, full: torch.Tensor) -> list:
         first_work = len(self._works)
@@ -243,9 +260,12 @@ class RowGather:
             for w in works:
                 w.wait()                            # the side stream waits for the collective; nobody else does yet
             index = full.device.index if full.device.index is not None else torch.cuda.current_device()
-            _lib.check(_lib.load().zett_scatter_rows(C.c_void_p(full.data_ptr() + lo * row_bytes), C.c_void_p(out.data_ptr()),
-                                                     C.c_void_p(self.order.data_ptr() + lo * 8), hi - lo, row_bytes, index,
-                                                     C.c_void_p(side.cuda_stream)), "zett_scatter_rows")
+            if row_bytes != 4 and row_bytes % 16:   # rows zett_scatter_rows does not take (a 16-bit bias, E * element size not a multiple of 16)
+                out.index_copy_(0, self.order[lo:hi], full[lo:hi])
+            else:
+                _lib.check(_lib.load().zett_scatter_rows(C.c_void_p(full.data_ptr() + lo * row_bytes), C.c_void_p(out.data_ptr()),
+                                                         C.c_void_p(self.order.data_ptr() + lo * 8), hi - lo, row_bytes, index,
+                                                         C.c_void_p(side.cuda_stream)), "zett_scatter_rows")
         # finish() must not wait for these again: the compute stream gets them through wait_stream(side), and a SECOND wait() on a
         # gloo send / recv work blocks for ever (its completion has been consumed: the two-ranks-on-one-device bench hung there)
         done = {id(w) for w in works}
@@ -323,7 +343,7 @@ def all_gather_rows(local: torch.Tensor, n_rows: int, per: int, group=None) -> t
 
 def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group=None, chunks: int = 2,
                     ready: Optional[Callable] = None, mode: str = "auto", prepare: Optional[Callable] = None,
-                    order: Optional[torch.Tensor] = None):
+                    order: Optional[torch.Tensor] = None, min_rows_per_shard: int = 4096):
     """Run `predict(rows) -> (pred_in, pred_out | None, bias)` on this rank's rows and return the full result on every
     rank.  The vocabulary is processed in `chunks` row blocks whose exchange overlaps the next block's forward (module
     docstring); chunks = 1 is the plain shard-then-gather.  `ready` (RowGather: early start of pred_in / bias) and `mode`
@@ -334,7 +354,8 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
 
     `order` (``affinity_order(...)``: int64 [n] on the device) — shard the rows in THAT order instead of vocabulary order: rank r
     computes rows order[lo:hi] of every block, and every gathered block is scattered to its vocabulary rows behind ITS exchange, on a
-    side stream (RowGather, zett_scatter_rows).  Same rows, same bits.
+    side stream (RowGather, zett_scatter_rows).  Same rows, same bits.  An order from affinity_order carries the block plan it was laid out
+    for (`chunks`, `min_rows_per_shard`): sharding it for another plan raises.
 
     `prepare(rows, stream)` (``engine.prepare``: zett_forward_prepare) — with more than one block per rank, the plan of block
     k + 1 is enqueued as soon as block k's forward is, on the engine's own stream behind a side stream that holds nothing but
@@ -345,12 +366,17 @@ def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group
         return predict(target_surface_forms)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = int(target_surface_forms.shape[0])
-    blocks = plan_blocks(n, world, rank, chunks)
+    blocks = plan_blocks(n, world, rank, chunks, min_rows_per_shard)
     if not blocks:
         return predict(target_surface_forms)
     if order is not None:
         if order.shape[0] != n:
             raise ValueError("order must hold one entry per row")
+        plan = getattr(order, "zett_plan", None)
+        if plan is not None and plan != (n, world, int(chunks), int(min_rows_per_shard)):
+            # still a permutation, so the result would be right — but the groups would straddle the shards and the affinity be lost silently
+            raise ValueError(f"order was built by affinity_order for (rows, world, chunks, min_rows_per_shard) = {plan}, "
+                             f"predict_sharded is sharding for {(n, world, int(chunks), int(min_rows_per_shard))}")
         order = order.to(torch.int64).contiguous()
         vocabulary_order = target_surface_forms
         target_surface_forms = vocabulary_order.index_select(0, order)
