@@ -37,28 +37,27 @@ def test_tiny_golden(path, precision):
     _check(case, out, precision)
 
 
-@pytest.mark.parametrize("path", REAL, ids=lambda p: p.split("/")[-1][:-4])
+# (the precisions of a case run back to back — the top-most parametrize varies fastest — so that util.seeded_inputs' one-entry cache hits)
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("path", REAL, ids=lambda p: p.split("/")[-1][:-4])
 def test_real_shape_golden(path, precision):
     case = util.load_case(path)
-    w = synth.make_weights(case["cfg"], case["seed"])
-    src = synth.make_source_embeddings(case["cfg"], case["seed"], dtype=case["src_dtype"])
+    w, src = util.seeded_inputs(case["cfg"], case["seed"], case["src_dtype"])
     model = util.hip_model(case["cfg"], w, precision)
     del w
     out = util.hip_forward(model, case["ids"], src, case["lang"])
     _check(case, out, precision)
 
 
-@pytest.mark.parametrize("path", REAL, ids=lambda p: p.split("/")[-1][:-4])
 @pytest.mark.parametrize("precision,residual_lo", [("f16", 0), ("bf16", 2)])
+@pytest.mark.parametrize("path", REAL, ids=lambda p: p.split("/")[-1][:-4])
 def test_real_shape_golden_other_residual_stream(path, precision, residual_lo):
     """The encoder's residual stream is 16-bit in f16 mode and fp32 in bf16 mode (zett_set_option "residual_lo", default 1).
     The other setting of each mode is an A/B option and must hold too: f16 on the fp32 stream inside the f16 tolerance; bf16
     on the 16-bit stream (8 significand bits per layer: why it is not the default) inside twice the bf16 rel-L2 tolerance."""
     import torch
     case = util.load_case(path)
-    w = synth.make_weights(case["cfg"], case["seed"])
-    src = synth.make_source_embeddings(case["cfg"], case["seed"], dtype=case["src_dtype"])
+    w, src = util.seeded_inputs(case["cfg"], case["seed"], case["src_dtype"])
     model = util.hip_model(case["cfg"], w, precision)
     model.engine(torch.device("cuda:0"), precision).set_option("residual_lo", residual_lo)
     out = util.hip_forward(model, case["ids"], src, case["lang"])
@@ -72,19 +71,21 @@ def test_real_shape_golden_other_residual_stream(path, precision, residual_lo):
                 assert rel < 2e-2, rel
 
 
-@pytest.mark.parametrize("path", BIG, ids=lambda p: p.split("/")[-1][:-4])
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("path", BIG, ids=lambda p: p.split("/")[-1][:-4])
 def test_big_batch_golden(path, precision):
     """640 rows per real shape: ~1 500 packed positions, so every large GEMM runs on its 256x256 tile (gemm4d for
     K >= 2048, gemm8r below and in fp32 mode) and meets outputs of the REFERENCE directly; the fixture holds the
     reference's rows for a 32-row sample."""
     case = util.load_case(path)
-    w = synth.make_weights(case["cfg"], case["seed"])
-    src = synth.make_source_embeddings(case["cfg"], case["seed"], dtype=case["src_dtype"])
+    w, src = util.seeded_inputs(case["cfg"], case["seed"], case["src_dtype"])
     model = util.hip_model(case["cfg"], w, precision)
     del w
     out = util.hip_forward(model, case["ids"], src, case["lang"])
     _check(case, [None if o is None else o[case["sample"]] for o in out], precision)
+
+
+_EDGE_ORACLE = {}
 
 
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
@@ -103,7 +104,10 @@ def test_fold_epilogues_on_edge_shapes_vs_oracle(precision, hidden, heads, rows,
     src = synth.make_source_embeddings(cfg, seed=9)
     ids = synth.make_surface_forms(cfg, rows, seed=9, hist=hist, n_special=2)
     li = 3 if lang else None
-    want = hypernet_ref.forward(w, cfg, ids, src, lang_index=li)
+    key = (hidden, heads, rows, lang, layers)
+    if key not in _EDGE_ORACLE:           # (the oracle's CPU forward is most of this test's time: once per shape, not per precision)
+        _EDGE_ORACLE[key] = hypernet_ref.forward(w, cfg, ids, src, lang_index=li)
+    want = _EDGE_ORACLE[key]
     model = util.hip_model(cfg, w, precision)
     got = util.hip_forward(model, ids, src, li)
     keep = ~util.all_pad_rows(cfg, ids)

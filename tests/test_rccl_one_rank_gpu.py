@@ -64,10 +64,15 @@ for chunks in (1, 3):
     order = order[torch.randperm(order.shape[0], device=dev)] if chunks == 3 else order          # (one rank: the partition is the identity; any order must work)
     for mode in ("allgather", "fanout"):
         for ready in (None, eng.stream_wait_output):
-            full = predict_sharded(predict, ids, chunks=chunks, ready=ready, mode=mode, order=order)
+            full = predict_sharded(predict, ids, chunks=chunks, ready=ready, mode=mode, order=order, min_rows_per_shard=1024)
             torch.cuda.synchronize()
             ok = ok and all(torch.equal(a, b) for a, b in zip(full, single))
             runs += 1
+    if chunks == 1:           # an order laid out for ANOTHER block plan is refused (the affinity would be lost silently otherwise)
+        try:
+            predict_sharded(predict, ids, chunks=2, order=order, min_rows_per_shard=1024); ok = False
+        except ValueError:
+            pass
 # the flag-word reduction of the sharded CLI (MAX per bit: RCCL refuses ReduceOp.BOR)
 ok = ok and reduce_flag_word(5, dev) == 5 and reduce_flag_word(0, dev) == 0
 try:

@@ -78,6 +78,22 @@ def assert_f16_close(got, want, what):
 CLOSE = {"f32": assert_f32_close, "bf16": assert_bf16_close, "f16": assert_f16_close}
 
 
+_INPUT_CACHE = {}
+
+
+def seeded_inputs(cfg, seed, src_dtype="float32"):
+    """(weights, source_embeddings) of synth.make_weights / make_source_embeddings, kept for the NEXT test of the same case: the
+    parametrised golden tests run a case's three precisions back to back, and generating a Llama-3-shaped checkpoint (673 M
+    parameters + a 128 256 x 8 192 source matrix from the counter-based RNG) was 20 of each such test's 25 s.  One entry only
+    (host memory: a case is up to 5 GB)."""
+    from zett_amd import synth
+    key = (json.dumps(cfg, sort_keys=True), int(seed), str(src_dtype))
+    if key not in _INPUT_CACHE:
+        _INPUT_CACHE.clear()
+        _INPUT_CACHE[key] = (synth.make_weights(cfg, seed), synth.make_source_embeddings(cfg, seed, dtype=src_dtype))
+    return _INPUT_CACHE[key]
+
+
 def hip_model(cfg, weights, precision):
     """ZettHypernet on cuda:0 with the given numpy weights (goes through the C ABI)."""
     import torch

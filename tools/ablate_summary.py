@@ -10,6 +10,8 @@ import sys
 src = sys.argv[1]
 NAMES = {"L1": "(i) the MFMAs of the K loop alone", "L2": "(ii) + fragment reads (ds_read_b128, 32 per wave and K step)", "L3": "(iii) + LDS-DMA requests (16 per wave and K step)",
          "L4": "(iv) + waits and barriers = the whole K loop", "L5": "(v) + epilogue (16-bit output) = the product kernel", "L4_zero": "(iv) on all-zero operands", "L5_zero": "(v) on all-zero operands"}
+for _k in ("L1", "L2", "L3", "L4", "L4_zero"):
+    NAMES["M32_" + _k] = NAMES[_k] + " — on v_mfma_f32_32x32x16 (64 MFMAs per K step)"
 
 
 def smi(path):
@@ -54,7 +56,7 @@ def pmc(dirname):
 
 print("| what runs | TFLOP/s | of the 2.5 PFLOP/s roof | socket power (W, median under load) | shader clock (MHz, median) | MFMA peak at that clock (TFLOP/s) | of THAT peak | SQ_VALU_MFMA_BUSY (PMC pass) |")
 print("|---|---|---|---|---|---|---|---|")
-for key in ("L1", "L2", "L3", "L4", "L5", "L4_zero", "L5_zero"):
+for key in ("L1", "M32_L1", "L2", "M32_L2", "L3", "M32_L3", "L4", "M32_L4", "L5", "L4_zero", "M32_L4_zero", "L5_zero"):
     p = os.path.join(src, key + ".json")
     if not os.path.exists(p) or not open(p).read().strip():
         continue

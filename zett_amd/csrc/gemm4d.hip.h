@@ -58,6 +58,16 @@ namespace zett {
 #define G4D_ABLATE 5
 #endif
 constexpr int G4D_ABL = G4D_ABLATE;
+// Second hook of the same harness (r6): -DG4D_MFMA32 runs the K loop of the full tile on v_mfma_f32_32x32x16_{f16,bf16}
+// (a wave's 128x128 as 4 x 4 blocks of 32x32; same LDS image, same request / wait / barrier slots, half as many MFMAs of twice the
+// work) — levels 1-4 only (no epilogue: the accumulator layout differs).  The library never defines it.
+#ifdef G4D_MFMA32
+constexpr bool G4D_M32 = true;
+static_assert(G4D_ABLATE < 5, "the 32x32x16 K loop exists for the ablation levels without an epilogue");
+#else
+constexpr bool G4D_M32 = false;
+#endif
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt = simm16[15:14]:[3:0], expcnt [6:4], lgkmcnt [11:8])
 constexpr int g4d_wait_vm(int n) { return ((n >> 4) << 14) | 0x0F70 | (n & 15); }
@@ -73,6 +83,14 @@ template <> __device__ __forceinline__ void mfma16_agpr<bf16_t>(f32x4& c, const 
 }
 template <> __device__ __forceinline__ void mfma16_agpr<f16_t>(f32x4& c, const u32x4& a, const u32x4& b) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <typename T> __device__ __forceinline__ void mfma32_agpr(f32x16& c, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mfma32_agpr<bf16_t>(f32x16& c, const u32x4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <> __device__ __forceinline__ void mfma32_agpr<f16_t>(f32x16& c, const u32x4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
 // value of lane (l ^ K) within each group of 32 lanes (ds_swizzle bit mode: no LDS access, K < 32)
@@ -210,13 +228,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                  w_voff[r], kt * GEMM_ROW_BYTES, 0, 0);
     };
 
+    constexpr bool M32 = G4D_M32 && !HALF;
     f32x4 acc[8][8];                // 128x128 (HALF: 64x128) per wave as GEO::MI x 8 tiles of 16x16
+    f32x16 acc32[4][4];             // (ablation, G4D_MFMA32: the same 128x128 as 4 x 4 tiles of 32x32; constant bounds, see G4dGeom; unused -> no registers)
+    if constexpr (M32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+    } else {
 #pragma unroll
     for (int i = 0; i < GEO::MI; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    }
 
     // fragment of a 16x16x32 MFMA: lane l holds row (l & 15), K elements (l >> 4)*8 .. +7 of a 32-wide K block,
     // i.e. 16-byte chunk kb*4 + (l >> 4) of the 128-byte row; 16-row steps leave the swizzle unchanged
@@ -231,12 +260,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             w_off[kb] = GEO::A_BYTES + (wn * 128 + l15) * GEMM_ROW_BYTES + c;
         }
     }
+    // (G4D_MFMA32) fragment of a 32x32x16 MFMA: lane l holds row (l & 31), K elements (l >> 5)*8 .. +7 of a 16-wide K block, i.e.
+    // 16-byte chunk k16*2 + (l >> 5) of the row; 32-row steps leave the swizzle unchanged.  Read q (0..7) of a 64-wide K block kb:
+    // K block k16 = kb*2 + q/4, row block q%4 — the same eight reads per operand and K block as the 16x16x32 loop issues.
+    int a_off32[4], w_off32[4];
+    if constexpr (M32) {
+        const int l31 = lane & 31, kh = lane >> 5;
+        const int swz = (l31 >> 1) & 7;
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16) {
+            const int c = ((k16 * 2 + kh) ^ swz) << 4;
+            a_off32[k16] = (wm * GEO::WROWS + l31) * GEMM_ROW_BYTES + c;
+            w_off32[k16] = GEO::A_BYTES + (wn * 128 + l31) * GEMM_ROW_BYTES + c;
+        }
+    }
     u32x4 fa[2][8], fw[2][8];
     auto read_a = [&](int stage, int kb, int i) {
-        fa[kb][i] = *(const u32x4*)(smem + stage * GEO::STAGE_BYTES + a_off[kb] + i * 16 * GEMM_ROW_BYTES);
+        if constexpr (M32) fa[kb][i] = *(const u32x4*)(smem + stage * GEO::STAGE_BYTES + a_off32[kb * 2 + (i >> 2)] + (i & 3) * 32 * GEMM_ROW_BYTES);
+        else fa[kb][i] = *(const u32x4*)(smem + stage * GEO::STAGE_BYTES + a_off[kb] + i * 16 * GEMM_ROW_BYTES);
     };
     auto read_w = [&](int stage, int kb, int j) {
-        fw[kb][j] = *(const u32x4*)(smem + stage * GEO::STAGE_BYTES + w_off[kb] + j * 16 * GEMM_ROW_BYTES);
+        if constexpr (M32) fw[kb][j] = *(const u32x4*)(smem + stage * GEO::STAGE_BYTES + w_off32[kb * 2 + (j >> 2)] + (j & 3) * 32 * GEMM_ROW_BYTES);
+        else fw[kb][j] = *(const u32x4*)(smem + stage * GEO::STAGE_BYTES + w_off[kb] + j * 16 * GEMM_ROW_BYTES);
     };
 
     const int nk = g.K / BK;
@@ -319,6 +364,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (M32) {
+                // slot p of the 16x16x32 schedule; MFMA p/2 of the 32x32x16 loop is issued in front of the even slot: K block
+                // k16 = kb*2 + h, row block i32, column block j32 (64 MFMAs of 16 passes where the product loop issues 128 of 8)
+                if ((p & 1) == 0) {
+                    const int q = (p >> 1) & 31, h = q >> 4, i32 = (q >> 2) & 3, j32 = q & 3;
+                    mfma32_agpr<T>(acc32[i32][j32], fa[kb][h * 4 + i32], fw[kb][h * 4 + j32]);
+                }
+            } else
             mfma16_agpr<T>(acc[i][j], fa[kb][i], fw[kb][j]);
             constexpr bool RD = G4D_ABL >= 2, DMA = G4D_ABL >= 3;          // (ablation hook: always true in the library)
             if (RD && p < 16 && (p & 1) == 0) read_w(cur, 1, p >> 1);
@@ -337,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (more && p >= 60 && p <= 63) read_a(nxt, 0, p - 60);
                 if constexpr (LN16K) { if (!more && p >= 24 && p < 56 && (p & 1) == 0 && res16_early) res16_request(0, (p - 24) >> 1); }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (!M32 || (p & 1)) __builtin_amdgcn_sched_barrier(0);
         }
     };
     typedef std::integral_constant<bool, true> yes_t;
@@ -360,10 +413,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_nop 15\n\ts_nop 15");     // last MFMA (8 passes) -> first accumulator read
     if constexpr (G4D_ABL < 5) {          // (ablation: no epilogue — one value per lane keeps the accumulators alive)
         float keep = 0.f;
+        if constexpr (M32) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += acc32[i][j][r];
+        } else {
 #pragma unroll
         for (int i = 0; i < GEO::MI; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        }
         if (keep == 123.456f) g.epi.out_lo[threadIdx.x] = (T)0;
         return;
     }
