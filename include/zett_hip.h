@@ -26,10 +26,11 @@
 extern "C" {
 #endif
 
-#define ZETT_ABI_VERSION 6      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range;
+#define ZETT_ABI_VERSION 7      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range;
                                    4: ZETT_RETOK_WORDPIECE (zett_retok_model gained piece_continuing, max_input_chars_per_word);
                                    5: zett_forward_prepare, zett_retokenize_async / zett_retok_result;
-                                   6: zett_retokenize_async takes NUL-separated text (offsets == NULL); options gemm_tail_split */
+                                   6: zett_retokenize_async takes NUL-separated text (offsets == NULL); options gemm_tail_split;
+                                   7: zett_retok_set_option */
 
 enum zett_status {
     ZETT_OK = 0,
@@ -302,6 +303,11 @@ typedef struct zett_retok_model {
 
 int zett_retok_create(const zett_retok_model* model, int device, zett_retok** out);
 int zett_retok_destroy(zett_retok* r);
+/* A/B switches of a retokenizer handle (as zett_set_option for the forward): "unigram_workgroup" 1 (default) = Unigram models
+ * run the workgroup-per-64-tokens kernel (all piece lookups of 64 tokens in flight at once, then the Viterbi walk on LDS);
+ * 0 = the lane-per-token kernel every model kind used before.  Same ids either way (tests/test_retok_gpu.py).  Unknown key:
+ * ZETT_E_INVALID.  No counterpart in the reference (tokenizers' Unigram::tokenize has one code path). */
+int zett_retok_set_option(zett_retok* r, const char* key, int64_t value);
 
 /* get_surface_form_matrix(tokens, maxlen, tokenizer_to_use)
  *   token_chars   device: UTF-8 text of the byte-level target tokens, concatenated

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.zett_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.zett_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_cli_dtype_selects_one_precision_policy():

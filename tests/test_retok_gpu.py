@@ -152,6 +152,60 @@ def test_unigram_without_unk_raises():
         get_surface_form_matrix(["ab", "azb"], 4, spec)
 
 
+def test_unigram_workgroup_kernel_equals_lane_kernel_and_oracle():
+    """Unigram models run a workgroup per 64 tokens (r6: every (start, end) piece lookup of the 64 tokens in flight at once, then
+    the Viterbi walk on LDS; zett_retok_set_option "unigram_workgroup"): same ids as the lane-per-token kernel and as the C oracle —
+    on pieces of up to 24 bytes (tables of len x 24 slots), tokens long enough that 64 of them need several rounds of the 3 072-slot
+    table, one that exceeds it alone, a workgroup whose text does not fit its LDS stage, ties between equal scores, byte
+    fallback; and on the 50 k tokens / 250 k pieces of the XLM-R workload bench.py measures."""
+    import torch
+
+    from zett_amd import synth
+    from zett_amd.surface_forms import DeviceRetokenizer, HnTokenizerSpec
+    rng = random.Random(77)
+    alphabet = "abcdeĠ"
+    for byte_fallback in (False, True):
+        vocab = [["<unk>", 0.0]] + [[c, rng.choice([-3.0, -2.5, -3.5])] for c in "abcdĠ"]          # 'e' has no piece: unknown runs
+        seen = set()
+        for _ in range(3000):
+            piece = "".join(rng.choice(alphabet[:5] + "Ġ") for _ in range(rng.choice([2, 2, 3, 3, 4, 5, 6, 8, 12, 16, 24])))
+            if piece not in seen:
+                seen.add(piece)
+                vocab.append([piece, rng.choice([-4.0, -5.0, -6.0, -7.5, -9.0, -12.0])])
+        if byte_fallback:
+            vocab += [[f"<0x{b:02X}>", -20.0] for b in range(256)]
+        model = {"type": "Unigram", "unk_id": 0, "byte_fallback": byte_fallback, "vocab": vocab}
+        tokens = (["".join(rng.choice(alphabet) for _ in range(rng.randint(1, 30))) for _ in range(3000)]
+                  + ["".join(rng.choice(alphabet) for _ in range(rng.randint(40, 90))) for _ in range(200)]          # several rounds per workgroup
+                  + ["".join(rng.choice(alphabet) for _ in range(200))]                                              # > 3 072 slots alone
+                  + ["".join(rng.choice(alphabet) for _ in range(100)) for _ in range(64)]                           # > 4 KiB of text in one workgroup
+                  + ["", "a", "<unk>", "e", "eee", "aeea"])
+        spec = HnTokenizerSpec.from_model_json(model, ["<unk>"], [0], 1)
+        rt = DeviceRetokenizer(spec, torch.device("cuda", 0))
+        got_wg, tr_wg = rt(tokens, 11)
+        rt.set_option("unigram_workgroup", 0)
+        got_lane, tr_lane = rt(tokens, 11)
+        assert torch.equal(got_wg, got_lane) and tr_wg == tr_lane
+        oracle_model = retok_ref.model_from_tokenizer_json(model, ["<unk>"], [0])
+        want, want_tr = retok_ref.surface_form_matrix_c(oracle_model, tokens, 11, 1)
+        np.testing.assert_array_equal(got_wg.cpu().numpy(), want)
+        assert tr_wg == want_tr
+        with pytest.raises(Exception, match="option"):
+            rt.set_option("no_such_option", 1)
+        rt.close()
+    cfg, rows, _, hist = synth.workload("xlmr_gpt2")
+    ids = synth.make_surface_forms(cfg, rows, seed=0, hist=hist)
+    hn_model, piece_of_id = synth.make_hn_model("xlmr_gpt2", cfg)
+    spec = HnTokenizerSpec.from_model_json(hn_model, ["<unk>", "<s>", "</s>"], [0, 1, 2], cfg["pad_token_id"])
+    rt = DeviceRetokenizer(spec, torch.device("cuda", 0))
+    d_text, d_off, n = rt.encode(synth.tokens_for_surface_forms(cfg, ids, piece_of_id))
+    a, tr_a = rt.run(d_text, d_off, n, 7)
+    rt.set_option("unigram_workgroup", 0)
+    b, tr_b = rt.run(d_text, d_off, n, 7)
+    assert torch.equal(a, b) and tr_a == tr_b == 0 and torch.equal(a.cpu(), torch.from_numpy(ids))
+    rt.close()
+
+
 def test_full_size_vocab_matches_oracle():
     """50k-token target vocabulary against the C oracle (size of the GPT-2 / GPT-NeoX configs)."""
     from zett_amd.surface_forms import get_surface_form_matrix

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "zett_last_error", "zett_abi_version", "zett_create", "zett_destroy", "zett_load_weight",
     "zett_finalize", "zett_forward", "zett_get_stats", "zett_workspace_bytes", "zett_set_option",
     "zett_retok_create", "zett_retok_destroy", "zett_retokenize", "zett_check_range", "zett_get_gemm_log",
-    "zett_stream_wait_output", "zett_forward_prepare", "zett_retokenize_async", "zett_retok_result",
+    "zett_stream_wait_output", "zett_forward_prepare", "zett_retokenize_async", "zett_retok_result", "zett_retok_set_option",
     "zett_partition_rows", "zett_partition_workspace_bytes", "zett_scatter_rows",
     # training primitives (zett_amd/autograd.py)
     "zett_op_gemm_f32", "zett_op_transpose_f32", "zett_op_colsum_f32", "zett_op_elementwise_f32", "zett_op_rowdot_f32",
@@ -41,7 +41,7 @@ class ZettConfig(C.Structure):
         ("ln_eps_encoder", C.c_float), ("ln_eps_projector", C.c_float)]
 
 
-ABI_VERSION = 6      # ZETT_ABI_VERSION of include/zett_hip.h
+ABI_VERSION = 7      # ZETT_ABI_VERSION of include/zett_hip.h
 
 
 class ZettStats(C.Structure):
@@ -107,6 +107,7 @@ def load():
         lib.zett_get_gemm_log.argtypes = [C.c_void_p, C.POINTER(ZettGemmRecord), C.c_int64, C.POINTER(C.c_int64)]
         lib.zett_retok_create.argtypes = [C.POINTER(ZettRetokModel), C.c_int, C.POINTER(C.c_void_p)]
         lib.zett_retok_destroy.argtypes = [C.c_void_p]
+        lib.zett_retok_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.zett_retokenize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                         C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]
         lib.zett_retokenize_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,

@@ -399,6 +399,29 @@ __device__ inline void bpe_merge(const RetokTables& t, const RetokLds& L, typena
 // Viterbi lattice of a Unigram token of len bytes: best[len + 1] (double) + bstart / bid / fwd [len + 1]
 __device__ inline int unigram_state_words(int len) { return 5 * (len + 1) + 1; }
 
+// the best path of a finished lattice -> ids: backward links reversed, runs of unknown pieces fused, optional byte fallback
+template <typename M>
+__device__ inline void unigram_emit(const RetokTables& t, const RetokLds& L, typename M::bytes raw, int len, typename M::words bstart,
+                                    typename M::words bid, typename M::words fwd, RowWriter& w) {
+    for (int e = len; e > 0; e = bstart[e]) fwd[bstart[e]] = e;
+    for (int s = 0; s < len;) {
+        int e = fwd[s];
+        if (bid[e] != -2) { w.push(bid[e]); s = e; continue; }
+        int fe = e;                                 // fuse the run of unknown pieces
+        while (fe < len && bid[fwd[fe]] == -2) fe = fwd[fe];
+        bool ok = t.byte_fallback != 0;
+        if (ok) {
+            for (int i = s; i < fe && ok; ++i) { int32_t fb[2]; int nfb; ok = fallback_pair(L, raw[i], fb, &nfb); }
+        }
+        if (ok) {
+            for (int i = s; i < fe; ++i) { int32_t fb[2]; int nfb = 0; fallback_pair(L, raw[i], fb, &nfb); for (int k = 0; k < nfb; ++k) w.push(fb[k]); }
+        } else {
+            w.push(t.unk_id);
+        }
+        s = fe;
+    }
+}
+
 // returns false on "unknown token but unk_id is missing"
 template <typename M>
 __device__ inline bool unigram_token(const RetokTables& t, const RetokLds& L, typename M::bytes raw, int len, typename M::words scr, RowWriter& w) {
@@ -446,23 +469,42 @@ __device__ inline bool unigram_token(const RetokTables& t, const RetokLds& L, ty
             if (bstart[e] == -1 || cand > best[e]) { best[e] = cand; bstart[e] = s; bid[e] = -2; }
         }
     }
-    for (int e = len; e > 0; e = bstart[e]) fwd[bstart[e]] = e;
-    for (int s = 0; s < len;) {
-        int e = fwd[s];
-        if (bid[e] != -2) { w.push(bid[e]); s = e; continue; }
-        int fe = e;                                 // fuse the run of unknown pieces
-        while (fe < len && bid[fwd[fe]] == -2) fe = fwd[fe];
-        bool ok = t.byte_fallback != 0;
-        if (ok) {
-            for (int i = s; i < fe && ok; ++i) { int32_t fb[2]; int nfb; ok = fallback_pair(L, raw[i], fb, &nfb); }
+    unigram_emit<M>(t, L, raw, len, bstart, bid, fwd, w);
+    return true;
+}
+
+// (r6) the same Viterbi walk when every (start, end) lookup of the token has already been made by the workgroup
+// (retok_unigram_kernel, phase 1): slot s * W + k of the token's table holds the piece of bytes [s, s + 1 + k) — its id (UG_MISS:
+// no such piece) and score.  Same visiting order, same strictly-greater updates, same double additions as unigram_token.
+constexpr int32_t UG_MISS = -0x7fffffff - 1;
+template <typename M>
+__device__ inline bool unigram_token_table(const RetokTables& t, const RetokLds& L, typename M::bytes raw, int len, typename M::words scr, RowWriter& w,
+                                           const lds_i32* pid, const lds_f64* pscore, int W) {
+    typename M::doubles best = (typename M::doubles)scr;
+    typename M::words bstart = scr + 2 * (len + 1);
+    typename M::words bid = bstart + len + 1;
+    typename M::words fwd = bid + len + 1;
+    for (int i = 0; i <= len; ++i) { best[i] = 0.0; bstart[i] = -1; bid[i] = -1; }
+    for (int s = 0; s < len; ++s) {
+        const double base = best[s];
+        bool has_single = false;
+        const int kmax = (len - s < W) ? len - s : W;
+        for (int k = 0; k < kmax; ++k) {
+            const int32_t id = pid[s * W + k];
+            if (id == UG_MISS) continue;
+            const int e = s + 1 + k;
+            const double cand = pscore[s * W + k] + base;
+            if (bstart[e] == -1 || cand > best[e]) { best[e] = cand; bstart[e] = s; bid[e] = id; }
+            if (k == 0) has_single = true;
         }
-        if (ok) {
-            for (int i = s; i < fe; ++i) { int32_t fb[2]; int nfb = 0; fallback_pair(L, raw[i], fb, &nfb); for (int k = 0; k < nfb; ++k) w.push(fb[k]); }
-        } else {
-            w.push(t.unk_id);
+        if (!has_single) {
+            if (t.unk_id < 0) return false;
+            const double cand = t.unk_score + base;
+            const int e = s + 1;
+            if (bstart[e] == -1 || cand > best[e]) { best[e] = cand; bstart[e] = s; bid[e] = -2; }
         }
-        s = fe;
     }
+    unigram_emit<M>(t, L, raw, len, bstart, bid, fwd, w);
     return true;
 }
 
@@ -589,6 +631,158 @@ __global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const u
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// stage 2 for Unigram models (r6): a WORKGROUP per 64 tokens — the piece lookups by all four waves, the Viterbi walk by lane
+// ---------------------------------------------------------------------------------------
+// The one-lane-per-token kernel above runs a Unigram token as len starts x up to max_piece_len ends of DEPENDENT table probes
+// (a 32-byte entry of a 16 MiB table: an L2 / MALL miss, ~1-2 us), and a wave's 64 lanes walk tokens of different lengths in
+// lockstep: 0.25 ms for the 50 k tokens of XLM-R -> GPT-2 whatever the occupancy (NOTEBOOK R5.5).  But the lookups do not depend
+// on the lattice at all — only the score accumulation does.  So:
+//   phase 0  (wave 0, a lane per token) special-token lookup, sizes: the token's (start, end) table has len x W slots,
+//            W = min(len, max_piece_len); a wavefront scan places the tables of the 64 tokens in one LDS array
+//   phase 1  (256 threads) the slots of all tokens as ONE flat work list: thread -> (token, start, end) by a binary search over
+//            the 65 prefix sums, FNV hash of the substring from the staged text, first table entries of four slots fetched
+//            together, then resolved; (id, score) or a miss into the slot.  Every probe of the workgroup is in flight at once:
+//            ~9 slots per thread instead of ~150 dependent round trips per lane
+//   phase 2  (wave 0, a lane per token) unigram_token_table: the same walk on LDS reads, then the same emission
+// Tokens whose tables do not fit the 3 072 slots together are processed in rounds; a token that alone exceeds them, and a
+// workgroup whose text does not fit its LDS stage, take the per-lane code.  Integer results, same visiting order: identical ids.
+constexpr int UG_THREADS = 256;
+constexpr int UG_TOKENS = 64;
+constexpr int UG_PCAP = 3072;
+
+__global__ __launch_bounds__(UG_THREADS) void retok_unigram_kernel(RetokTables t, const uint8_t* __restrict__ raw,
+                                                                   const int32_t* __restrict__ raw_off, int64_t n_tokens,
+                                                                   int maxlen, int32_t pad_id, int32_t* __restrict__ out, int32_t* __restrict__ scratch,
+                                                                   unsigned long long* __restrict__ n_truncated,
+                                                                   unsigned long long* __restrict__ err_unk, uint32_t call) {
+    __shared__ RetokLds L;
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[RT_TEXT_BYTES + 16];
+    __shared__ __attribute__((aligned(8))) int32_t s_arena[RT_ARENA_WORDS];
+    __shared__ __attribute__((aligned(8))) double s_pscore[UG_PCAP];
+    __shared__ int32_t s_pid[UG_PCAP];
+    __shared__ int s_base[UG_TOKENS + 1];          // first slot of every token's table (0 slots: nothing to segment)
+    __shared__ int s_len[UG_TOKENS], s_toff[UG_TOKENS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool wave0 = tid < 64;
+    for (int i = tid; i < 256; i += UG_THREADS) { L.single_id[i] = t.single_id[i]; L.bf_ids[i] = t.bf_ids[i]; }
+    const int64_t tok0 = (int64_t)blockIdx.x * UG_TOKENS;
+    const int64_t tok = tok0 + lane;
+    const bool live = wave0 && tok < n_tokens;
+    const int o0 = live ? raw_off[tok] : 0;
+    const int len = live ? raw_off[tok + 1] - o0 : 0;
+    const int w_lo = raw_off[tok0];
+    const int w_hi = raw_off[tok0 + UG_TOKENS < n_tokens ? tok0 + UG_TOKENS : n_tokens];
+    const int mis = w_lo & 15;
+    const bool text_lds = (w_hi - w_lo) + mis <= RT_TEXT_BYTES;          // (uniform)
+    if (text_lds)
+        for (int i = tid * 16; i < (w_hi - w_lo) + mis; i += UG_THREADS * 16) *(uint4*)(s_text + i) = *(const uint4*)(raw + (w_lo - mis) + i);
+    __syncthreads();
+    const lds_u8* sl = (const lds_u8*)s_text + mis + (o0 - w_lo);
+    const uint8_t* sg = raw + o0;
+    RowWriter w{out + (live ? tok : 0) * maxlen, maxlen, 0};
+    bool todo = live && len > 0;
+    if (todo && t.special_mask != 0xffffffffu) {              // zett/utils.py:671-673
+        const int id = text_lds ? whole_token_id<LdsMem>(t.specials, t.special_mask, t.special_blob, sl, len)
+                                : whole_token_id<GlobalMem>(t.specials, t.special_mask, t.special_blob, sg, len);
+        if (id >= 0) { w.row[0] = id; todo = false; }
+    }
+    int need = todo ? ((unigram_state_words(len) + 1) & ~1) : 0;
+    const int W_mine = len < t.max_piece_len ? len : t.max_piece_len;
+    int slots = (todo && text_lds) ? len * W_mine : 0;
+    int a0 = 0;
+    if (wave0) {
+        int inc = need, inc_s = slots;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off, 64), vs = __shfl_up(inc_s, off, 64);
+            if (lane >= off) { inc += v; inc_s += vs; }
+        }
+        a0 = inc - need;
+        s_base[lane + 1] = inc_s;
+        if (lane == 0) s_base[0] = 0;
+        s_len[lane] = todo ? len : 0;
+        s_toff[lane] = mis + (o0 - w_lo);
+    }
+    __syncthreads();
+    bool ok = true;
+    auto finish = [&]() {
+        if (!todo) return;
+        if (!ok) { atomicMin(err_unk, ((unsigned long long)call << 32) | (uint32_t)(tok < 0x7ffffffe ? tok : 0x7ffffffe)); return; }
+        if (w.n > maxlen) atomicAdd(n_truncated, 1ull);       // zett/utils.py:683-685
+    };
+    if (!text_lds) {          // (uniform) more than 4 KiB of text in 64 tokens: the per-lane code on global memory
+        if (todo) {
+            int32_t* scr = scratch + ((int64_t)o0 * SCR_PER_BYTE + tok * SCR_FIXED);
+            ok = unigram_token<GlobalMem>(t, L, sg, len, scr, w);
+        }
+        finish();
+        return;
+    }
+    for (int tb = 0; tb < UG_TOKENS;) {          // rounds of tokens [tb, te) whose tables fit together (all of it uniform: LDS values only)
+        int te = tb;
+        while (te < UG_TOKENS && s_base[te + 1] - s_base[tb] <= UG_PCAP) ++te;
+        const bool solo = te == tb;               // token tb alone exceeds the table: the per-lane code
+        if (solo) te = tb + 1;
+        const int b0 = s_base[tb], total = solo ? 0 : s_base[te] - b0;
+        // ---- phase 1: every (token, start, end) slot of the round, four per thread at a time
+        for (int i = tid; i < total; i += UG_THREADS * 4) {
+            uint64_t hh[4];
+            uint32_t slot[4];
+            PieceEntry first[4];
+            int sub_off[4], sub_len[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = i + k * UG_THREADS;
+                sub_len[k] = 0;
+                if (idx >= total) continue;
+                int lo = tb, hi = te - 1;              // the last token whose table starts at or before b0 + idx
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_base[mid] - b0 <= idx) lo = mid; else hi = mid - 1;
+                }
+                const int tl = s_len[lo];
+                const int Wt = tl < t.max_piece_len ? tl : t.max_piece_len;
+                const int local = idx - (s_base[lo] - b0);
+                const int st = local / Wt, e = st + 1 + local % Wt;
+                if (e > tl) { s_pid[idx] = UG_MISS; continue; }          // (the tail of the table's last rows: no such substring)
+                sub_off[k] = s_toff[lo] + st;
+                sub_len[k] = e - st;
+                uint64_t h = FNV_OFFSET;
+                for (int b = 0; b < sub_len[k]; ++b) h = fnv_step(h, s_text[sub_off[k] + b]);
+                hh[k] = h;
+                slot[k] = piece_slot(h, t.piece_mask);
+                first[k] = t.pieces[slot[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (sub_len[k] == 0) continue;
+                const int idx = i + k * UG_THREADS;
+                const PieceEntry* pe = piece_find_from(t.pieces, t.piece_mask, t.piece_blob, hh[k], (const lds_u8*)s_text + sub_off[k], sub_len[k], slot[k], first[k]);
+                if (pe) { s_pid[idx] = pe->id; s_pscore[idx] = pe->score; }
+                else s_pid[idx] = UG_MISS;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: the walk, a lane per token
+        if (wave0 && todo && lane >= tb && lane < te) {
+            const bool arena = a0 + need <= RT_ARENA_WORDS;
+            int32_t* scr = scratch + ((int64_t)o0 * SCR_PER_BYTE + tok * SCR_FIXED);
+            if (solo) {
+                ok = arena ? unigram_token<LdsMem>(t, L, sl, len, (lds_i32*)s_arena + a0, w) : unigram_token<GlobalMem>(t, L, sg, len, scr, w);
+            } else {
+                const lds_i32* pid = (const lds_i32*)s_pid + (s_base[lane] - b0);
+                const lds_f64* psc = (const lds_f64*)s_pscore + (s_base[lane] - b0);
+                ok = arena ? unigram_token_table<LdsMem>(t, L, sl, len, (lds_i32*)s_arena + a0, w, pid, psc, W_mine)
+                           : unigram_token_table<GlobalMem>(t, L, sg, len, scr, w, pid, psc, W_mine);
+            }
+            finish();
+        }
+        __syncthreads();
+        tb = te;
+    }
+}
+
 }  // namespace zett
 
 // =========================================================================================
@@ -605,6 +799,7 @@ struct zett_retok {
     struct Call { const int32_t* offsets; int64_t n_tokens; };
     std::vector<Call> recent;            // the calls since the last result query (for the token of a KeyError)
     bool words_ready = false;            // the device result words hold their initial values
+    bool unigram_wg = true;              // Unigram models: the workgroup-per-64-tokens kernel (false: the lane-per-token kernel — A/B and the identity test)
 };
 
 namespace zett {
@@ -740,6 +935,13 @@ int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
     return 0;
 }
 
+int zett_retok_set_option(zett_retok* r, const char* key, int64_t value) {
+    using namespace zett;
+    if (!r || !key) return fail(ZETT_E_INVALID, "null argument");
+    if (!strcmp(key, "unigram_workgroup")) { r->unigram_wg = value != 0; return 0; }
+    return fail(ZETT_E_INVALID, "unknown retokenizer option '%s'", key);
+}
+
 int zett_retok_destroy(zett_retok* r) {
     if (!r) return 0;
     ::zett::DeviceScope _scope(r->device);
@@ -816,8 +1018,12 @@ int zett_retokenize_async(zett_retok* r, const uint8_t* token_chars, const int32
         if (!sep)
             hipLaunchKernelGGL(token_raw_offsets_kernel, dim3((unsigned)((n_tokens + 1 + 255) / 256)), dim3(256), 0, st, offsets, n_tokens,
                                n_text, r->raw_pos.as<uint32_t>(), blk_scan, n_blocks, r->raw_off.as<int32_t>());
-        hipLaunchKernelGGL(retok_tokens_kernel, dim3((unsigned)((n_tokens + 63) / 64)), dim3(64), 0, st, r->t, r->raw.as<uint8_t>(),
-                           r->raw_off.as<int32_t>(), n_tokens, maxlen, pad_id, out, r->scratch.as<int32_t>(), words + 2, words + 1, call);
+        if (r->t.kind == ZETT_RETOK_UNIGRAM && r->unigram_wg)
+            hipLaunchKernelGGL(retok_unigram_kernel, dim3((unsigned)((n_tokens + UG_TOKENS - 1) / UG_TOKENS)), dim3(UG_THREADS), 0, st, r->t, r->raw.as<uint8_t>(),
+                               r->raw_off.as<int32_t>(), n_tokens, maxlen, pad_id, out, r->scratch.as<int32_t>(), words + 2, words + 1, call);
+        else
+            hipLaunchKernelGGL(retok_tokens_kernel, dim3((unsigned)((n_tokens + 63) / 64)), dim3(64), 0, st, r->t, r->raw.as<uint8_t>(),
+                               r->raw_off.as<int32_t>(), n_tokens, maxlen, pad_id, out, r->scratch.as<int32_t>(), words + 2, words + 1, call);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(r->host_pinned + 4, words, 24, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(r->done, st));

@@ -220,6 +220,11 @@ class DeviceRetokenizer:
         self._outstanding = []          # (text, offsets) tensors of the asynchronous calls since the last result()
         self._staging = {}              # element width -> pinned staging buffer + the event of its last transfer (_to_device)
 
+    def set_option(self, key: str, value: int) -> None:
+        """zett_retok_set_option: A/B switches of the handle ("unigram_workgroup": 1 = the workgroup-per-64-tokens Unigram kernel,
+        the default; 0 = the lane-per-token kernel)."""
+        _lib.check(self.lib.zett_retok_set_option(self.handle, key.encode(), int(value)), "zett_retok_set_option")
+
     @staticmethod
     def flatten_tokens(tokens: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
         """UTF-8 text of all tokens back to back (uint8) + int32 offsets [n + 1] — ONE join / encode for the whole list and
