@@ -141,6 +141,19 @@ def measure_traffic_live(args, timeout_s=240):
             cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "t", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--workload", args.workload, "--precision", args.precision,
                    "--no-cpu-baseline", "--no-alt-precision", "--no-live-traffic", "--no-side-configs"]
+            # (the A/B switches of the parent run apply to the child too: the traffic is that of the kernels that were timed)
+            for kv in args.option:
+                cmd += ["--option", kv]
+            for flag, val in (("--gemm-variant", args.gemm_variant), ("--gemm4d-min-k", args.gemm4d_min_k), ("--gemm-tile-order", args.gemm_tile_order),
+                              ("--max-chunk-tokens", args.max_chunk_tokens)):
+                if val:
+                    cmd += [flag, str(val)]
+            if args.no_pair_dedupe:
+                cmd.append("--no-pair-dedupe")
+            if args.no_ln_fold:
+                cmd.append("--no-ln-fold")
+            elif args.ln_fold != 1:
+                cmd += ["--ln-fold", str(args.ln_fold)]
             env = dict(os.environ, TMPDIR=work)
             res = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=timeout_s)
             files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
@@ -850,7 +863,7 @@ def main():
         from zett_amd.build import source_hash
         pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
         if (args.workload == "mistral_gpt2_32k" and args.precision == pmc.get("precision") and world == 1 and not args.rows
-                and pmc.get("source_hash") == source_hash()):
+                and pmc.get("source_hash") == source_hash() and not pmc.get("stale")):
             traffic = pmc["hbm_bytes_per_launch"]
             traffic_source = {"profile_set": pmc.get("tag"), "commit": pmc.get("commit"), "source_hash": pmc.get("source_hash"), "method": pmc.get("method")}
         else:

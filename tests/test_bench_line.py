@@ -76,3 +76,28 @@ def test_self_launch_command(monkeypatch):
     assert 1024 < int(a[a.index("--master-port") + 1]) < 65536
     k = a.index(os.path.join(REPO, "bench.py"))
     assert a[k + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "3"]
+
+
+def test_committed_pmc_traffic_matches_the_sources_or_says_stale():
+    """profiles/pmc_traffic.json is the fallback of roofline.traffic when the live PMC passes cannot run: it must have been taken
+    on the HIP sources of THIS tree (zett_amd.build.source_hash) or carry "stale": true — bench.py then reports null, never an
+    old number (the live measurement of every default run does not depend on the file)."""
+    from zett_amd.build import source_hash
+    pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+    assert pmc.get("stale") is True or pmc["source_hash"] == source_hash(), (pmc.get("source_hash"), source_hash())
+
+
+def test_cached_cpu_baselines_cover_the_side_configs():
+    """profiles/cpu_baselines.json (tools/cpu_baselines.py on a GPU box's host): one entry per BASELINE.json config, each on a
+    >= 1 024-row slice, labelled with the box; the compact line quotes C2 / C3 from it."""
+    cached = json.load(open(os.path.join(REPO, "profiles", "cpu_baselines.json")))
+    assert cached["box"] and len(cached["by_config"]) == 6
+    for e in cached["by_config"]:
+        assert e["kind"] == "port" and e["cores"] >= 1 and e["value"] > 0 and e["levers_value"] > 0
+        rows = int(e["sample"].split("first ")[1].split(" rows")[0])
+        assert rows >= min(1024, e["rows_in_config"]), e
+    assert {"xlmr_gpt2", "tinyllama_neox", "mistral_neox", "llama3_256k", "mistral_gpt2_32k"} <= set(cached["configs"])
+    full = _round5_full_line()
+    d = json.loads(bench.compact_line(full))
+    assert d["configs"][0]["cpu_baseline"]["value"] == pytest.approx(cached["configs"]["xlmr_gpt2"]["value"], rel=1e-3)
+    assert d["configs"][1]["cpu_baseline"]["kind"] == "port" and "cpu_baseline" not in d["configs"][2]

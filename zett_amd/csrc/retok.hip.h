@@ -76,6 +76,39 @@ __host__ __device__ inline uint32_t merge_slot(int32_t a, int32_t b, uint32_t ma
     return (uint32_t)(k >> 32) & mask;
 }
 
+// bytes [0, len) of a piece in the global blob against the candidate substring.  The blob side is fetched as WHOLE 8-byte words,
+// all of them before the first comparison (r6): the byte loop this replaces left after the first mismatch — so every byte was a
+// load the previous one's comparison had to wait for, up to len dependent L2 round trips behind a hash hit.  The blob carries 16
+// bytes of slack behind its last piece (build_piece_table), its base is 256-byte aligned (hipMalloc).
+constexpr int PIECE_CMP_WORDS = 4;          // pieces of up to 32 bytes take the word path
+template <typename BP>
+__device__ inline bool piece_bytes_equal(const uint8_t* p, BP s, int len) {
+    if (len > 8 * PIECE_CMP_WORDS) {
+        int i = 0;
+        while (i < len && p[i] == s[i]) ++i;
+        return i == len;
+    }
+    const uint64_t* base = (const uint64_t*)((uintptr_t)p & ~(uintptr_t)7);
+    const int sh = (int)((uintptr_t)p & 7) * 8;
+    const int nw = (len + 7) >> 3;
+    uint64_t w[PIECE_CMP_WORDS + 1];
+#pragma unroll
+    for (int j = 0; j <= PIECE_CMP_WORDS; ++j) w[j] = j <= nw ? base[j] : 0ull;
+    bool eq = true;
+#pragma unroll
+    for (int j = 0; j < PIECE_CMP_WORDS; ++j) {
+        if (j < nw) {
+            const uint64_t have = sh ? ((w[j] >> sh) | (w[j + 1] << (64 - sh))) : w[j];
+            uint64_t want = 0;
+            const int nb = len - 8 * j < 8 ? len - 8 * j : 8;
+            for (int b = 0; b < nb; ++b) want |= (uint64_t)s[8 * j + b] << (8 * b);
+            const uint64_t mask = nb == 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull);
+            eq = eq && ((have ^ want) & mask) == 0;
+        }
+    }
+    return eq;
+}
+
 // BP: pointer to the token's bytes — global memory, or the wave's staged text in LDS (stage 2 below)
 template <typename BP>
 __device__ inline const PieceEntry* piece_find(const PieceEntry* tab, uint32_t mask, const uint8_t* blob, uint64_t h, BP s, int len) {
@@ -83,10 +116,7 @@ __device__ inline const PieceEntry* piece_find(const PieceEntry* tab, uint32_t m
         const PieceEntry* e = tab + slot;
         if (e->len == 0) return nullptr;
         if (e->hash == h && e->len == len) {
-            const uint8_t* p = blob + e->off;
-            int i = 0;
-            while (i < len && p[i] == s[i]) ++i;
-            if (i == len) return e;
+            if (piece_bytes_equal(blob + e->off, s, len)) return e;
         }
     }
 }
@@ -97,19 +127,13 @@ __device__ inline const PieceEntry* piece_find_from(const PieceEntry* tab, uint3
                                                     uint32_t slot, const PieceEntry& first) {
     if (first.len == 0) return nullptr;
     if (first.hash == h && first.len == len) {
-        const uint8_t* p = blob + first.off;
-        int i = 0;
-        while (i < len && p[i] == s[i]) ++i;
-        if (i == len) return tab + slot;
+        if (piece_bytes_equal(blob + first.off, s, len)) return tab + slot;
     }
     for (slot = (slot + 1) & mask;; slot = (slot + 1) & mask) {
         const PieceEntry* e = tab + slot;
         if (e->len == 0) return nullptr;
         if (e->hash == h && e->len == len) {
-            const uint8_t* p = blob + e->off;
-            int i = 0;
-            while (i < len && p[i] == s[i]) ++i;
-            if (i == len) return e;
+            if (piece_bytes_equal(blob + e->off, s, len)) return e;
         }
     }
 }
@@ -122,10 +146,7 @@ __device__ inline const PieceEntry* piece_find_where(const PieceEntry* tab, uint
         const PieceEntry* e = tab + slot;
         if (e->len == 0) return nullptr;
         if (e->hash == h && e->len == len && e->where == where) {
-            const uint8_t* p = blob + e->off;
-            int i = 0;
-            while (i < len && p[i] == s[i]) ++i;
-            if (i == len) return e;
+            if (piece_bytes_equal(blob + e->off, s, len)) return e;
         }
     }
 }
@@ -355,6 +376,25 @@ __device__ inline int bpe_symbols(const RetokTables& t, const RetokLds& L, typen
 // triples with room for 2n entries — at most n - 1 pairs at the start, one more per merge, at most n - 1 merges
 __device__ inline int bpe_state_words(int n) { return 9 * n + 1; }
 
+// A merge-table lookup in two halves, so that several can be in flight at once (r6): merge_probe computes the slot and FETCHES its
+// entry, merge_resolve compares and walks on only on a collision.  A lane's lookups used to wait for one another — three dependent
+// L2 round trips per merge step (validate the popped pair, then the two new neighbours), one per start pair: the BPE kernel was a
+// chain of ~3n round trips per token of n symbols, ~150 us whatever the vocabulary size.
+struct MergeHit { bool found; int32_t rank, new_id; };
+__device__ inline void merge_probe(const RetokTables& t, int32_t a, int32_t b, uint32_t& slot, MergeEntry& first) {
+    slot = merge_slot(a, b, t.merge_mask);
+    first = t.merges[slot];
+}
+__device__ inline MergeHit merge_resolve(const RetokTables& t, int32_t a, int32_t b, uint32_t slot, const MergeEntry& first) {
+    if (first.a == -1) return {false, 0, 0};
+    if (first.a == a && first.b == b) return {true, first.rank, first.new_id};
+    for (slot = (slot + 1) & t.merge_mask;; slot = (slot + 1) & t.merge_mask) {
+        const MergeEntry* e = t.merges + slot;
+        if (e->a == -1) return {false, 0, 0};
+        if (e->a == a && e->b == b) return {true, e->rank, e->new_id};
+    }
+}
+
 template <typename M>
 __device__ inline void bpe_merge(const RetokTables& t, const RetokLds& L, typename M::bytes raw, int len, int n, typename M::words scr, RowWriter& w) {
     typename M::words c = scr;        // symbol ids, -1 = removed
@@ -364,9 +404,23 @@ __device__ inline void bpe_merge(const RetokTables& t, const RetokLds& L, typena
     bpe_symbols<true, M>(t, L, raw, len, c);
     for (int i = 0; i < n; ++i) { prev[i] = i - 1; next[i] = (i + 1 < n) ? i + 1 : -1; }
     int nq = 0;
-    for (int i = 0; i + 1 < n; ++i) {
-        const MergeEntry* e = merge_find(t, c[i], c[i + 1]);
-        if (e) { q[3 * nq] = e->rank; q[3 * nq + 1] = i; q[3 * nq + 2] = e->new_id; ++nq; }
+    const bool have_merges = t.merge_mask != 0xffffffffu;
+    if (have_merges) {
+        for (int i0 = 0; i0 + 1 < n; i0 += 4) {          // the start pairs, four lookups in flight
+            uint32_t slot[4];
+            MergeEntry first[4];
+            int32_t a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + k + 1 < n) { a[k] = c[i0 + k]; b[k] = c[i0 + k + 1]; merge_probe(t, a[k], b[k], slot[k], first[k]); }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + k + 1 >= n) break;
+                const MergeHit e = merge_resolve(t, a[k], b[k], slot[k], first[k]);
+                if (e.found) { q[3 * nq] = e.rank; q[3 * nq + 1] = i0 + k; q[3 * nq + 2] = e.new_id; ++nq; }
+            }
+        }
     }
     while (nq > 0) {                  // Word::merge_all
         int best = 0;
@@ -376,20 +430,29 @@ __device__ inline void bpe_merge(const RetokTables& t, const RetokLds& L, typena
         --nq;
         q[3 * best] = q[3 * nq]; q[3 * best + 1] = q[3 * nq + 1]; q[3 * best + 2] = q[3 * nq + 2];
         if (c[pos] < 0 || next[pos] == -1) continue;
-        const int r = next[pos];
-        const MergeEntry* e = merge_find(t, c[pos], c[r]);
-        if (!e || e->new_id != new_id) continue;             // expired entry: compared by new id only
+        const int r = next[pos], pl = prev[pos], nr = next[r];
+        // the popped pair as it stands NOW (an expired entry is one whose pair no longer merges to the same id), and — speculatively,
+        // they only count if it is still valid — the two pairs the merged symbol will form with its neighbours: one round trip
+        const int32_t ca = c[pos], cb = c[r];
+        const int32_t la = pl >= 0 ? c[pl] : 0, rb = nr != -1 ? c[nr] : 0;
+        uint32_t s0, s1 = 0, s2 = 0;
+        MergeEntry f0, f1{}, f2{};
+        merge_probe(t, ca, cb, s0, f0);
+        if (pl >= 0) merge_probe(t, la, new_id, s1, f1);
+        if (nr != -1) merge_probe(t, new_id, rb, s2, f2);
+        const MergeHit e0 = merge_resolve(t, ca, cb, s0, f0);
+        if (!e0.found || e0.new_id != new_id) continue;      // expired entry: compared by new id only
         c[pos] = new_id;
         c[r] = -1;
-        next[pos] = next[r];
-        if (next[r] != -1) prev[next[r]] = pos;
-        if (prev[pos] >= 0) {
-            e = merge_find(t, c[prev[pos]], c[pos]);
-            if (e) { q[3 * nq] = e->rank; q[3 * nq + 1] = prev[pos]; q[3 * nq + 2] = e->new_id; ++nq; }
+        next[pos] = nr;
+        if (nr != -1) prev[nr] = pos;
+        if (pl >= 0) {
+            const MergeHit e = merge_resolve(t, la, new_id, s1, f1);
+            if (e.found) { q[3 * nq] = e.rank; q[3 * nq + 1] = pl; q[3 * nq + 2] = e.new_id; ++nq; }
         }
-        if (next[pos] != -1) {
-            e = merge_find(t, c[pos], c[next[pos]]);
-            if (e) { q[3 * nq] = e->rank; q[3 * nq + 1] = pos; q[3 * nq + 2] = e->new_id; ++nq; }
+        if (nr != -1) {
+            const MergeHit e = merge_resolve(t, new_id, rb, s2, f2);
+            if (e.found) { q[3 * nq] = e.rank; q[3 * nq + 1] = pos; q[3 * nq + 2] = e.new_id; ++nq; }
         }
     }
     for (int i = 0; i < n; ++i)
@@ -489,13 +552,29 @@ __device__ inline bool unigram_token_table(const RetokTables& t, const RetokLds&
         const double base = best[s];
         bool has_single = false;
         const int kmax = (len - s < W) ? len - s : W;
-        for (int k = 0; k < kmax; ++k) {
-            const int32_t id = pid[s * W + k];
-            if (id == UG_MISS) continue;
-            const int e = s + 1 + k;
-            const double cand = pscore[s * W + k] + base;
-            if (bstart[e] == -1 || cand > best[e]) { best[e] = cand; bstart[e] = s; bid[e] = id; }
-            if (k == 0) has_single = true;
+        // four ends of the start at a time: their table slots and lattice cells are read TOGETHER (distinct ends: no two of the
+        // four updates touch the same cell), then compared and written — the walk is a chain of LDS latencies otherwise
+        for (int k0 = 0; k0 < kmax; k0 += 4) {
+            int32_t id[4];
+            double sc[4], be[4];
+            int bs[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = k0 + k < kmax;
+                const int slot = s * W + (in ? k0 + k : k0), e = s + 1 + (in ? k0 + k : k0);
+                id[k] = in ? pid[slot] : UG_MISS;
+                sc[k] = pscore[slot];
+                be[k] = best[e];
+                bs[k] = bstart[e];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (id[k] == UG_MISS) continue;
+                const int e = s + 1 + k0 + k;
+                const double cand = sc[k] + base;
+                if (bs[k] == -1 || cand > be[k]) { best[e] = cand; bstart[e] = s; bid[e] = id[k]; }
+                if (k0 + k == 0) has_single = true;
+            }
         }
         if (!has_single) {
             if (t.unk_id < 0) return false;
@@ -847,6 +926,7 @@ inline void build_piece_table(const uint8_t* bytes, const int32_t* offsets, cons
         if (len > out.max_len) out.max_len = len;
         if (single_id && len == 1 && !wh) single_id[(uint8_t)kv.first[0]] = ids[i];
     }
+    out.blob.resize(out.blob.size() + 16, 0);          // slack for piece_bytes_equal's whole-word reads
 }
 
 template <typename U>
