@@ -303,9 +303,10 @@ typedef struct zett_retok_model {
 
 int zett_retok_create(const zett_retok_model* model, int device, zett_retok** out);
 int zett_retok_destroy(zett_retok* r);
-/* A/B switches of a retokenizer handle (as zett_set_option for the forward): "unigram_workgroup" 1 (default) = Unigram models
- * run the workgroup-per-64-tokens kernel (all piece lookups of 64 tokens in flight at once, then the Viterbi walk on LDS);
- * 0 = the lane-per-token kernel every model kind used before.  Same ids either way (tests/test_retok_gpu.py).  Unknown key:
+/* A/B switches of a retokenizer handle (as zett_set_option for the forward): "unigram_workgroup" — which stage-2 kernel Unigram
+ * models run: the workgroup-per-64-tokens kernel (all piece lookups of 64 tokens in flight at once, then the Viterbi walk on
+ * LDS) or the lane-per-token kernel every model kind used before.  1 (default) = by size (the workgroup kernel for calls of up to
+ * 32 768 tokens), 2 = always the workgroup kernel, 0 = never.  Same ids either way (tests/test_retok_gpu.py).  Unknown key:
  * ZETT_E_INVALID.  No counterpart in the reference (tokenizers' Unigram::tokenize has one code path). */
 int zett_retok_set_option(zett_retok* r, const char* key, int64_t value);
 

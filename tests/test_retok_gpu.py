@@ -182,6 +182,7 @@ def test_unigram_workgroup_kernel_equals_lane_kernel_and_oracle():
                   + ["", "a", "<unk>", "e", "eee", "aeea"])
         spec = HnTokenizerSpec.from_model_json(model, ["<unk>"], [0], 1)
         rt = DeviceRetokenizer(spec, torch.device("cuda", 0))
+        rt.set_option("unigram_workgroup", 2)
         got_wg, tr_wg = rt(tokens, 11)
         rt.set_option("unigram_workgroup", 0)
         got_lane, tr_lane = rt(tokens, 11)
@@ -199,6 +200,7 @@ def test_unigram_workgroup_kernel_equals_lane_kernel_and_oracle():
     spec = HnTokenizerSpec.from_model_json(hn_model, ["<unk>", "<s>", "</s>"], [0, 1, 2], cfg["pad_token_id"])
     rt = DeviceRetokenizer(spec, torch.device("cuda", 0))
     d_text, d_off, n = rt.encode(synth.tokens_for_surface_forms(cfg, ids, piece_of_id))
+    rt.set_option("unigram_workgroup", 2)
     a, tr_a = rt.run(d_text, d_off, n, 7)
     rt.set_option("unigram_workgroup", 0)
     b, tr_b = rt.run(d_text, d_off, n, 7)

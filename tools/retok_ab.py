@@ -33,7 +33,7 @@ def timed(rt, d_text, d_off, n, seq, reps=20):
 def main():
     dev = torch.device("cuda", 0)
     res = []
-    for name in ("xlmr_gpt2", "mistral_gpt2_32k", "tinyllama_neox", "llama3_256k"):
+    for name in (sys.argv[1:] or ("xlmr_gpt2", "mistral_gpt2_32k", "tinyllama_neox", "llama3_256k")):
         cfg, rows, _, hist = synth.workload(name)
         ids = synth.make_surface_forms(cfg, rows, seed=0, hist=hist)
         hn_model, piece_of_id = synth.make_hn_model(name, cfg)
@@ -42,8 +42,10 @@ def main():
         for n_rows in (rows, 4096):
             d_text, d_off, n = rt.encode(synth.tokens_for_surface_forms(cfg, ids[:n_rows], piece_of_id))
             line = {"workload": name, "model": hn_model["type"], "tokens": n, "text_bytes": int(d_text.numel())}
+            if os.environ.get("ZETT_RETOK_STOP"):          # (tools/_dbg build only: the stage-2 kernel returns after that phase)
+                line["stop_after_phase"] = int(os.environ["ZETT_RETOK_STOP"])
             if hn_model["type"] == "Unigram":
-                rt.set_option("unigram_workgroup", 1)
+                rt.set_option("unigram_workgroup", 2)
                 line["us_workgroup_kernel"], a = timed(rt, d_text, d_off, n, ids.shape[1])
                 rt.set_option("unigram_workgroup", 0)
                 line["us_lane_kernel"], b = timed(rt, d_text, d_off, n, ids.shape[1])

@@ -56,6 +56,8 @@ struct MergeEntry {
 
 struct RetokTables {
     const PieceEntry* pieces; uint32_t piece_mask; const uint8_t* piece_blob;
+    const uint32_t* piece_bits; uint32_t piece_bits_mask;      // (r6) one bit per piece hash, 32 bits of table per piece: see piece_maybe
+
     const PieceEntry* specials; uint32_t special_mask; const uint8_t* special_blob;
     const MergeEntry* merges; uint32_t merge_mask;
     const int32_t* single_id;     // [256] id of the one-byte piece or -1
@@ -63,7 +65,15 @@ struct RetokTables {
     const int16_t* cp_to_byte;    // [324] code point -> byte or -1
     int kind, unk_id, fuse_unk, byte_fallback, ignore_merges, max_piece_len, max_word_chars;
     double unk_score;             // min_score - kUnkPenalty
+#ifdef ZETT_RETOK_DEBUG
+    int debug_stop;               // tools/retok_phases.sh only (-DZETT_RETOK_DEBUG): the stage-2 kernels return after phase <n>; the library never defines it
+#endif
 };
+#ifdef ZETT_RETOK_DEBUG
+#define RETOK_STOP(n) do { if (t.debug_stop == (n)) return; } while (0)
+#else
+#define RETOK_STOP(n) do { } while (0)
+#endif
 
 constexpr uint64_t FNV_OFFSET = 14695981039346656037ull;
 constexpr uint64_t FNV_PRIME = 1099511628211ull;
@@ -71,6 +81,15 @@ constexpr uint64_t FNV_OFFSET_CONT = FNV_OFFSET ^ 0x5bd1e9955bd1e995ull;      //
 
 __host__ __device__ inline uint64_t fnv_step(uint64_t h, uint8_t b) { return (h ^ b) * FNV_PRIME; }
 __host__ __device__ inline uint32_t piece_slot(uint64_t h, uint32_t mask) { return (uint32_t)(h ^ (h >> 32)) & mask; }
+// Pre-filter of the Unigram lookups: most (start, end) substrings of a token are not pieces, and each of those misses was a round
+// trip to a 16-64 MB table.  A bitmap with 32 bits per piece (XLM-R: 1 MB — L2-resident) answers ~97 % of them from L2: bit
+// piece_bit(h) is set for every piece's hash; a clear bit is a certain miss, a set bit goes to the table as before.  Same ids.
+__host__ __device__ inline uint32_t piece_bit(uint64_t h, uint32_t mask) { return (uint32_t)((h * 0xD6E8FEB86659FD93ull) >> 37) & mask; }
+__device__ inline bool piece_maybe(const uint32_t* bits, uint32_t mask, uint64_t h) {
+    if (!bits) return true;
+    const uint32_t b = piece_bit(h, mask);
+    return (bits[b >> 5] >> (b & 31)) & 1u;
+}
 __host__ __device__ inline uint32_t merge_slot(int32_t a, int32_t b, uint32_t mask) {
     const uint64_t k = (((uint64_t)(uint32_t)a) << 32 | (uint32_t)b) * 0x9E3779B97F4A7C15ull;
     return (uint32_t)(k >> 32) & mask;
@@ -422,6 +441,7 @@ __device__ inline void bpe_merge(const RetokTables& t, const RetokLds& L, typena
             }
         }
     }
+    RETOK_STOP(4);
     while (nq > 0) {                  // Word::merge_all
         int best = 0;
         for (int i = 1; i < nq; ++i)
@@ -455,6 +475,7 @@ __device__ inline void bpe_merge(const RetokTables& t, const RetokLds& L, typena
             if (e.found) { q[3 * nq] = e.rank; q[3 * nq + 1] = pos; q[3 * nq + 2] = e.new_id; ++nq; }
         }
     }
+    RETOK_STOP(5);
     for (int i = 0; i < n; ++i)
         if (c[i] >= 0) w.push(c[i]);
 }
@@ -505,19 +526,22 @@ __device__ inline bool unigram_token(const RetokTables& t, const RetokLds& L, ty
             uint64_t hh[4];
             uint32_t slot[4];
             PieceEntry first[4];
+            bool may[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                may[k] = false;
                 if (e0 + k <= emax) {
                     h = fnv_step(h, raw[e0 + k - 1]);
                     hh[k] = h;
-                    slot[k] = piece_slot(h, t.piece_mask);
-                    first[k] = t.pieces[slot[k]];
+                    may[k] = piece_maybe(t.piece_bits, t.piece_bits_mask, h);
+                    if (may[k]) { slot[k] = piece_slot(h, t.piece_mask); first[k] = t.pieces[slot[k]]; }
                 }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int e = e0 + k;
                 if (e > emax) break;
+                if (!may[k]) continue;
                 const PieceEntry* p = piece_find_from(t.pieces, t.piece_mask, t.piece_blob, hh[k], raw + s, e - s, slot[k], first[k]);
                 if (!p) continue;
                 const double cand = p->score + base;
@@ -583,6 +607,9 @@ __device__ inline bool unigram_token_table(const RetokTables& t, const RetokLds&
             if (bstart[e] == -1 || cand > best[e]) { best[e] = cand; bstart[e] = s; bid[e] = -2; }
         }
     }
+#ifdef ZETT_RETOK_DEBUG
+    if (t.debug_stop == 4) return true;
+#endif
     unigram_emit<M>(t, L, raw, len, bstart, bid, fwd, w);
     return true;
 }
@@ -662,6 +689,7 @@ __global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const u
     if (text_lds)
         for (int i = lane * 16; i < (w_hi - w_lo) + mis; i += 64 * 16) *(uint4*)(s_text + i) = *(const uint4*)(raw + (w_lo - mis) + i);
     __syncthreads();
+    RETOK_STOP(1);
     const lds_u8* sl = (const lds_u8*)s_text + mis + (o0 - w_lo);
     const uint8_t* sg = raw + o0;
     RowWriter w{out + tok * maxlen, maxlen, 0};
@@ -676,6 +704,7 @@ __global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const u
                                 : whole_token_id<GlobalMem>(t.pieces, t.piece_mask, t.piece_blob, sg, len);
         if (id >= 0) { w.push(id); todo = false; }
     }
+    RETOK_STOP(2);
     // state of the token, and its place in the wave's arena: an exclusive wavefront scan over the 64 sizes
     int n_sym = 0, need = 0;
     if (todo) {
@@ -694,6 +723,7 @@ __global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const u
         if (lane >= off) inc += v;
     }
     const int a0 = inc - need;
+    RETOK_STOP(3);
     if (todo) {
         bool ok;
         if (text_lds && a0 + need <= RT_ARENA_WORDS) {
@@ -724,11 +754,11 @@ __global__ __launch_bounds__(64) void retok_tokens_kernel(RetokTables t, const u
 //            together, then resolved; (id, score) or a miss into the slot.  Every probe of the workgroup is in flight at once:
 //            ~9 slots per thread instead of ~150 dependent round trips per lane
 //   phase 2  (wave 0, a lane per token) unigram_token_table: the same walk on LDS reads, then the same emission
-// Tokens whose tables do not fit the 3 072 slots together are processed in rounds; a token that alone exceeds them, and a
+// Tokens whose tables do not fit the 4 096 slots together are processed in rounds; a token that alone exceeds them, and a
 // workgroup whose text does not fit its LDS stage, take the per-lane code.  Integer results, same visiting order: identical ids.
 constexpr int UG_THREADS = 256;
 constexpr int UG_TOKENS = 64;
-constexpr int UG_PCAP = 3072;
+constexpr int UG_PCAP = 4096;
 
 __global__ __launch_bounds__(UG_THREADS) void retok_unigram_kernel(RetokTables t, const uint8_t* __restrict__ raw,
                                                                    const int32_t* __restrict__ raw_off, int64_t n_tokens,
@@ -757,6 +787,7 @@ __global__ __launch_bounds__(UG_THREADS) void retok_unigram_kernel(RetokTables t
     if (text_lds)
         for (int i = tid * 16; i < (w_hi - w_lo) + mis; i += UG_THREADS * 16) *(uint4*)(s_text + i) = *(const uint4*)(raw + (w_lo - mis) + i);
     __syncthreads();
+    RETOK_STOP(1);
     const lds_u8* sl = (const lds_u8*)s_text + mis + (o0 - w_lo);
     const uint8_t* sg = raw + o0;
     RowWriter w{out + (live ? tok : 0) * maxlen, maxlen, 0};
@@ -784,6 +815,7 @@ __global__ __launch_bounds__(UG_THREADS) void retok_unigram_kernel(RetokTables t
         s_toff[lane] = mis + (o0 - w_lo);
     }
     __syncthreads();
+    RETOK_STOP(2);
     bool ok = true;
     auto finish = [&]() {
         if (!todo) return;
@@ -830,6 +862,7 @@ __global__ __launch_bounds__(UG_THREADS) void retok_unigram_kernel(RetokTables t
                 uint64_t h = FNV_OFFSET;
                 for (int b = 0; b < sub_len[k]; ++b) h = fnv_step(h, s_text[sub_off[k] + b]);
                 hh[k] = h;
+                if (!piece_maybe(t.piece_bits, t.piece_bits_mask, h)) { s_pid[idx] = UG_MISS; sub_len[k] = 0; continue; }      // a certain miss, answered from L2
                 slot[k] = piece_slot(h, t.piece_mask);
                 first[k] = t.pieces[slot[k]];
             }
@@ -843,6 +876,7 @@ __global__ __launch_bounds__(UG_THREADS) void retok_unigram_kernel(RetokTables t
             }
         }
         __syncthreads();
+        RETOK_STOP(3);
         // ---- phase 2: the walk, a lane per token
         if (wave0 && todo && lane >= tb && lane < te) {
             const bool arena = a0 + need <= RT_ARENA_WORDS;
@@ -878,20 +912,27 @@ struct zett_retok {
     struct Call { const int32_t* offsets; int64_t n_tokens; };
     std::vector<Call> recent;            // the calls since the last result query (for the token of a KeyError)
     bool words_ready = false;            // the device result words hold their initial values
-    bool unigram_wg = true;              // Unigram models: the workgroup-per-64-tokens kernel (false: the lane-per-token kernel — A/B and the identity test)
+    int unigram_wg = 1;                  // Unigram models: 1 = the workgroup-per-64-tokens kernel for calls of up to 32 768 tokens, 2 = always, 0 = never (the lane-per-token kernel)
 };
 
 namespace zett {
 
+// Open addressing with linear probing, load factor 1/16 .. 1/8 (r6; was 1/4 .. 1/2).  A wave waits for the LONGEST probe chain among
+// its 64 lanes' lookups, every probe a dependent L2 / MALL round trip, and the clusters of linear probing at half load have a heavy
+// tail: the phase timing of round 6 (tools/retok_ab.py on a -DZETT_RETOK_DEBUG build) put 48 of a Unigram workgroup's 87 us into
+// its lookups and 70 of the BPE kernel's 135 into the merge loop.  Memory is not the constraint on a 288 GB part (XLM-R's 250 k
+// pieces: 64 MB; Llama-3's 128 k merges: 16 MB).
 inline uint32_t pow2_capacity(size_t n) {
     uint32_t c = 16;
-    while (c < 2 * n + 2) c <<= 1;
+    while (c < 8 * n + 2) c <<= 1;
     return c;
 }
 
 struct HostPieceTable {
     std::vector<PieceEntry> slots;
     std::vector<uint8_t> blob;
+    std::vector<uint32_t> bits;          // piece_maybe's bitmap (word-initial WordPiece / all other pieces alike: keyed by the hash)
+    uint32_t bits_mask = 0;
     uint32_t mask = 0xffffffffu;
     int max_len = 0;
 };
@@ -912,6 +953,8 @@ inline void build_piece_table(const uint8_t* bytes, const int32_t* offsets, cons
     const uint32_t cap = pow2_capacity(last.size());
     out.mask = cap - 1;
     out.slots.assign(cap, PieceEntry{0, 0, 0, 0, 0, 0.0});
+    out.bits_mask = cap * 4 - 1;         // 32 .. 64 bits per piece
+    out.bits.assign((size_t)cap * 4 / 32, 0u);
     for (auto& kv : last) {
         const int i = kv.second;
         const int len = (int)kv.first.size() - (where ? 1 : 0);
@@ -923,6 +966,7 @@ inline void build_piece_table(const uint8_t* bytes, const int32_t* offsets, cons
         uint32_t slot = piece_slot(h, out.mask);
         while (out.slots[slot].len != 0) slot = (slot + 1) & out.mask;
         out.slots[slot] = e;
+        { const uint32_t b = piece_bit(h, out.bits_mask); out.bits[b >> 5] |= 1u << (b & 31); }
         if (len > out.max_len) out.max_len = len;
         if (single_id && len == 1 && !wh) single_id[(uint8_t)kv.first[0]] = ids[i];
     }
@@ -994,6 +1038,9 @@ int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
     if ((rc = upload(r, pt.slots, &dp))) { zett_retok_destroy(r); return rc; } t.pieces = dp;
     if ((rc = upload(r, pt.blob, &db))) { zett_retok_destroy(r); return rc; } t.piece_blob = db;
     t.piece_mask = pt.mask;
+    { const uint32_t* dbits = nullptr;
+      if ((rc = upload(r, pt.bits, &dbits))) { zett_retok_destroy(r); return rc; }
+      t.piece_bits = dbits; t.piece_bits_mask = pt.bits_mask; }
     if (!dp) {   // empty vocabulary: one empty slot so lookups terminate
         std::vector<PieceEntry> one(16, PieceEntry{0, 0, 0, 0, 0, 0.0});
         if ((rc = upload(r, one, &dp))) { zett_retok_destroy(r); return rc; }
@@ -1008,6 +1055,9 @@ int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
     if ((rc = upload(r, cp, &dc))) { zett_retok_destroy(r); return rc; } t.cp_to_byte = dc;
     t.kind = m->kind; t.unk_id = m->unk_id; t.fuse_unk = m->fuse_unk; t.byte_fallback = m->byte_fallback;
     t.ignore_merges = m->ignore_merges; t.max_piece_len = pt.max_len; t.max_word_chars = m->max_input_chars_per_word;
+#ifdef ZETT_RETOK_DEBUG
+    { const char* e = getenv("ZETT_RETOK_STOP"); t.debug_stop = e ? atoi(e) : 0; }
+#endif
     t.unk_score = m->unigram_min_score - 10.0;   // tokenizers kUnkPenalty
     HIP_TRY(hipHostMalloc((void**)&r->host_pinned, 128, hipHostMallocDefault));
     HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
@@ -1018,7 +1068,11 @@ int zett_retok_create(const zett_retok_model* m, int device, zett_retok** out) {
 int zett_retok_set_option(zett_retok* r, const char* key, int64_t value) {
     using namespace zett;
     if (!r || !key) return fail(ZETT_E_INVALID, "null argument");
-    if (!strcmp(key, "unigram_workgroup")) { r->unigram_wg = value != 0; return 0; }
+    if (!strcmp(key, "unigram_workgroup")) {
+        if (value < 0 || value > 2) return fail(ZETT_E_INVALID, "unigram_workgroup: 0 (lane kernel), 1 (by size), 2 (workgroup kernel)");
+        r->unigram_wg = (int)value;
+        return 0;
+    }
     return fail(ZETT_E_INVALID, "unknown retokenizer option '%s'", key);
 }
 
@@ -1098,7 +1152,10 @@ int zett_retokenize_async(zett_retok* r, const uint8_t* token_chars, const int32
         if (!sep)
             hipLaunchKernelGGL(token_raw_offsets_kernel, dim3((unsigned)((n_tokens + 1 + 255) / 256)), dim3(256), 0, st, offsets, n_tokens,
                                n_text, r->raw_pos.as<uint32_t>(), blk_scan, n_blocks, r->raw_off.as<int32_t>());
-        if (r->t.kind == ZETT_RETOK_UNIGRAM && r->unigram_wg)
+        // Unigram: the workgroup kernel while its workgroups (two per CU) fit the chip in one round — a rank's shard, a CLI batch —,
+        // the lane kernel beyond (five single-wave workgroups per CU, all resident): 4 096 tokens 74 vs 90 us, 50 350 tokens 125 vs 103
+        // (profiles/r6_retok_ab.jsonl); "unigram_workgroup" 2 / 0 force one of them
+        if (r->t.kind == ZETT_RETOK_UNIGRAM && (r->unigram_wg == 2 || (r->unigram_wg == 1 && n_tokens <= 32768)))
             hipLaunchKernelGGL(retok_unigram_kernel, dim3((unsigned)((n_tokens + UG_TOKENS - 1) / UG_TOKENS)), dim3(UG_THREADS), 0, st, r->t, r->raw.as<uint8_t>(),
                                r->raw_off.as<int32_t>(), n_tokens, maxlen, pad_id, out, r->scratch.as<int32_t>(), words + 2, words + 1, call);
         else

@@ -328,6 +328,13 @@ struct LnEmbed {
     const int32_t* row_offset; // [N+1]                                     } chunk_row() below
     int64_t row0;              // first vocabulary row of the chunk
     int rows;                  // vocabulary rows in the chunk
+    // (r6) the table as the LayerNorm-fold producer left it: the 16-bit copy of the ProjectorBlock's PRE-LayerNorm sum, (mean, rstd)
+    // per table row, and the block's gamma / beta — the embed variant normalises a table row as it reads it (ln_affine), so the
+    // ProjectorBlock's LayerNorm is not a launch and a table element is 2 bytes instead of 4 on both sides.  null: `table` is fp32.
+    const void* table_lo;      // [D, H] of the launch's operand type
+    const float* table_stats;  // [D] (mean, rstd)
+    const float* table_gamma;  // [H] input_projection.1.ln.weight
+    const float* table_beta;   // [H]
 };
 
 // Row order of a chunk's hidden-state buffers: POSITION 0 FIRST.  A chunk covers vocabulary rows [row0, row0 + rows) =
@@ -377,9 +384,16 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     const float* posr = nullptr;
     bool is_lang = false;
     int ro = r;                            // output row
+    const T* tbl_lo = nullptr;             // EMBED on the 16-bit table: the row's 16-bit pre-LayerNorm sum and its statistics
+    float2 tbl_st = make_float2(0.f, 1.f);
     if constexpr (EMBED) {
         const int slot = emb.tok_slot[tok0 + r];
         is_lang = slot < 0;
+        if (emb.table_lo && !is_lang) {
+            tbl_lo = (const T*)emb.table_lo + (size_t)slot * H;
+            tbl_st = *(const float2*)(emb.table_stats + 2 * (size_t)slot);
+            x = emb.lang;                  // (not read)
+        } else
         x = is_lang ? emb.lang : emb.table + (size_t)slot * H;
         posr = emb.pos_emb + (size_t)emb.tok_pos[tok0 + r] * H;
         if (emb.tok_row) {                 // (null: rows are pairs, written in place)
@@ -398,7 +412,20 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
                 return a;
             }
         }
-        float4 a = *(const float4*)(x + v * 4);
+        float4 a;
+        if constexpr (EMBED && sizeof(T) == 2) {
+            if (tbl_lo) {          // (uniform per row: a table row of the 16-bit table, normalised on the fly)
+                const uint2 u = *(const uint2*)(tbl_lo + v * 4);
+                unpack2_lo<T>(u.x, a.x, a.y); unpack2_lo<T>(u.y, a.z, a.w);
+                const float4 g = *(const float4*)(emb.table_gamma + v * 4), b = *(const float4*)(emb.table_beta + v * 4);
+                a = make_float4(ln_affine(a.x, tbl_st.x, tbl_st.y, g.x, b.x), ln_affine(a.y, tbl_st.x, tbl_st.y, g.y, b.y),
+                                ln_affine(a.z, tbl_st.x, tbl_st.y, g.z, b.z), ln_affine(a.w, tbl_st.x, tbl_st.y, g.w, b.w));
+            } else {
+                a = *(const float4*)(x + v * 4);
+            }
+        } else {
+            a = *(const float4*)(x + v * 4);
+        }
         if constexpr (EMBED) {
             const float4 t0 = *(const float4*)(emb.type0 + v * 4);
             const float4 p = *(const float4*)(posr + v * 4);
@@ -684,12 +711,23 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
 //   fold_weight_kernel  one-off, at zett_finalize: W'[n,k] = lo(W[n,k] * gamma[k]),  c[n] = sum_k W'[n,k],
 //                       b'[n] = b[n] + sum_k W[n,k] * beta[k]     so that   LN(x) W^T + b = rstd (x W'^T - mean c) + b'
 // ---------------------------------------------------------------------------
-__global__ void ln_stats_kernel(const float2* __restrict__ part, int parts, int ld_part, int rows, int H, float eps,
-                                float* __restrict__ stats) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
+// (r6) four threads per row, each adding every fourth partial, combined in a fixed order through LDS: the one-thread-per-row
+// version walked 32 dependent 8-byte loads per row at H = 4096 — 12-16 us for a kernel that moves 2-20 MB, seven to ten times per
+// forward (1 % of a 4 096-row shard's step).  64 rows per workgroup; loads of one partial are coalesced over the rows.
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float2* __restrict__ part, int parts, int ld_part, int rows, int H, float eps,
+                                                      float* __restrict__ stats) {
+    __shared__ float2 red[4][64];
+    const int rl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + rl;
     float s = 0.f, q = 0.f;
-    for (int p = 0; p < parts; ++p) { const float2 v = part[(size_t)p * ld_part + r]; s += v.x; q += v.y; }
+    if (r < rows)
+        for (int p = pg; p < parts; p += 4) { const float2 v = part[(size_t)p * ld_part + r]; s += v.x; q += v.y; }
+    red[pg][rl] = make_float2(s, q);
+    __syncthreads();
+    if (pg != 0 || r >= rows) return;
+    const float2 a = red[0][rl], b = red[1][rl], c = red[2][rl], d = red[3][rl];
+    s = (a.x + b.x) + (c.x + d.x);
+    q = (a.y + b.y) + (c.y + d.y);
     const float mean = s / (float)H;
     const float var = fmaxf(q / (float)H - mean * mean, 0.f);
     *(float2*)(stats + 2 * (size_t)r) = make_float2(mean, 1.0f / sqrtf(var + eps));

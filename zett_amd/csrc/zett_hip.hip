@@ -85,6 +85,7 @@ struct zett_hypernet {
     int gemm_tail_split = 1;          // gemm4d: a launch's partly filled last round of 256 CUs as 128x256 tiles (gemm4d.hip.h gemm4d_row_split): 0 never,
                                       // 1 when the split is cheaper (default), 2 = cut every launch in the middle, 3 = half tiles only (tests: same bits)
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
+    int table_lo = 1;                 // 16-bit hoisted table with the ProjectorBlock's LayerNorm folded into the embeddings' kernel (with the 16-bit residual stream); 0 = fp32 table (A/B)
     int gemm_group = 0;               // gemm4d: column (order 0) / row (order 1) tiles per group; 0 = the kernel's default, 4 (A/B)
     int gemm4d_min_k = 512;           // 16-bit launches with K >= this take the four-wave direct-to-LDS tile (r2: with the streamlined epilogues it is ahead of gemm8r down to K = 768: +1.8 % on the XLM-R workload)
     int gemm_variant = 0;             // 0 auto, 1 = 128x128, 2 = 256x256 register-staged (8 waves), 3 = 384x256 LDS-DMA,
@@ -588,6 +589,8 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "gemm_tail_split") {
         if (value < 0 || value > 3) return fail(ZETT_E_INVALID, "gemm_tail_split must be 0 (never), 1 (auto), 2 (cut every gemm4d launch in the middle) or 3 (128x256 tiles only)");
         h->gemm_tail_split = (int)value;
+    } else if (k == "table_lo") {
+        h->table_lo = value != 0;
     } else if (k == "gemm_group") {
         if (value < 0 || value > 64) return fail(ZETT_E_INVALID, "gemm_group must be 0 (default: 4) .. 64");
         h->gemm_group = (int)value;
@@ -898,7 +901,7 @@ struct Runner {
     // LayerNorm fold: (mean, rstd) per row from the partials the producer GEMM wrote
     void ln_stats(const float2* parts, int ld_part, int rows, float eps, float* stats) {
         if (rc || rows <= 0) return;
-        hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, parts, h->cfg.hidden / 128, ld_part, rows,
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 63) / 64), dim3(256), 0, st, parts, h->cfg.hidden / 128, ld_part, rows,
                            h->cfg.hidden, eps, stats);
         check("ln_stats");
     }
@@ -1023,6 +1026,16 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     if (int rc = h->lnparts.reserve(ws_parts)) return rc;
     float2* PARTS = h->lnparts.as<float2>();
     float* TBL = h->table.as<float>();
+    // 16-bit hoisted table (r6; with the 16-bit residual stream, i.e. f16 by default): the ProjectorBlock of the input projection ends
+    // in the LayerNorm-fold PRODUCER the output heads use (dense2 writes the 16-bit copy of its pre-LayerNorm sum + partial row
+    // statistics; ln_stats makes (mean, rstd)), and the embeddings' kernel normalises a table row as it reads it: the block's
+    // LayerNorm launch is gone (0.40 ms on the headline, 0.16 of XLM-R's 7.3), a table element is 2 bytes on both sides, and a
+    // table exchanged between ranks (SURVEY 8e's optional second exchange) would be 239 instead of 478 MB.  One 16-bit rounding of
+    // the pre-LayerNorm sum replaces none: the same step the encoder's stream takes per layer.  The buffer keeps its fp32 size:
+    // [D, H] 16-bit values, then [D] (mean, rstd).
+    const bool table_lo = lo_stream && h->table_lo != 0;
+    T* TBL16 = (T*)h->table.as<float>();
+    float* TBLST = (float*)((char*)h->table.as<float>() + (((size_t)D * H * sizeof(T) + 15) / 16) * 16);
     T* X0 = h->x0.as<T>();
     float* Zf = h->yf.as<float>();
     T* Zt = h->yt.as<T>();
@@ -1054,7 +1067,8 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         GemmEpilogue<T> e0 = R.epi();
         e0.bias = R.Wf("input_projection.0.bias"); e0.out_f32 = Zf; e0.ld_f32 = H; e0.out_lo = Zt; e0.ld_lo = H;
         R.gemm(X0, EIN, R.Wlo("input_projection.0.weight"), EIN, m, H, EIN, e0);
-        R.projector("input_projection.1.", Zt, Zf, m, BIG, PRE, TBL + (size_t)s0 * H, nullptr);
+        if (table_lo) R.projector("input_projection.1.", Zt, Zf, m, BIG, PRE, nullptr, TBL16 + (size_t)s0 * H, PARTS, (int)MCS, TBLST + 2 * (size_t)s0);
+        else R.projector("input_projection.1.", Zt, Zf, m, BIG, PRE, TBL + (size_t)s0 * H, nullptr);
     }
     if (R.rc) return R.rc;
 
@@ -1095,7 +1109,8 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         float2* const PARTS = h->lnparts.as<float2>() + lane.off;
 
         LnEmbed emb{TBL, p.tok_slot, p.tok_pos, R.Wf("model.embeddings.token_type_embeddings.weight"),
-                    R.Wf("model.embeddings.position_embeddings.weight"), lang_vec, seq, p.tok_row, p.row_offset, r0, rows};
+                    R.Wf("model.embeddings.position_embeddings.weight"), lang_vec, seq, p.tok_row, p.row_offset, r0, rows,
+                    table_lo ? (const void*)TBL16 : nullptr, TBLST, R.Wf("input_projection.1.ln.weight"), R.Wf("input_projection.1.ln.bias")};
         // hidden state = (sum buffer, statistics, gamma, beta); the embeddings' LayerNorm starts it in (Zf, STb)
         float* hs_sum = Zf;
         float* hs_stats = STb;

@@ -221,8 +221,8 @@ class DeviceRetokenizer:
         self._staging = {}              # element width -> pinned staging buffer + the event of its last transfer (_to_device)
 
     def set_option(self, key: str, value: int) -> None:
-        """zett_retok_set_option: A/B switches of the handle ("unigram_workgroup": 1 = the workgroup-per-64-tokens Unigram kernel,
-        the default; 0 = the lane-per-token kernel)."""
+        """zett_retok_set_option: A/B switches of the handle ("unigram_workgroup": which Unigram kernel runs — 1 = by size, the
+        default; 2 = the workgroup-per-64-tokens kernel; 0 = the lane-per-token kernel)."""
         _lib.check(self.lib.zett_retok_set_option(self.handle, key.encode(), int(value)), "zett_retok_set_option")
 
     @staticmethod
