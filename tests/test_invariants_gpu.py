@@ -337,3 +337,48 @@ def test_workspace_bytes_bounds_what_a_forward_reserves():
     with pytest.raises(Exception):
         eng.workspace_bytes(-1, 7)
     del out
+
+
+@pytest.mark.parametrize("name,rows", [("tinyllama_neox", 3001), ("xlmr_gpt2", 2500)])
+def test_folded_table_option(name, rows):
+    """r6: with the 16-bit residual stream (f16) the hoisted input-projection table is kept as the LayerNorm-fold producer leaves it
+    — the 16-bit pre-LayerNorm sum + (mean, rstd) per distinct id — and normalised by the embeddings' kernel as it reads it
+    (zett_set_option "table_lo", default 1).  The fp32 table (0) is the A/B: both meet the oracle inside the f16 tolerance, they
+    differ from each other by one 16-bit rounding of the table (rel-L2 well under the tolerance), shards and chunks of the folded
+    table reproduce its single forward bit for bit (a table row's bits do not depend on which tile computed it), and bf16 mode —
+    fp32 stream — ignores the option."""
+    from oracle import hypernet_ref
+    from zett_amd.sharding import shard_bounds
+    cfg, _, src_dtype, hist = synth.workload(name)
+    lang = 3 if cfg.get("hn_embed_lang_id") else -1
+    src_np = synth.make_source_embeddings(cfg, 4, dtype=src_dtype)
+    src = torch.from_numpy(src_np).cuda()
+    ids = synth.make_surface_forms(cfg, rows, seed=4, hist=hist, n_special=2)
+    eng = _engine(cfg, 4, "f16")
+    folded = _run(eng, ids, src, lang)
+    for world in (3, 8):
+        parts = [_run(eng, ids[slice(*shard_bounds(len(ids), world, r))], src, lang) for r in range(world)]
+        assert _eq([None if parts[0][k] is None else torch.cat([p[k] for p in parts]) for k in range(3)], folded)
+    eng.set_option("max_chunk_tokens", 1024)
+    assert _eq(_run(eng, ids, src, lang), folded)
+    eng.set_option("max_chunk_tokens", 1 << 22)
+    eng.set_option("table_lo", 0)
+    plain = _run(eng, ids, src, lang)
+    assert not _eq(plain, folded)
+    for a, b in zip(plain, folded):
+        if a is not None and a.dim() == 2:
+            assert float((a - b).norm() / a.norm()) < 1e-3
+    sample = np.arange(0, rows, 37)
+    from bench import device_weights
+    w = {k: v.float().cpu().numpy() for k, v in device_weights(cfg, torch.device("cuda:0"), seed=4).items()}
+    hypernet_ref.set_matmul_backend("torch")
+    want = hypernet_ref.forward(w, cfg, ids[sample], src_np, None if lang < 0 else lang)
+    keep = ~util.all_pad_rows(cfg, ids[sample])
+    for out in (folded, plain):
+        for g, r in zip(out, want):
+            if g is not None and r is not None:
+                util.CLOSE["f16"](g[torch.from_numpy(sample).cuda()].cpu().numpy()[keep], r[keep], f"{name} table option")
+    b16 = _engine(cfg, 4, "bf16")
+    x = _run(b16, ids, src, lang)
+    b16.set_option("table_lo", 0)
+    assert _eq(_run(b16, ids, src, lang), x)

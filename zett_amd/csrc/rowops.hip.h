@@ -711,23 +711,15 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
 //   fold_weight_kernel  one-off, at zett_finalize: W'[n,k] = lo(W[n,k] * gamma[k]),  c[n] = sum_k W'[n,k],
 //                       b'[n] = b[n] + sum_k W[n,k] * beta[k]     so that   LN(x) W^T + b = rstd (x W'^T - mean c) + b'
 // ---------------------------------------------------------------------------
-// (r6) four threads per row, each adding every fourth partial, combined in a fixed order through LDS: the one-thread-per-row
-// version walked 32 dependent 8-byte loads per row at H = 4096 — 12-16 us for a kernel that moves 2-20 MB, seven to ten times per
-// forward (1 % of a 4 096-row shard's step).  64 rows per workgroup; loads of one partial are coalesced over the rows.
-__global__ __launch_bounds__(256) void ln_stats_kernel(const float2* __restrict__ part, int parts, int ld_part, int rows, int H, float eps,
-                                                      float* __restrict__ stats) {
-    __shared__ float2 red[4][64];
-    const int rl = threadIdx.x & 63, pg = threadIdx.x >> 6;
-    const int r = blockIdx.x * 64 + rl;
+// (r6: a version with four threads per row — every fourth partial each, combined through LDS — was 2-3 x faster on a 12-16 us kernel
+//  and changed the summation order: bf16 mode, which sits ON its 1e-2 tolerance, went from 0.99e-2 to 1.002e-2 on the Llama-3 sample.
+//  The sequential order of rounds 3-5 stays.)
+__global__ void ln_stats_kernel(const float2* __restrict__ part, int parts, int ld_part, int rows, int H, float eps,
+                                float* __restrict__ stats) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
     float s = 0.f, q = 0.f;
-    if (r < rows)
-        for (int p = pg; p < parts; p += 4) { const float2 v = part[(size_t)p * ld_part + r]; s += v.x; q += v.y; }
-    red[pg][rl] = make_float2(s, q);
-    __syncthreads();
-    if (pg != 0 || r >= rows) return;
-    const float2 a = red[0][rl], b = red[1][rl], c = red[2][rl], d = red[3][rl];
-    s = (a.x + b.x) + (c.x + d.x);
-    q = (a.y + b.y) + (c.y + d.y);
+    for (int p = 0; p < parts; ++p) { const float2 v = part[(size_t)p * ld_part + r]; s += v.x; q += v.y; }
     const float mean = s / (float)H;
     const float var = fmaxf(q / (float)H - mean * mean, 0.f);
     *(float2*)(stats + 2 * (size_t)r) = make_float2(mean, 1.0f / sqrtf(var + eps));

@@ -901,7 +901,7 @@ struct Runner {
     // LayerNorm fold: (mean, rstd) per row from the partials the producer GEMM wrote
     void ln_stats(const float2* parts, int ld_part, int rows, float eps, float* stats) {
         if (rc || rows <= 0) return;
-        hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 63) / 64), dim3(256), 0, st, parts, h->cfg.hidden / 128, ld_part, rows,
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, parts, h->cfg.hidden / 128, ld_part, rows,
                            h->cfg.hidden, eps, stats);
         check("ln_stats");
     }
