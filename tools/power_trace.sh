@@ -5,7 +5,7 @@ set -u
 tag=${1:-rX}; w=${2:-mistral_gpt2_32k}
 out=$GRAFT_REPO_ROOT/gpurun_out/${tag}_power_$w
 cd /tmp
-python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 150 --warmup 3 --no-cpu-baseline --no-alt-precision --no-live-traffic > $out.bench.json 2> /dev/null &
+python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 150 --warmup 3 --no-cpu-baseline --no-alt-precision --no-live-traffic --no-side-configs > $out.bench.json 2> /dev/null &
 pid=$!
 : > $out.txt
 while kill -0 $pid 2>/dev/null; do

@@ -9,11 +9,13 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 bench="python $GRAFT_REPO_ROOT/bench.py --no-live-traffic --no-side-configs"      # (the PMC passes below are the profile set; the default line measures its own traffic and carries the side lines)
 python $GRAFT_REPO_ROOT/bench.py 2>/dev/null | tail -1 > $out/bench_default.json
-for w in xlmr_gpt2 tinyllama_neox mistral_neox llama3_256k; do $bench --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_$w.json; done
+cp $GRAFT_REPO_ROOT/bench_side.json $out/bench_default_side.json      # (r6: stdout is the compact line; the full objects — per-class tables of every side config — are in bench_side.json)
+for w in xlmr_gpt2 tinyllama_neox mistral_neox llama3_256k; do $bench --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_$w.json; cp $GRAFT_REPO_ROOT/bench_side.json $out/bench_${w}_side.json; done
 $bench --precision f32 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_default_f32.json
 $bench --precision bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_default_bf16.json
-for r in 16384 8192 4096; do $bench --rows $r --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_rows_$r.json; done
+for r in 16384 8192 4096; do $bench --rows $r --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_rows_$r.json; cp $GRAFT_REPO_ROOT/bench_side.json $out/bench_rows_${r}_side.json; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o $tag -- $bench --steps 3 --warmup 1 --no-cpu-baseline --no-alt-precision > $out/prof_bench.json 2> $out/prof.err
+cp $GRAFT_REPO_ROOT/bench_side.json $out/prof_bench_side.json
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   d=$out/pmc_$(echo $c | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o t -- $bench --steps 1 --warmup 1 --no-cpu-baseline --no-alt-precision > /dev/null 2> $d.err

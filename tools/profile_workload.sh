@@ -8,9 +8,11 @@ extra="$*"
 out=$GRAFT_REPO_ROOT/gpurun_out/${tag}_$w
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-bench="python $GRAFT_REPO_ROOT/bench.py --workload $w --no-live-traffic --no-cpu-baseline --no-alt-precision $extra"
+bench="python $GRAFT_REPO_ROOT/bench.py --workload $w --no-live-traffic --no-cpu-baseline --no-alt-precision --no-side-configs $extra"
 $bench 2>/dev/null | tail -1 > $out/bench.json
+cp $GRAFT_REPO_ROOT/bench_side.json $out/bench_side.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o $tag -- $bench --steps 3 --warmup 1 > $out/prof_bench.json 2> $out/prof.err
+cp $GRAFT_REPO_ROOT/bench_side.json $out/prof_bench_side.json
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   d=$out/pmc_$(echo $c | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o t -- $bench --steps 1 --warmup 1 > /dev/null 2> $d.err
