@@ -433,15 +433,19 @@ print("ok")
 def test_no_product_kernel_uses_scratch(tmp_path):
     """Every kernel of libzett_hip.so must fit its registers: a spilled GEMM epilogue once returned wrong
     tiles on the first launches of a process (gemm384 with a residual epilogue), and scratch reloads
-    sit behind vmcnt(0) waits inside store sequences.  hipcc's resource-usage remarks, device-only
-    compile of the one translation unit."""
+    sit behind vmcnt(0) waits inside store sequences.  hipcc's resource-usage remarks: the ones zett_amd.build kept
+    beside each object when it compiled the translation unit, as long as no source changed since (r6: recompiling every
+    unit here took two of the CPU suite's six minutes) - otherwise a device-only compile of that unit."""
     import re
     import shutil
     from concurrent.futures import ThreadPoolExecutor
-    from zett_amd.build import CSRC, SOURCES
+    from zett_amd.build import CSRC, SOURCES, fresh_remarks
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
     def remarks(name):
+        kept = fresh_remarks(name)
+        if kept is not None and "Function Name:" in kept:
+            return kept
         out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only", os.path.join(CSRC, name),
                               "-o", str(tmp_path / (name + ".o")), "-Rpass-analysis=kernel-resource-usage"],
                              capture_output=True, text=True, timeout=1500)

@@ -382,3 +382,55 @@ def test_folded_table_option(name, rows):
     x = _run(b16, ids, src, lang)
     b16.set_option("table_lo", 0)
     assert _eq(_run(b16, ids, src, lang), x)
+
+
+@pytest.mark.parametrize("hidden,heads,rows", [(768, 12, 2501), (128, 2, 1003), (256, 4, 515), (576, 9, 333), (2048, 32, 700), (320, 5, 257)])
+def test_narrow_row_kernels_r6(hidden, heads, rows):
+    """r6, the row kernels of the narrow hypernets.  (a) `attention_pack`: a last column group of 256 / 128 / 64 columns (H = 768,
+    128, 256, 576) takes 2 / 4 / 8 rows per wave instead of idle lanes — the same arithmetic per element, so ON and OFF give the same
+    bits, also with forced chunks (a chunk's last wave is partly filled) and in the position-0-only last layer; H = 2048 / 320 have
+    no such group and the option changes nothing.  (b) `ln_rows8`: the 16-bit LayerNorm launches with eight columns per lane
+    (H = 256·k <= 1024: 32 lanes per row; 512·k <= 2048: 64) add a row's values up in another order than the float4 kernel: both
+    meet the oracle inside the f16 tolerance and differ from each other by rounding only; shards reproduce the single forward bit
+    for bit with either."""
+    from oracle import hypernet_ref
+    from zett_amd.sharding import shard_bounds
+    base = synth.workload("tiny")[0]
+    cfg = dict(base, n_embd=128, hn_hidden_size=hidden, hn_intermediate_size=2 * hidden if hidden <= 1024 else 512, hn_num_attention_heads=heads, hn_n_layers=3)
+    lang = 3 if cfg.get("hn_embed_lang_id") else -1
+    src_np = synth.make_source_embeddings(cfg, 6)
+    src = torch.from_numpy(src_np).cuda()
+    ids = synth.make_surface_forms(cfg, rows, seed=6, n_special=2)
+    for precision in ("f16", "bf16"):
+        eng = _engine(cfg, 6, precision)
+        ref = _run(eng, ids, src, lang)
+        eng.set_option("attention_pack", 0)
+        assert _eq(_run(eng, ids, src, lang), ref), "attention_pack changed bits"
+        eng.set_option("attention_pack", 1)
+        eng.set_option("max_chunk_tokens", 1024)
+        assert _eq(_run(eng, ids, src, lang), ref)
+        eng.set_option("max_chunk_tokens", 1 << 22)
+        eng.set_option("attention_fast", 0)                  # the generic loop under the packed mapping
+        slow = _run(eng, ids, src, lang)
+        eng.set_option("attention_pack", 0)
+        assert _eq(_run(eng, ids, src, lang), slow)
+        eng.set_option("attention_pack", 1)
+        eng.set_option("attention_fast", 1)
+        parts = [_run(eng, ids[slice(*shard_bounds(len(ids), 3, r))], src, lang) for r in range(3)]
+        assert _eq([None if parts[0][k] is None else torch.cat([p[k] for p in parts]) for k in range(3)], ref)
+        eng.set_option("ln_rows8", 0)
+        old = _run(eng, ids, src, lang)
+        parts = [_run(eng, ids[slice(*shard_bounds(len(ids), 3, r))], src, lang) for r in range(3)]
+        assert _eq([None if parts[0][k] is None else torch.cat([p[k] for p in parts]) for k in range(3)], old)
+        for a, b in zip(old, ref):
+            if a is not None and a.dim() == 2:
+                assert float((a - b).norm() / a.norm()) < (2e-4 if precision == "f16" else 2e-3)
+        if precision == "f16":
+            from bench import device_weights
+            w = {k: v.float().cpu().numpy() for k, v in device_weights(cfg, torch.device("cuda:0"), seed=6).items()}
+            want = hypernet_ref.forward(w, cfg, ids, src_np, None if lang < 0 else lang)
+            keep = ~util.all_pad_rows(cfg, ids)
+            for out in (ref, old):
+                for g, r in zip(out, want):
+                    if g is not None and r is not None:
+                        util.CLOSE["f16"](g.cpu().numpy()[keep], r[keep], f"H={hidden} narrow row kernels")

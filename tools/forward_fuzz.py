@@ -45,6 +45,13 @@ def case(seed):
     # r5: the 128x256 HALF tile (0 never, 1 where the launcher finds it cheaper, 2 every launch cut in the middle, 3 half tiles only).
     # Drawn from its own generator so that the cases of the earlier campaigns stay what they were.
     opts["gemm_tail_split"] = int(np.random.default_rng(515000 + seed).choice([0, 1, 1, 2, 3]))
+    # r6: the 16-bit hoisted table (the ProjectorBlock's LayerNorm folded into the embeddings' kernel; with the 16-bit stream only)
+    r6 = np.random.default_rng(616000 + seed)
+    opts["table_lo"] = int(r6.choice([0, 1, 1]))
+    # r6: the narrow-row kernels (LayerNorm launches with eight columns per lane; a narrow last column group of the attention kernel
+    # as several rows per wave)
+    opts["ln_rows8"] = int(r6.choice([0, 1, 1]))
+    opts["attention_pack"] = int(r6.choice([0, 1, 1]))
     if rng.random() < 0.3:
         opts["max_chunk_tokens"] = int(rng.choice([1024, 2048, 5000]))
     if rng.random() < 0.3:

@@ -74,6 +74,20 @@ def _object_stale(src: str, obj: str) -> bool:
     return any(os.path.getmtime(p) > built for p in [src, *_includes(src)])
 
 
+def remarks_path(source_name: str) -> str:
+    """where build() keeps hipcc's -Rpass-analysis=kernel-resource-usage output of one translation unit"""
+    return os.path.join(OBJ_DIR, source_name[:-4] + ".remarks")
+
+
+def fresh_remarks(source_name: str):
+    """The resource-usage remarks of a translation unit as the last build wrote them, or None if its sources changed since."""
+    src, path = os.path.join(CSRC, source_name), remarks_path(source_name)
+    if not os.path.exists(path) or _object_stale(src, path):
+        return None
+    with open(path) as f:
+        return f.read()
+
+
 LAST_BUILD = {"hipcc_commands": 0}      # what the most recent build() did (printed by __graft_entry__.build)
 
 
@@ -89,12 +103,28 @@ def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ_DIR, s[:-4] + ".o")
         objs.append(obj)
         if force or _object_stale(src, obj):
-            todo.append([hipcc, *HIPCC_FLAGS, "-c", src, "-o", obj])
+            todo.append([hipcc, *HIPCC_FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
             print("[zett_amd.build]", " ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True, cwd=CSRC)
+        if "-c" not in cmd:
+            subprocess.run(cmd, check=True, cwd=CSRC)
+            return
+        # the compiler's per-kernel resource-usage remarks (registers, LDS, scratch) of this translation unit are kept beside its
+        # object: tests/test_host_logic.py::test_no_product_kernel_uses_scratch reads them instead of compiling everything again
+        out = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+        if out.returncode != 0:
+            sys.stderr.write(out.stderr)
+            raise subprocess.CalledProcessError(out.returncode, cmd)
+        if verbose and ("warning:" in out.stderr or "error:" in out.stderr):          # (the remarks and their source-context lines stay in the file)
+            import re
+            other = [l for l in out.stderr.splitlines() if "remark:" not in l and l.strip() and not re.match(r"^\s*(\d+\s*)?\|", l)]
+            sys.stderr.write("\n".join(other) + "\n")
+        name = os.path.basename(cmd[cmd.index("-c") + 1])
+        with open(remarks_path(name) + ".tmp", "w") as f:
+            f.write(out.stderr)
+        os.replace(remarks_path(name) + ".tmp", remarks_path(name))
 
     jobs = jobs or int(os.environ.get("ZETT_BUILD_JOBS", "0")) or min(len(todo) or 1, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:

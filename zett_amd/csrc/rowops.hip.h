@@ -526,6 +526,145 @@ template <typename T> __device__ __forceinline__ void store8_16bit(T* p, const f
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&o)[8]) { store8_16bit<bf16_t>(p, o); }
 template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&o)[8]) { store8_16bit<f16_t>(p, o); }
 
+// ---- narrow rows (r6): layernorm_rows_kernel for 16-bit operand types and H <= 2048, EIGHT columns per lane -------------------
+// The one-wave-per-row instantiation above (TPR = 64, float4 / 8-byte accesses) is latency-bound on the narrow hypernets: at
+// H = 768 a wave has 1.5 KB in flight and four waves fit a SIMD (106 VGPRs) — 1.8 TB/s on XLM-R's embeddings launch.  Here a lane
+// takes 8 consecutive columns (16-byte accesses on the 16-bit side, two float4 on the fp32 side) and a row takes TPR = 32 lanes
+// for H <= 1024 (two rows per wave) or 64 for H <= 2048: H = 8 * TPR * NV with NV <= 4 vectors per lane.  Element for element the
+// arithmetic of layernorm_rows_kernel (the same load / ln_affine / emit expressions); only the ORDER in which a row's values are
+// added up for its mean and variance differs (8 per lane, then a butterfly over TPR lanes).
+template <int TPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = TPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// lanes per row of layernorm_rows8_kernel for rows of H columns, or 0: the row does not fit (H = 8 * TPR * NV, NV <= 4)
+inline int ln_rows8_tpr(int H) {
+    if (H % 256 == 0 && H <= 1024) return 32;
+    if (H % 512 == 0 && H <= 2048) return 64;
+    return 0;
+}
+
+template <typename T, bool EMBED, int TPR, bool READOUT>
+__global__ __launch_bounds__(256) void layernorm_rows8_kernel(const float* __restrict__ in, int ld_in, int rows, int H,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              float* __restrict__ out_f32, T* __restrict__ out_lo,
+                                                              float* __restrict__ stats_out, float* __restrict__ sum_out,
+                                                              LnEmbed emb, int tok0, LnReadout readout) {
+    static_assert(sizeof(T) == 2 && (TPR == 32 || TPR == 64), "16-bit operand types, 32 or 64 lanes per row");
+    constexpr int NVMAX = 4;
+    const int r = blockIdx.x * (256 / TPR) + (int)threadIdx.x / TPR;
+    if (r >= rows) return;                 // (a lane group leaves: the reductions below stay inside a group)
+    const int nv = H / (8 * TPR);          // vectors of 8 columns per lane, <= NVMAX (the launcher checks)
+    const int tid = threadIdx.x % TPR;
+    const float* x = nullptr;
+    const float* posr = nullptr;
+    bool is_lang = false;
+    int ro = r;
+    const T* tbl_lo = nullptr;
+    float2 tbl_st = make_float2(0.f, 1.f);
+    if constexpr (EMBED) {
+        const int slot = emb.tok_slot[tok0 + r];
+        is_lang = slot < 0;
+        if (emb.table_lo && !is_lang) {
+            tbl_lo = (const T*)emb.table_lo + (size_t)slot * H;
+            tbl_st = *(const float2*)(emb.table_stats + 2 * (size_t)slot);
+            x = emb.lang;                  // (not read)
+        } else
+        x = is_lang ? emb.lang : emb.table + (size_t)slot * H;
+        posr = emb.pos_emb + (size_t)emb.tok_pos[tok0 + r] * H;
+        if (emb.tok_row) {
+            const int n = emb.tok_row[tok0 + r];
+            ro = chunk_row(r, (int)(n - emb.row0), emb.row_offset[n] == tok0 + r, emb.rows);
+        }
+    } else {
+        x = in + (size_t)r * ld_in;
+    }
+    auto load = [&](int c, float (&a)[8]) {          // the 8 values of columns [c, c + 8)
+        bool have = false;
+        if constexpr (READOUT) {
+            if (readout.in_lo) { load8<T>((const T*)readout.in_lo + (size_t)r * ld_in + c, a); have = true; }
+        }
+        if constexpr (EMBED) {
+            if (tbl_lo) {          // a row of the 16-bit table, normalised on the fly
+                load8<T>(tbl_lo + c, a);
+                float g[8], b[8];
+                load8<float>(emb.table_gamma + c, g);
+                load8<float>(emb.table_beta + c, b);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = ln_affine(a[k], tbl_st.x, tbl_st.y, g[k], b[k]);
+                have = true;
+            }
+        }
+        if (!have) load8<float>(x + c, a);
+        if constexpr (EMBED) {
+            float t0[8], p[8];
+            load8<float>(emb.type0 + c, t0);
+            load8<float>(posr + c, p);
+            if (is_lang) {   // lang -= type0 + pos[L]   (then the embeddings add them back)
+                float pl[8];
+                load8<float>(emb.pos_emb + (size_t)emb.lang_pos * H + c, pl);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] -= (t0[k] + pl[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = (a[k] + t0[k]) + p[k];
+        }
+    };
+    float v[NVMAX][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVMAX; ++j) {
+        if (j < nv) {
+            load((tid + TPR * j) * 8, v[j]);
+            s += ((v[j][0] + v[j][1]) + (v[j][2] + v[j][3])) + ((v[j][4] + v[j][5]) + (v[j][6] + v[j][7]));
+        }
+    }
+    const float mean = group_sum<TPR>(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVMAX; ++j) {
+        if (j < nv) {
+            float d[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { d[k] = v[j][k] - mean; d[k] *= d[k]; }
+            q += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+        }
+    }
+    const float var = group_sum<TPR>(q) / (float)H;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (stats_out && tid == 0) *(float2*)(stats_out + 2 * (size_t)ro) = make_float2(mean, rstd);
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVMAX; ++j) {
+        if (j < nv) {
+            const int c = (tid + TPR * j) * 8;
+            float g[8], b[8], o[8];
+            load8<float>(gamma + c, g);
+            load8<float>(beta + c, b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = ln_affine(v[j][k], mean, rstd, g[k], b[k]);
+            if (EMBED && sum_out) store8<float>(sum_out + (size_t)ro * H + c, v[j]);
+            if (out_f32) store8<float>(out_f32 + (size_t)ro * H + c, o);
+            if (out_lo) store8<T>(out_lo + (size_t)ro * H + c, o);
+            if (READOUT && readout.bias_w) {
+                float w[8];
+                load8<float>(readout.bias_w + c, w);
+                dot += ((o[0] * w[0] + o[1] * w[1]) + (o[2] * w[2] + o[3] * w[3])) + ((o[4] * w[4] + o[5] * w[5]) + (o[6] * w[6] + o[7] * w[7]));
+            }
+        }
+    }
+    if constexpr (READOUT) {
+        if (readout.out_bias) {
+            const float tot = group_sum<TPR>(dot);
+            if (tid == 0) readout.out_bias[r] = readout.bias_w ? tot + readout.bias_b[0] : 0.f;
+        }
+    }
+}
+
 // ---- fast path of the attention kernel (16-bit operands, rows of at most ATT_FAST_KEYS packed positions: every row of the
 // BASELINE workloads, hn_surface_maxlen 7 + language token) ----------------------------------------------------------------
 // (r4) The generic loop below walks (query, key) pairs one after the other: a K and a V load, a shuffle reduction through the
@@ -569,6 +708,26 @@ __device__ __forceinline__ float head_sum(float s, int lph) {
     return s;
 }
 
+// How the (row, 512-column group) work of the attention kernel maps to waves: `full` waves of one row and one whole group each
+// (full_groups per row), then — `pack`, and the last group is 256 / 128 / 64 columns wide — waves that take that group of
+// 64 / lanes_per_row rows at a time; otherwise the partial group is one more "full" wave per row with idle lanes.
+struct AttentionWaves { int64_t total, full; int full_groups, lanes_per_row; };
+__host__ __device__ inline AttentionWaves attention_waves(int rows, int H, bool pack) {
+    const int rem = H & 511, gfull = H >> 9;
+    AttentionWaves a;
+    if (pack && (rem == 256 || rem == 128 || rem == 64)) {
+        a.full_groups = gfull; a.lanes_per_row = rem >> 3;
+        a.full = (int64_t)rows * gfull;
+        const int per = 64 / a.lanes_per_row;
+        a.total = a.full + (rows + per - 1) / per;
+    } else {
+        a.full_groups = (H + 511) >> 9; a.lanes_per_row = 64;
+        a.full = (int64_t)rows * a.full_groups;
+        a.total = a.full;
+    }
+    return a;
+}
+
 // Rows of q / k / v / ctx are BUFFER rows (position 0 first, chunk_row above); the plan arrays are indexed by packed position.
 // q: [T, ldq] per packed position, or (cls_only) [rows, ldq] holding the query of position 0
 // of each row; k, v: [T, ldkv]; ctx: [T or rows, H].  cls_only: compute query 0 only and
@@ -580,16 +739,33 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
                                                              const int32_t* __restrict__ row_offset,
                                                              const uint8_t* __restrict__ row_uniform,
                                                              const uint8_t* __restrict__ tok_key, int64_t row0,
-                                                             int rows, int tok0, float scaling, int flags /* bit 0: cls_only, bit 1: fast path on */,
+                                                             int rows, int tok0, float scaling, int flags /* bit 0: cls_only, bit 1: fast path on, bit 2: pack a narrow last group */,
                                                              const int32_t* __restrict__ tok_pair, T* __restrict__ ctx) {
     const int cls_only = flags & 1;
-    const int groups = (H + 511) >> 9;
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= (int64_t)rows * groups) return;
-    const int rl = (int)(w / groups), grp = (int)(w % groups);
-    const int col = grp * 512 + lane * 8;
-    const bool active = col < H;
+    // (r6) a last column group of 256 / 128 / 64 columns (H = 768: the XLM-R shape) used to leave half or more of its wave's
+    // lanes idle; with flag bit 2 such a wave takes that group of 2 / 4 / 8 ROWS instead (`lpr` lanes per row, `base` = the first
+    // lane of this lane's row).  Everything per row below (t0, t1, the key mask, the pair slots) is then per lane group; heads
+    // never straddle a group (the group's width is a multiple of head_dim), so the head sums stay inside it.  Same arithmetic
+    // per element: same bits.
+    const AttentionWaves aw = attention_waves(rows, H, (flags & 4) != 0);
+    if (w >= aw.total) return;
+    int rl, grp, li = lane, base = 0, lpr = 64;
+    bool valid = true;
+    if (w < aw.full) { rl = (int)(w / aw.full_groups); grp = (int)(w % aw.full_groups); }
+    else {
+        lpr = aw.lanes_per_row;
+        const int sub = lane / lpr;
+        li = lane - sub * lpr;
+        base = sub * lpr;
+        rl = (int)(w - aw.full) * (64 / lpr) + sub;
+        grp = aw.full_groups;
+        valid = rl < rows;
+        if (!valid) rl = rows - 1;                     // (a lane group past the last row repeats it and stores nothing)
+    }
+    const int col = grp * 512 + li * 8;
+    const bool active = valid && col < H;
     const int lph = head_dim >> 3;                     // lanes per head (power of two)
     const int64_t n = row0 + rl;
     const int t0 = row_offset[n] - tok0, t1 = row_offset[n + 1] - tok0;
@@ -605,17 +781,17 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
     //  hn_surface_maxlen >= 64 is legal, max_positions is 514 — reads the slots past the 64th directly: t is
     //  wave-uniform, so the branch is too)
     int pslot = 0;
-    if (tok_pair) { const int t = t0 + lane; pslot = t < t1 ? tok_pair[tok0 + t] : 0; }
+    if (tok_pair) { const int t = t0 + li; pslot = t < t1 ? tok_pair[tok0 + t] : 0; }
     auto qrow = [&](int t) -> size_t {
         if (!tok_pair) return brow(t);
-        return t - t0 < 64 ? (size_t)__shfl(pslot, t - t0, 64) : (size_t)tok_pair[tok0 + t];
+        return t - t0 < lpr ? (size_t)__shfl(pslot, base + (t - t0), 64) : (size_t)tok_pair[tok0 + t];
     };
     const int nk = t1 - t0;
     if constexpr (sizeof(T) == 2) {
         if (nk <= ATT_FAST_KEYS && (flags & 2)) {
             // which keys count: lane j asks for key j, the answer is a wave-uniform bit mask
-            const bool mine = lane < nk && (uniform || tok_key[tok0 + t0 + lane] != 0);
-            const unsigned on = (unsigned)__ballot(mine);
+            const bool mine = li < nk && (uniform || tok_key[tok0 + t0 + li] != 0);
+            const unsigned on = (unsigned)(__ballot(mine) >> base) & (lpr >= 32 ? 0xffffffffu : ((1u << lpr) - 1u));
             uint4 kk[ATT_FAST_KEYS], vv[ATT_FAST_KEYS], qq[ATT_FAST_KEYS];
 #pragma unroll
             for (int j = 0; j < ATT_FAST_KEYS; ++j) {
@@ -714,12 +890,31 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
 // (r6: a version with four threads per row — every fourth partial each, combined through LDS — was 2-3 x faster on a 12-16 us kernel
 //  and changed the summation order: bf16 mode, which sits ON its 1e-2 tolerance, went from 0.99e-2 to 1.002e-2 on the Llama-3 sample.
 //  The sequential order of rounds 3-5 stays.)
-__global__ void ln_stats_kernel(const float2* __restrict__ part, int parts, int ld_part, int rows, int H, float eps,
-                                float* __restrict__ stats) {
+// (r6, second version: the partials of a row are still ADDED in their sequential order — same bits — but FETCHED eight at a time:
+//  the loop of rounds 3-5 waited for every load before it issued the next, 32 dependent round trips at H = 4096.  64-thread
+//  workgroups, so that a 4 096-row shard's 9.7 k rows reach 150 CUs instead of 38.)
+__global__ __launch_bounds__(64) void ln_stats_kernel(const float2* __restrict__ part, int parts, int ld_part, int rows, int H, float eps,
+                                                      float* __restrict__ stats) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     float s = 0.f, q = 0.f;
-    for (int p = 0; p < parts; ++p) { const float2 v = part[(size_t)p * ld_part + r]; s += v.x; q += v.y; }
+    const float2* col = part + r;
+    int p = 0;
+    for (; p + 8 <= parts; p += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = col[(size_t)(p + j) * ld_part];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s += v[j].x; q += v[j].y; }
+    }
+    {
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p + j < parts ? col[(size_t)(p + j) * ld_part] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (p + j < parts) { s += v[j].x; q += v[j].y; }
+    }
     const float mean = s / (float)H;
     const float var = fmaxf(q / (float)H - mean * mean, 0.f);
     *(float2*)(stats + 2 * (size_t)r) = make_float2(mean, 1.0f / sqrtf(var + eps));

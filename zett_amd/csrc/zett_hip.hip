@@ -82,9 +82,11 @@ struct zett_hypernet {
     hipStream_t lane_stream = nullptr;
     hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};      // fork, lane 1: bias written / out_in written / done
     int attention_fast = 1;           // rows of <= 8 packed positions: keys / values fetched once, all keys of a query side by side (rowops.hip.h)
+    int attention_pack = 1;           // a last column group of 256 / 128 / 64 columns (H = 768) takes 2 / 4 / 8 rows per wave instead of idle lanes (r6; same bits)
     int gemm_tail_split = 1;          // gemm4d: a launch's partly filled last round of 256 CUs as 128x256 tiles (gemm4d.hip.h gemm4d_row_split): 0 never,
                                       // 1 when the split is cheaper (default), 2 = cut every launch in the middle, 3 = half tiles only (tests: same bits)
     int gemm_tile_order = 0;          // gemm4d: 0 = column-tile-major groups, 1 = row-tile-major groups (A/B)
+    int ln_rows8 = 1;                 // 16-bit modes, H <= 2048: LayerNorm launches on layernorm_rows8_kernel (eight columns per lane; rowops.hip.h); 0 = the float4 kernel (A/B)
     int table_lo = 1;                 // 16-bit hoisted table with the ProjectorBlock's LayerNorm folded into the embeddings' kernel (with the 16-bit residual stream); 0 = fp32 table (A/B)
     int gemm_group = 0;               // gemm4d: column (order 0) / row (order 1) tiles per group; 0 = the kernel's default, 4 (A/B)
     int gemm4d_min_k = 512;           // 16-bit launches with K >= this take the four-wave direct-to-LDS tile (r2: with the streamlined epilogues it is ahead of gemm8r down to K = 768: +1.8 % on the XLM-R workload)
@@ -589,6 +591,10 @@ int zett_set_option(zett_hypernet* h, const char* key, int64_t value) {
     } else if (k == "gemm_tail_split") {
         if (value < 0 || value > 3) return fail(ZETT_E_INVALID, "gemm_tail_split must be 0 (never), 1 (auto), 2 (cut every gemm4d launch in the middle) or 3 (128x256 tiles only)");
         h->gemm_tail_split = (int)value;
+    } else if (k == "attention_pack") {
+        h->attention_pack = value != 0;
+    } else if (k == "ln_rows8") {
+        h->ln_rows8 = value != 0;
     } else if (k == "table_lo") {
         h->table_lo = value != 0;
     } else if (k == "gemm_group") {
@@ -890,6 +896,19 @@ struct Runner {
         if (rc || rows <= 0) return;
         readout.in_lo = in_lo;          // (16-bit residual stream: the rows are read from the 16-bit copy of the sum; READOUT instantiations only)
         const int H = h->cfg.hidden;
+        // (r6) 16-bit modes, narrow rows: eight columns per lane, 32 lanes per row up to H = 1024 (two rows per wave), 64 up to 2048
+        if constexpr (sizeof(T) == 2) {
+            const int tpr8 = h->ln_rows8 ? ln_rows8_tpr(H) : 0;
+            if (tpr8) {
+                const dim3 grid8((rows + 256 / tpr8 - 1) / (256 / tpr8));
+#define ZETT_LN8_LAUNCH(TPR, RO) hipLaunchKernelGGL((layernorm_rows8_kernel<T, false, TPR, RO>), grid8, dim3(256), 0, st, in, H, rows, H, gamma, beta, eps, of, ol, stats, (float*)nullptr, LnEmbed{}, 0, readout)
+                if (readout.out_bias) { if (tpr8 == 32) ZETT_LN8_LAUNCH(32, true); else ZETT_LN8_LAUNCH(64, true); }
+                else { if (tpr8 == 32) ZETT_LN8_LAUNCH(32, false); else ZETT_LN8_LAUNCH(64, false); }
+#undef ZETT_LN8_LAUNCH
+                check("layernorm");
+                return;
+            }
+        }
         const dim3 grid = H <= 2048 ? dim3((rows + 3) / 4) : dim3(rows);      // H <= 2048: a wave per row, four rows per workgroup
 #define ZETT_LN_LAUNCH(TPR, RO) hipLaunchKernelGGL((layernorm_rows_kernel<T, false, TPR, RO>), grid, dim3(256), 0, st, in, H, rows, H, gamma, beta, eps, of, ol, stats, (float*)nullptr, LnEmbed{}, 0, readout)
         if (readout.out_bias) { if (H <= 2048) ZETT_LN_LAUNCH(64, true); else ZETT_LN_LAUNCH(256, true); }
@@ -901,7 +920,7 @@ struct Runner {
     // LayerNorm fold: (mean, rstd) per row from the partials the producer GEMM wrote
     void ln_stats(const float2* parts, int ld_part, int rows, float eps, float* stats) {
         if (rc || rows <= 0) return;
-        hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, parts, h->cfg.hidden / 128, ld_part, rows,
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, parts, h->cfg.hidden / 128, ld_part, rows,
                            h->cfg.hidden, eps, stats);
         check("ln_stats");
     }
@@ -1078,7 +1097,6 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     // only (modeling_hypernet.py:234) — is then the first `rows` rows of every buffer, with no gather in between.
     const float* lang_vec = lam ? R.Wf("lang_embeddings.weight") + (size_t)lang_index * H : nullptr;
     const float scaling = 1.0f / std::sqrt((float)(H / c.heads));
-    const int groups = (H + 511) / 512;
     // One chunk = vocabulary rows [r0, r1) on one LANE: a stream and a slice of every workspace buffer starting `off` rows in.
     // Normally there is one lane (the caller's stream, offset 0) and the chunks follow each other.  A call that is ONE chunk
     // can instead run as two half-vocabulary chunks on two lanes at once (r4, "concurrent_lanes"): rows are independent, so the
@@ -1117,6 +1135,20 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
         const float* hs_gamma = R.Wf("model.embeddings.LayerNorm.weight");
         const float* hs_beta = R.Wf("model.embeddings.LayerNorm.bias");
         auto embed_ln = [&](const LnEmbed& e, int n, int t0, T* lo, float* stats, float* sum) {
+            if constexpr (sizeof(T) == 2) {
+                const int tpr8 = h->ln_rows8 ? ln_rows8_tpr(H) : 0;
+                if (tpr8) {
+                    const dim3 grid8((n + 256 / tpr8 - 1) / (256 / tpr8));
+                    if (tpr8 == 32)
+                        hipLaunchKernelGGL((layernorm_rows8_kernel<T, true, 32, false>), grid8, dim3(256), 0, st, (const float*)nullptr, H, n, H,
+                                           hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, lo, stats, sum, e, t0, LnReadout{});
+                    else
+                        hipLaunchKernelGGL((layernorm_rows8_kernel<T, true, 64, false>), grid8, dim3(256), 0, st, (const float*)nullptr, H, n, H,
+                                           hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, lo, stats, sum, e, t0, LnReadout{});
+                    R.check("embed_layernorm");
+                    return;
+                }
+            }
             if (H <= 2048)
                 hipLaunchKernelGGL((layernorm_rows_kernel<T, true, 64>), dim3((n + 3) / 4), dim3(256), 0, st, (const float*)nullptr, H, n, H,
                                    hs_gamma, hs_beta, c.ln_eps_encoder, (float*)nullptr, lo, stats, sum, e, t0, LnReadout{});
@@ -1158,7 +1190,8 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
             const T* wqkv = raw ? (const T*)h->fold_qkv[l].w : (const T*)h->qkv_w[l];
             const float* bqkv = raw ? h->fold_qkv[l].b : h->qkv_b[l];
             const float* cqkv = raw ? h->fold_qkv[l].c : nullptr;
-            const int64_t waves = (int64_t)rows * groups;
+            const int64_t waves = attention_waves(rows, H, h->attention_pack != 0).total;
+            const int att_flags = (h->attention_fast ? 2 : 0) | (h->attention_pack ? 4 : 0);
             if (!cls_only) {
                 const bool by_pair = pairs && l == 0;       // Zt holds the P pair rows; BIG gets their Q/K/V
                 GemmEpilogue<T> eq = R.epi();
@@ -1167,7 +1200,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 R.gemm(Zt, H, wqkv, H, by_pair ? P : m, 3 * H, H, eq);
                 hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                                    (const T*)BIG, (size_t)3 * H, (const T*)BIG + H, (const T*)BIG + 2 * H, (size_t)3 * H,
-                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 0 | (h->attention_fast ? 2 : 0),
+                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 0 | att_flags,
                                    by_pair ? (const int32_t*)p.tok_pair : (const int32_t*)nullptr, CTX);
                 R.check("attention");
             } else {
@@ -1186,7 +1219,7 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
                 R.gemm(Zt, H, wqkv, H, rows, H, H, eq);
                 hipLaunchKernelGGL((attention_rows_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                                    (const T*)Q, (size_t)H, (const T*)KV, (const T*)KV + H, (size_t)2 * H,
-                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 1 | (h->attention_fast ? 2 : 0),
+                                   H, H / c.heads, p.row_offset, p.row_uniform, p.tok_key, r0, rows, tok0, scaling, 1 | att_flags,
                                    (const int32_t*)nullptr, CTX);
                 R.check("attention(position 0)");
                 zrows = rows;
