@@ -293,6 +293,29 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
         raise SystemExit("a retokenized surface form was truncated")
     st = engine.stats()
     flags = engine.range_flags()
+    # the same steps as a caller runs them: without the per-launch HIP events and the stream sync that reads them at the end of
+    # every forward (on the narrow workloads the instrumentation is 2-3 % of a step)
+    engine.set_option("time_gemm", 0)
+
+    def plain():
+        sfm = retok.run_async(d_text, d_off, n_tok, seq_len)
+        if affinity:
+            order = affinity_order(sfm, shard_of, dims.pad_token_id, n_ids, chunks=1)
+            sfm = sfm.index_select(0, torch.cat([order[b.lo:b.hi] for b in blocks]))
+        return engine.forward(sfm, src, lang)
+
+    keep = None
+    for _ in range(warmup):
+        keep = plain()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        keep = plain()
+    torch.cuda.synchronize()
+    ms_plain = (time.perf_counter() - t2) / steps * 1e3
+    del keep
+    retok.result()
+    engine.set_option("time_gemm", 1)
     tf = acc["gemm_flops_timed"] / (acc["gemm_ms"] * 1e-3) / 1e12 if acc["gemm_ms"] > 0 else 0.0
     by = sum(v[3] for v in classes.values())
     tbs = by / (acc["gemm_ms"] * 1e-3) / 1e12 if acc["gemm_ms"] > 0 else 0.0
@@ -326,7 +349,7 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
         del bufs, outs
     res = {"workload": workload + (f" (rank 0 of {shard_of}: {n} of {vocab_rows} rows, {partition} shards)" if shard_of else ""), "rows": n, "dtype": precision,
            "partition": partition if shard_of else None, "unpermute_ms": unpermute_ms,
-           "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "value": n * steps / dt, "unit": "token-embeddings/s",
+           "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "ms_per_step_uninstrumented": ms_plain, "value": n * steps / dt, "unit": "token-embeddings/s",
            "packed_tokens": st["packed_tokens"], "distinct_source_ids": st["distinct_ids"], "distinct_id_position_pairs": st["distinct_positions"],
            "range_flags": flags,
            "roofline": {"bound": "mfma" if (acc["gemm_flops_timed"] / by if by else 1e9) >= RIDGE_FLOP_PER_BYTE else "mfma/hbm (launch intensity under the ridge)",
@@ -551,6 +574,8 @@ def compact_line(result, limit=LINE_LIMIT):
             name = str(c.get("workload", "")).split(" (")[0]
             e = {"workload": name, "rows": c.get("rows"), "ms_per_step": _r(c.get("ms_per_step"), 4), "frac": _r(r.get("frac"), 3), "hbm_frac": _r(r.get("hbm_frac"), 3),
                  "gemm_ms": _r(r.get("gemm_ms_per_step"), 4)}
+            if c.get("ms_per_step_uninstrumented") is not None:          # (the same steps without the per-launch HIP events)
+                e["ms_uninstrumented"] = _r(c["ms_per_step_uninstrumented"], 4)
             if c.get("partition"):
                 e["shard"] = f"rank 0 of 8, {c['partition']}"
                 if c.get("unpermute_ms") is not None:
