@@ -239,7 +239,13 @@ int zett_workspace_bytes(const zett_hypernet* h, int64_t n_rows, int32_t seq, in
  * tiles fill R whole rounds of the 256 CUs and part of one more is cut into 256x256 tiles on the rows of the whole rounds and
  * 128x256 tiles — twice as many workgroups of half the work — on the rest, when that is cheaper (a rank's 4 096-row shard at
  * 8 GPUs: M = 9 682, N = 4096 is 2.375 rounds); 0 = never, 2 = cut every launch in the middle, 3 = 128x256 tiles only (tests);
- * same bits). */
+ * same bits), "table_lo" (0/1, default 1, round 6: with the 16-bit residual stream the hoisted input-projection table is kept as
+ * the 16-bit copy of its pre-LayerNorm sum + (mean, rstd) per distinct id and normalised by the embeddings' kernel as it reads a
+ * row; 0 = the fp32 table; one 16-bit rounding apart), "ln_rows8" (0/1, default 1, round 6: LayerNorm launches of the 16-bit
+ * modes at hidden sizes of 256 k <= 1024 / 512 k <= 2048 give a lane eight columns and a row 32 / 64 lanes; 0 = the float4
+ * kernel; the row sums are added in another order, results differ by rounding), "attention_pack" (0/1, default 1, round 6: a
+ * last group of 256 / 128 / 64 hidden columns of the attention kernel — hidden size 768 — takes 2 / 4 / 8 rows per wave instead
+ * of leaving lanes idle; same bits). */
 int zett_set_option(zett_hypernet* h, const char* key, int64_t value);
 
 /* ---- id-affinity row partition (ABI 6) ----------------------------------------------
