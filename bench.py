@@ -543,6 +543,8 @@ def compact_line(result, limit=LINE_LIMIT):
     out["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch",
                                   "launches_per_step", "gemm_ms_per_step", "executed_tflop_per_step"))
     out["roofline"]["kernel"] = "zett::gemm4d_tn_kernel (+gemm8r/384x256/128x128 tiles): all GEMM launches, FLOP-weighted"
+    if "ONE untimed" in str(rf.get("source", "")):          # an N > 1 line: the timed steps carry no per-launch events
+        out["roofline"]["source"] = "one untimed instrumented pass over rank 0's row blocks after the timed region"
     ts = rf.get("traffic_source") or {}
     out["roofline"]["traffic_live"] = bool(ts.get("live")) if ts else None
     if ts.get("stale"):
@@ -865,16 +867,35 @@ def main():
         dt = float(t.item())
         # untimed: the gathered matrix must hold this rank's rows bit for bit (rows are shard-independent)
         ids_dev = torch.from_numpy(ids_all).to(device) if affinity else None
+        # the same untimed pass measures this rank's GEMM launches with per-launch HIP events (kept out of the timed steps: the sync that
+        # reads them would serialise the overlap of exchange and forward): the roofline figure of an N > 1 line
+        post = {"gemm_ms": 0.0, "gemm_flops_timed": 0.0, "gemm_launches": 0}
+        post_classes = {}
+        engine.set_option("time_gemm", 1)
         for b, ids_b in zip(blocks, ids_blocks):
             mine = step.order[b.lo:b.hi] if affinity else None
             chk = engine.forward(ids_dev.index_select(0, mine) if affinity else ids_b, src, lang_arg)          # `ids_b` == the retokenized matrix (checked above)
+            st_k = engine.stats()
+            for key in post:
+                post[key] += st_k[key]
+            for r in engine.gemm_log():
+                c = post_classes.setdefault(launch_class(r), [0, 0.0, 0.0, 0.0])
+                c[0] += 1; c[1] += r["ms"]; c[2] += r["flops"]; c[3] += r["bytes"]
             for full, loc in zip(out, chk):
                 if full is not None and not torch.equal(full.index_select(0, mine) if affinity else full[b.lo:b.hi], loc):
                     raise SystemExit(f"rank {rank}: all-gathered rows [{b.lo}, {b.hi}) differ from the local forward")
+        engine.set_option("time_gemm", 0)
     st = engine.stats()
 
     ms_per_step = dt / args.steps * 1e3
     value = rows * args.steps / dt
+    roofline_steps = args.steps
+    roofline_source = "per-launch HIP events of the timed steps"
+    if exchange and gemm_ms <= 0 and post["gemm_ms"] > 0:
+        gemm_ms, gemm_fl, launches = post["gemm_ms"], post["gemm_flops_timed"], post["gemm_launches"]
+        timed_classes = {k: list(v) for k, v in post_classes.items()}
+        roofline_steps = 1
+        roofline_source = "per-launch HIP events of ONE untimed pass over this rank's row blocks after the timed region (rank 0; the timed steps run without events)"
     achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.precision]
 
@@ -922,11 +943,11 @@ def main():
                             else "id matrix -> hypernet forward [A/B: --no-retokenize]") + ("" if world == 1 else " -> all-gather")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak if peak else None, "traffic": traffic,
-                     "kernel": "zett::gemm4d_tn_kernel (256x256 four-wave direct-to-LDS MFMA GEMM on 16x16x32 MFMAs: every 16-bit launch with K >= 512; its epilogues carry bias / GELU / residual and, with the LayerNorm fold, the encoder's LayerNorms), zett::gemm8r_tn_kernel (256x256 register-staged: shorter K and fp32 mode), 384x256 / 128x128 tiles where wave quantisation / small shapes call for them: all GEMM launches, FLOP-weighted", "launches_per_step": launches / max(args.steps, 1),
+                     "kernel": "zett::gemm4d_tn_kernel (256x256 four-wave direct-to-LDS MFMA GEMM on 16x16x32 MFMAs: every 16-bit launch with K >= 512; its epilogues carry bias / GELU / residual and, with the LayerNorm fold, the encoder's LayerNorms), zett::gemm8r_tn_kernel (256x256 register-staged: shorter K and fp32 mode), 384x256 / 128x128 tiles where wave quantisation / small shapes call for them: all GEMM launches, FLOP-weighted", "launches_per_step": launches / max(roofline_steps, 1), "source": roofline_source,
                      "note": ("the GEMM launches also carry the encoder's LayerNorms (LayerNorm fold, DESIGN.md section 4): same box with --no-ln-fold, "
                               "frac +0.01 and ms_per_step +0.9" if (args.precision != "f32" and not args.no_ln_fold) else "no LayerNorm fold in this run"),
-                     "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
-                     "executed_tflop_per_step": gemm_fl / max(args.steps, 1) / 1e12,
+                     "gemm_ms_per_step": gemm_ms / max(roofline_steps, 1),
+                     "executed_tflop_per_step": gemm_fl / max(roofline_steps, 1) / 1e12,
                      "traffic_source": traffic_source,
                      # A and W read once, every output written once, residual rows read once, summed over the launches of the
                      # timed steps / their number: what `traffic` (a PMC measurement, when present) is to be compared with
@@ -934,7 +955,7 @@ def main():
                      "traffic_over_algorithmic": (traffic / (alg_bytes / alg_launches)) if (traffic and alg_launches) else None,
                      # the same FLOP / HIP-event-time ratio per launch class (zett_get_gemm_log), so that the fraction can be
                      # read class by class: K loops are alike, the epilogues differ
-                     "by_class": class_table(timed_classes, args.steps, peak)},
+                     "by_class": class_table(timed_classes, roofline_steps, peak)},
         # N > 1: the part of a step the compute stream spent waiting for the row exchange (HIP events around the waits in
         # RowGather.finish, this rank); the rest of the exchange ran under forwards
         "exchange_exposed_ms_per_step": (sum(x for x in exposed if x is not None) / max(len(exposed), 1)) if exchange else None,

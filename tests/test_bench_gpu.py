@@ -38,6 +38,8 @@ def test_two_ranks_on_one_device(extra):
     assert d["exchange"]["early_start_of_pred_in_and_bias"] == ("--no-early-gather" not in extra)
     assert d["exchange_exposed_ms_per_step"] is not None and 0 <= d["exchange_exposed_ms_per_step"] < d["ms_per_step"]
     assert len(lines[0].encode()) < 6000
+    # (r6) an N > 1 line has a roofline figure too: the timed steps run without per-launch events, the untimed bit-identity pass behind them with
+    assert 0 < d["roofline"]["frac"] < 1 and "untimed" in d["roofline"]["source"] and d["roofline"]["gemm_ms_per_step"] > 0
 
 
 def test_default_line_is_short_and_complete(tmp_path):
