@@ -220,7 +220,7 @@ def class_table(classes, steps, peak):
     return out
 
 
-def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0, partition="contiguous"):
+def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0, partition="contiguous", table_exchange=False):
     """One more workload of BASELINE.json on this GPU, measured AFTER the timed region of the main line and reported under
     `configs` (never `value`): the same step — surface forms resident in HBM -> GPU retokenization -> hypernet forward — with
     per-launch HIP events, `steps` steps.  shard_of = P > 0: the rows are what rank 0 of P ranks computes of the workload's
@@ -228,12 +228,17 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
     "affinity": the rank's rows are chosen by zett_amd.sharding.affinity_order instead of being a contiguous range — then every
     step retokenizes the WHOLE vocabulary (each rank needs every row's ids to compute the same order), runs the partition kernel,
     gathers its rows and runs the forward; the indexed copy that puts the gathered matrices back into vocabulary order is timed
-    on full-size buffers and reported beside it (`unpermute_ms`: local HBM traffic, the same on 8 GPUs)."""
+    on full-size buffers and reported beside it (`unpermute_ms`: local HBM traffic, the same on 8 GPUs).  table_exchange (f16): the
+    rank computes its 1/P slice of the hoisted table of the WHOLE vocabulary's distinct ids (zett_amd.sharding.SharedTable: whole-vocabulary
+    retokenization, zett_table_plan, zett_table_rows) and runs its rows on the complete table (zett_forward_table; the peers' slices were
+    computed once, untimed); the table's all-gather is NOT in the time, as no exchange is in any of these proxies — its size is reported."""
     from zett_amd.hypernet import HipEngine
     from zett_amd.sharding import affinity_order, plan_blocks
     from zett_amd.surface_forms import DeviceRetokenizer, HnTokenizerSpec
 
     affinity = bool(shard_of) and partition == "affinity"
+    table_x = bool(shard_of) and table_exchange
+    whole = affinity or table_x
     cfg, default_rows, src_dtype, hist = synth.workload(workload)
     vocab_rows = rows or default_rows
     dims = HypernetDims.from_config(cfg)
@@ -245,7 +250,7 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
     ids_all = synth.make_surface_forms(cfg, vocab_rows, seed=0, hist=hist)
     if shard_of:
         blocks = plan_blocks(vocab_rows, shard_of, 0, 1)
-        ids_np = ids_all if affinity else np.concatenate([ids_all[b.lo:b.hi] for b in blocks])
+        ids_np = ids_all if whole else np.concatenate([ids_all[b.lo:b.hi] for b in blocks])
     else:
         ids_np = ids_all
     n = int(sum(b.hi - b.lo for b in blocks)) if shard_of else int(ids_np.shape[0])
@@ -263,13 +268,30 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
     g.manual_seed(1)
     src = (0.02 * torch.randn((dims.original_vocab_size, dims.n_in_embd), device=device, generator=g)).to(getattr(torch, src_dtype))
     classes, acc = {}, {"gemm_ms": 0.0, "gemm_flops_timed": 0.0, "gemm_launches": 0}
+    table_bufs, table_bytes = None, None
+    if table_x:
+        from zett_amd.sharding import SharedTable
+        n_all, = engine.table_plan(sfm0)[2:]
+        table_bufs = engine.table_buffers(n_all + shard_of)
+        SharedTable(engine, sfm0, src, only_rank=0, world=1, buffers=table_bufs)          # the complete table, once, untimed: the peers' slices
 
-    def one():
-        sfm = retok.run_async(d_text, d_off, n_tok, seq_len)
+    def forward_rows(sfm):
+        """what rank 0 runs on the retokenized matrix `sfm` (the whole vocabulary's with an affinity order or a shared table)"""
+        nonlocal table_bytes
+        rows_sfm = sfm
         if affinity:          # the whole vocabulary's ids -> the order every rank computes -> this rank's rows
             order = affinity_order(sfm, shard_of, dims.pad_token_id, n_ids, chunks=1)
-            sfm = sfm.index_select(0, torch.cat([order[b.lo:b.hi] for b in blocks]))
-        out = engine.forward(sfm, src, lang)
+            rows_sfm = sfm.index_select(0, torch.cat([order[b.lo:b.hi] for b in blocks]))
+        elif table_x:
+            rows_sfm = sfm[blocks[0].lo:blocks[0].hi] if len(blocks) == 1 else torch.cat([sfm[b.lo:b.hi] for b in blocks])
+        if table_x:           # this rank's slice of the shared table, then its rows on the complete table
+            shared = SharedTable(engine, sfm, src, only_rank=0, world=shard_of, buffers=table_bufs)
+            table_bytes = shared.bytes_received()
+            return engine.forward_table(rows_sfm, shared.table, shared.stats, shared.id_slot, lang)
+        return engine.forward(rows_sfm, src, lang)
+
+    def one():
+        out = forward_rows(retok.run_async(d_text, d_off, n_tok, seq_len))
         st_k = engine.stats()
         for key in acc:
             acc[key] += st_k[key]
@@ -298,11 +320,7 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
     engine.set_option("time_gemm", 0)
 
     def plain():
-        sfm = retok.run_async(d_text, d_off, n_tok, seq_len)
-        if affinity:
-            order = affinity_order(sfm, shard_of, dims.pad_token_id, n_ids, chunks=1)
-            sfm = sfm.index_select(0, torch.cat([order[b.lo:b.hi] for b in blocks]))
-        return engine.forward(sfm, src, lang)
+        return forward_rows(retok.run_async(d_text, d_off, n_tok, seq_len))
 
     keep = None
     for _ in range(warmup):
@@ -349,6 +367,7 @@ def side_config(workload, rows, precision, device, steps=3, warmup=1, shard_of=0
         del bufs, outs
     res = {"workload": workload + (f" (rank 0 of {shard_of}: {n} of {vocab_rows} rows, {partition} shards)" if shard_of else ""), "rows": n, "dtype": precision,
            "partition": partition if shard_of else None, "unpermute_ms": unpermute_ms,
+           "table_exchange": bool(table_x) if shard_of else None, "table_bytes_received": table_bytes,
            "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "ms_per_step_uninstrumented": ms_plain, "value": n * steps / dt, "unit": "token-embeddings/s",
            "packed_tokens": st["packed_tokens"], "distinct_source_ids": st["distinct_ids"], "distinct_id_position_pairs": st["distinct_positions"],
            "range_flags": flags,
@@ -535,7 +554,7 @@ def compact_line(result, limit=LINE_LIMIT):
     out = {k: _r(result.get(k)) for k in top}
     cfg = result.get("config") or {}
     out["config"] = {k: (v if not isinstance(v, str) else v[:200]) for k, v in cfg.items() if k in
-                     ("workload", "rows", "rows_per_gpu", "partition", "parallelism", "precision", "packed_tokens_rank0", "distinct_source_ids_rank0",
+                     ("workload", "rows", "rows_per_gpu", "partition", "table_exchange", "parallelism", "precision", "packed_tokens_rank0", "distinct_source_ids_rank0",
                       "distinct_id_position_pairs_rank0", "hn_tokenizer") and v is not None}
     if isinstance(out["config"].get("parallelism"), str):
         out["config"]["parallelism"] = out["config"]["parallelism"].split(" (")[0]
@@ -559,7 +578,7 @@ def compact_line(result, limit=LINE_LIMIT):
             out[k] = _r(result[k])
     ex = result.get("exchange")
     if ex:
-        out["exchange"] = _pick(ex, ("mode", "backend", "one_rank_group", "early_start_of_pred_in_and_bias", "bytes_received_per_rank_per_step"))
+        out["exchange"] = _pick(ex, ("mode", "backend", "one_rank_group", "early_start_of_pred_in_and_bias", "bytes_received_per_rank_per_step", "table_bytes_received_per_rank_per_step"))
         out["exchange"]["GPU_MAX_HW_QUEUES"] = os.environ.get("GPU_MAX_HW_QUEUES")
     if result.get("alt_precision"):
         out["alt_precision"] = _pick(result["alt_precision"], ("dtype", "value", "ms_per_step", "roofline_frac"))
@@ -579,7 +598,9 @@ def compact_line(result, limit=LINE_LIMIT):
             if c.get("ms_per_step_uninstrumented") is not None:          # (the same steps without the per-launch HIP events)
                 e["ms_uninstrumented"] = _r(c["ms_per_step_uninstrumented"], 4)
             if c.get("partition"):
-                e["shard"] = f"rank 0 of 8, {c['partition']}"
+                e["shard"] = f"rank 0 of 8, {c['partition']}" + (", shared table" if c.get("table_exchange") else "")
+                if c.get("table_bytes_received"):
+                    e["table_mb_received"] = _r(c["table_bytes_received"] / 1e6, 4)
                 if c.get("unpermute_ms") is not None:
                     e["unpermute_ms"] = _r(c["unpermute_ms"], 3)
             elif name in cached.get("configs", {}):
@@ -669,6 +690,10 @@ def main():
                     help="N > 1: which rows a rank computes — contiguous ranges of the vocabulary, or the id-affinity order of zett_amd.sharding.affinity_order "
                          "(zett_partition_rows: rows that share source ids share a rank; every step then retokenizes the whole vocabulary on every rank, runs the "
                          "partition kernel, and ends with the indexed copy that puts the gathered matrices back into vocabulary order)")
+    ap.add_argument("--table-exchange", action="store_true",
+                    help="N > 1 (f16): the hoisted input-projection table is computed ONCE across the ranks (zett_amd.sharding.SharedTable, zett_table_* of ABI 8: "
+                         "every rank retokenizes the whole vocabulary, computes 1/N of the table of its distinct ids and all-gathers the slices) instead of "
+                         "per rank for the ids of its own rows; same rows, same bits")
     ap.add_argument("--no-early-gather", action="store_true", help="N > 1, A/B: start the exchange of pred_in / bias behind the whole forward instead of behind their own completion point")
     args = ap.parse_args()
 
@@ -774,6 +799,10 @@ def main():
     retok = None
     texts = []
     affinity = exchange and args.partition == "affinity"
+    table_x = exchange and args.table_exchange
+    if table_x and (args.no_retokenize or args.precision != "f16"):
+        raise SystemExit("--table-exchange shares the folded 16-bit table of the f16 mode and starts from the whole vocabulary's retokenized ids")
+    whole = affinity or table_x          # every rank retokenizes the WHOLE vocabulary
     if affinity and args.no_retokenize:
         raise SystemExit("--partition affinity orders the rows by the retokenized ids: it cannot be combined with --no-retokenize")
     seq_len = int(ids_all.shape[1])
@@ -783,7 +812,7 @@ def main():
         spec = HnTokenizerSpec.from_model_json(hn_model, ["<unk>", "<s>", "</s>"], [0, 1, 2], dims.pad_token_id)
         retok = DeviceRetokenizer(spec, device)
         # (affinity order: every rank retokenizes the WHOLE vocabulary — it needs every row's ids to compute the same order)
-        for lo, hi in ([(0, rows)] if affinity else [(b.lo, b.hi) for b in blocks]):
+        for lo, hi in ([(0, rows)] if whole else [(b.lo, b.hi) for b in blocks]):
             d_text, d_off, n_tok = retok.encode(synth.tokens_for_surface_forms(cfg, ids_all[lo:hi], piece_of_id))
             sfm0, n_trunc0 = retok.run(d_text, d_off, n_tok, seq_len)
             if n_trunc0 != 0 or not torch.equal(sfm0.cpu(), torch.from_numpy(ids_all[lo:hi])):
@@ -803,12 +832,20 @@ def main():
         # the step's id matrices: every block retokenized at the head of the step, without a host round trip
         # (zett_retokenize_async; the truncation count of all steps is asked for once, after the timed region)
         order = None
-        if affinity:
-            from zett_amd.sharding import affinity_order
+        shared = None
+        if whole:
             sfm_all = retok.run_async(*texts[0], seq_len)
-            order = affinity_order(sfm_all, world, dims.pad_token_id, dims.original_vocab_size + dims.n_extra, chunks=chunks)
-            step.order = order
-            sfms = [sfm_all.index_select(0, order[b.lo:b.hi]) for b in blocks]
+            if affinity:
+                from zett_amd.sharding import affinity_order
+                order = affinity_order(sfm_all, world, dims.pad_token_id, dims.original_vocab_size + dims.n_extra, chunks=chunks)
+                step.order = order
+                sfms = [sfm_all.index_select(0, order[b.lo:b.hi]) for b in blocks]
+            else:
+                sfms = [sfm_all[b.lo:b.hi] for b in blocks]
+            if table_x:          # plan of the whole vocabulary's ids, this rank's slice of the table, all-gather of the slices
+                from zett_amd.sharding import SharedTable
+                shared = SharedTable(engine, sfm_all, src)
+                step.table_bytes = shared.bytes_received()
         else:
             sfms = ids_blocks if retok is None else [retok.run_async(*texts[k], seq_len) for k in range(len(blocks))]
         if exchange:
@@ -816,8 +853,8 @@ def main():
         if len(blocks) > 1:
             ahead.wait_stream(torch.cuda.current_stream(device))      # behind this step's retokenization
         for k, b in enumerate(blocks):
-            outs = engine.forward(sfms[k], src, lang_arg)
-            if k + 1 < len(blocks):
+            outs = engine.forward(sfms[k], src, lang_arg) if shared is None else engine.forward_table(sfms[k], shared.table, shared.stats, shared.id_slot, lang_arg)
+            if k + 1 < len(blocks) and shared is None:
                 engine.prepare(sfms[k + 1], ahead)                    # the next block's plan runs under this block's forward (zett_forward_prepare)
             st_k = engine.stats()
             for key in acc:
@@ -931,7 +968,7 @@ def main():
                                f"H={dims.hidden} I={dims.intermediate} heads={dims.heads} layers={dims.layers} "
                                f"L={ids_all.shape[1]}, source_embeddings {src_dtype}",
                    "rows": rows, "rows_per_gpu": sum(b.hi - b.lo for b in blocks),
-                   "partition": args.partition if exchange else None,
+                   "partition": args.partition if exchange else None, "table_exchange": bool(table_x) if exchange else None,
                    "parallelism": f"vocab-row shards x{world} + RCCL all-gather" + ("" if world == 1 else (" (after the forward)" if chunks == 1 else f" ({len(blocks)} row blocks per step: the all-gather of a block runs on the RCCL stream under the next block's forward; nothing overlaps across steps)")),
                    "precision": f"{args.precision} MFMA operands, fp32 accumulate/LN/softmax/GELU/outputs" if args.precision != "f32" else "fp32 MFMA",
                    "packed_tokens_rank0": st["packed_tokens"], "distinct_source_ids_rank0": st["distinct_ids"],
@@ -960,7 +997,8 @@ def main():
         # RowGather.finish, this rank); the rest of the exchange ran under forwards
         "exchange_exposed_ms_per_step": (sum(x for x in exposed if x is not None) / max(len(exposed), 1)) if exchange else None,
         "exchange": None if not exchange else {"mode": gather_mode, "backend": dist.get_backend(), "one_rank_group": world == 1, "early_start_of_pred_in_and_bias": not args.no_early_gather,
-                                             "bytes_received_per_rank_per_step": int(rows * (world - 1) / world * (dims.n_embd * (2 if dims.separate_out else 1) + 1) * 4)},
+                                             "bytes_received_per_rank_per_step": int(rows * (world - 1) / world * (dims.n_embd * (2 if dims.separate_out else 1) + 1) * 4),
+                                             "table_bytes_received_per_rank_per_step": getattr(step, "table_bytes", None) if table_x else None},
         "as_written_tflops": rows * f_ref * args.steps / dt / 1e12,
         "as_written_gflop_per_row": f_ref / 1e9,
     }
@@ -1037,10 +1075,12 @@ def main():
         engine.close()
         torch.cuda.empty_cache()
         result["configs"] = []
-        for name, shard_of, part in (("xlmr_gpt2", 0, "contiguous"), ("tinyllama_neox", 0, "contiguous"), ("mistral_gpt2_32k", 8, "contiguous"),
-                                     ("mistral_gpt2_32k", 8, "affinity")):
+        for name, shard_of, part, tx in (("xlmr_gpt2", 0, "contiguous", False), ("tinyllama_neox", 0, "contiguous", False), ("mistral_gpt2_32k", 8, "contiguous", False),
+                                         ("mistral_gpt2_32k", 8, "affinity", False), ("mistral_gpt2_32k", 8, "contiguous", True)):
+            if tx and args.precision != "f16":
+                continue          # (the shared table is the folded 16-bit table of the f16 mode)
             try:
-                result["configs"].append(side_config(name, 0, args.precision, device, steps=5, warmup=2, shard_of=shard_of, partition=part))
+                result["configs"].append(side_config(name, 0, args.precision, device, steps=5, warmup=2, shard_of=shard_of, partition=part, table_exchange=tx))
             except Exception as e:          # a side line that cannot run must not take the benchmark line with it
                 result["configs"].append({"workload": name, "error": f"{type(e).__name__}: {e}"})
         result["api_path"] = []

@@ -26,11 +26,12 @@
 extern "C" {
 #endif
 
-#define ZETT_ABI_VERSION 7      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range;
+#define ZETT_ABI_VERSION 8      /* 2: zett_stats gained distinct_positions; 3: ZETT_E_RANGE, zett_check_range;
                                    4: ZETT_RETOK_WORDPIECE (zett_retok_model gained piece_continuing, max_input_chars_per_word);
                                    5: zett_forward_prepare, zett_retokenize_async / zett_retok_result;
                                    6: zett_retokenize_async takes NUL-separated text (offsets == NULL); options gemm_tail_split;
-                                   7: zett_retok_set_option */
+                                   7: zett_retok_set_option;
+                                   8: zett_table_plan, zett_table_rows, zett_forward_table (the hoisted table shared between ranks) */
 
 enum zett_status {
     ZETT_OK = 0,
@@ -266,6 +267,32 @@ int zett_partition_rows(const int32_t* surface_forms, int64_t n_rows, int32_t se
  * skip): puts an exchanged block of predicted rows back into vocabulary order — the counterpart of the reference's
  * `preds[indices] += ...` scatter (scripts/transfer.py:96-111).  An HBM stream on `stream`. */
 int zett_scatter_rows(const void* src, void* dst, const int64_t* order, int64_t n_rows, int64_t row_bytes, int32_t device, void* stream);
+
+/* ---- the hoisted table shared between ranks (ABI 8) ---------------------------------------
+ * Replaces: nothing the reference has — it is SURVEY.md 8e's optional second exchange of the row-sharded prediction
+ * (scripts/transfer.py:90-91, zett/utils.py:26): input_projection(in_scaler(source_embeddings[id])) depends on the source id
+ * only, so instead of every rank computing it for the distinct ids of ITS rows (8 340 of the 29 187 ids of the whole vocabulary on
+ * each of 8 ranks of the headline workload: 2.3 x the work in all), the ranks agree on the distinct ids of the WHOLE vocabulary,
+ * each computes 1/P of the table, and the slices are exchanged (the folded 16-bit table: 2 bytes per element + 8 per row).  A table
+ * row's bits do not depend on which rank or tile computed it, so the predicted matrices are those of zett_forward bit for bit.
+ * f16 arithmetic with the LayerNorm fold, the 16-bit residual stream and "table_lo" on (the defaults); ZETT_E_INVALID otherwise.
+ *
+ * zett_table_plan: the distinct source ids a forward over `surface_forms` [n_rows, seq] (device int32: every rank passes the WHOLE
+ * vocabulary's matrix) would reference, in ascending id order: id_list_out (device int32, capacity original_vocab_size +
+ * n_extra) receives them, id_slot_out (device int32 [original_vocab_size + n_extra + 1]) the table slot of every id (exclusive
+ * scan of the reference flags), *n_ids_out their number.  Waits for `stream` (one host round trip); ZETT_E_INDEX on an id outside
+ * the vocabulary, as zett_forward.
+ * zett_table_rows: table rows [first, first + count) of that list — gather + in_scaler + fallback, input_projection.0, the
+ * ProjectorBlock up to its pre-LayerNorm sum — into table_out (rows of `hidden` values of the handle's 16-bit type; the buffer
+ * holds the WHOLE table, row i at table_out + i * hidden) and stats_out (float [*, 2]: mean, rstd of row i at stats_out + 2 i).
+ * Asynchronous on `stream`.
+ * zett_forward_table: zett_forward on that table (complete: this rank's rows and its peers') instead of source embeddings. */
+int zett_table_plan(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq, int32_t* id_slot_out, int32_t* id_list_out,
+                    int64_t* n_ids_out, void* stream);
+int zett_table_rows(zett_hypernet* h, const int32_t* id_list, int64_t first, int64_t count, const void* source_embeddings, int src_dtype,
+                    int64_t v_src, void* table_out, float* stats_out, void* stream);
+int zett_forward_table(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq, const void* table, const float* table_stats,
+                       const int32_t* id_slot, int32_t lang_index, float* out_in, float* out_out, float* out_bias, void* stream);
 
 /* ---- retokenizer ------------------------------------------------------------
  * Replaces: zett.utils.get_surface_form_matrix (zett/utils.py:651-689) and the

@@ -42,6 +42,24 @@ def test_two_ranks_on_one_device(extra):
     assert 0 < d["roofline"]["frac"] < 1 and "untimed" in d["roofline"]["source"] and d["roofline"]["gemm_ms_per_step"] > 0
 
 
+@pytest.mark.parametrize("extra", [[], ["--partition", "affinity", "--gather-mode", "fanout"]], ids=["shared-table", "shared-table-affinity-fanout"])
+def test_two_ranks_share_the_hoisted_table(extra):
+    """--table-exchange (ABI 8, SURVEY 8e's optional second exchange): every rank retokenizes the whole vocabulary, computes half of the
+    table of its distinct ids, the halves are all-gathered, and the forwards run on the complete table — bench.py's own untimed check then
+    compares every gathered row with the PLAIN local forward bit for bit.  XLM-R shape (the folded 16-bit table needs H >= 512), 20 001 rows."""
+    env = dict(os.environ, ZETT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "xlmr_gpt2", "--rows", "20001",
+           "--no-cpu-baseline", "--table-exchange"] + extra
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["table_exchange"] is True and d["config"]["rows"] == 20001
+    assert d["exchange"]["table_bytes_received_per_rank_per_step"] > 0 and d["value"] > 0 and len(lines[0].encode()) < 6000
+
+
 def test_default_line_is_short_and_complete(tmp_path):
     """The DEFAULT command (what the driver runs, with fewer steps): ONE `{` line on stdout, under 6 000 bytes (the driver keeps an
     ~8 KB tail of stdout: round 5's 22 KB line was cut and its record did not parse), carrying the contract fields, `roofline`

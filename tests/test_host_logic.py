@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.zett_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.zett_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_cli_dtype_selects_one_precision_policy():
@@ -309,6 +309,39 @@ try:
     predict_sharded(fake, big, order=torch.arange(3)); ok = False
 except ValueError:
     pass
+# the hoisted table shared between ranks (zett_amd.sharding.SharedTable, ABI 8): every rank plans the same distinct-id list, computes ITS
+# slice, the slices are all-gathered, and the sharded forward on the complete table equals the single-process one — here with a
+# stand-in engine (table row i = a function of id_list[i]); the HIP engine's bit-identity is tests/test_invariants_gpu.py's
+from zett_amd.sharding import SharedTable
+class FakeEngine:
+    V = 1000
+    def table_plan(self, m):
+        ids = torch.unique(m)
+        flag = torch.zeros(self.V, dtype=torch.int32); flag[ids] = 1
+        slot = torch.zeros(self.V + 1, dtype=torch.int32); slot[1:] = torch.cumsum(flag, 0)
+        return slot, ids.to(torch.int32), int(ids.numel())
+    def table_buffers(self, n):
+        return torch.full((n, 8), float("nan"), dtype=torch.float16), torch.full((n, 2), float("nan"))
+    def table_rows(self, id_list, first, count, src, table, stats):
+        i = id_list[first:first + count].long()
+        table[first:first + count] = src[i].to(torch.float16); stats[first:first + count, 0] = i.float(); stats[first:first + count, 1] = 1.0
+    def forward_table(self, rows, table, stats, id_slot, lang):
+        sl = id_slot[rows.long()].long()
+        x = table[sl].float().sum(1) * stats[sl][..., 1].sum(1, keepdim=True) + stats[sl][..., 0].sum(1, keepdim=True)
+        return x, None, x[:, 0].clone() + lang
+g2 = torch.Generator(); g2.manual_seed(11)
+src_t = torch.randn(1000, 8, generator=g2)
+eng = FakeEngine()
+shared = SharedTable(eng, big, src_t)
+lo_, hi_ = shared.rows
+ok = ok and shared.world == world and shared.rank == rank and shared.n_ids == 1000 and (lo_, hi_) == (min(rank * shared.per, 1000), min((rank + 1) * shared.per, 1000))
+ok = ok and not torch.isnan(shared.table[:1000].float()).any() and not torch.isnan(shared.stats[:1000]).any()          # every peer's slice arrived
+ok = ok and shared.bytes_received() == (world - 1) * shared.per * (8 * 2 + 8)
+alone = SharedTable(eng, big, src_t, only_rank=0, world=1)
+ok = ok and torch.equal(alone.table[:1000], shared.table[:1000]) and torch.equal(alone.stats[:1000], shared.stats[:1000])
+for chunks in (1, 2):
+    t_full = predict_sharded(shared.predict(3), big, chunks=chunks); t_one = alone.predict(3)(big)
+    ok = ok and torch.equal(t_full[0], t_one[0]) and t_full[1] is None and torch.equal(t_full[2], t_one[2])
 shapes = [tuple(t.shape) for t in full]
 if rank == 0:
     json.dump({{"ok": ok, "shapes": shapes}}, open({out!r}, "w"))

@@ -434,3 +434,56 @@ def test_narrow_row_kernels_r6(hidden, heads, rows):
                 for g, r in zip(out, want):
                     if g is not None and r is not None:
                         util.CLOSE["f16"](g.cpu().numpy()[keep], r[keep], f"H={hidden} narrow row kernels")
+
+
+@pytest.mark.parametrize("name,rows", [("xlmr_gpt2", 2500), ("tinyllama_neox", 3001), ("mistral_gpt2_32k", 700)])
+def test_shared_table_reproduces_the_forward(name, rows):
+    """ABI 8 (SURVEY 8e's optional second exchange): the hoisted table computed in P slices of the GLOBAL distinct-id list
+    (zett_table_plan / zett_table_rows — what P ranks would compute and exchange) and a forward on that table (zett_forward_table)
+    give zett_forward's rows BIT FOR BIT: for the whole matrix and for row shards, whatever P, with forced chunks on both sides, and
+    with the slices computed out of order.  The global list is the ascending list of referenced ids; the modes without the folded
+    16-bit table (bf16, f32, table_lo 0) refuse."""
+    from zett_amd.sharding import SharedTable, shard_bounds
+    cfg, _, src_dtype, hist = synth.workload(name)
+    lang = 3 if cfg.get("hn_embed_lang_id") else -1
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 5, dtype=src_dtype)).cuda()
+    ids_np = synth.make_surface_forms(cfg, rows, seed=5, hist=hist, n_special=2)
+    ids = torch.from_numpy(ids_np).cuda()
+    eng = _engine(cfg, 5, "f16")
+    ref = _run(eng, ids, src, lang)
+    id_slot, id_list, n = eng.table_plan(ids)
+    want_ids = np.unique(np.concatenate([ids_np[ids_np != cfg["pad_token_id"]], ids_np[:, 0]]))
+    assert n == len(want_ids) and np.array_equal(id_list.cpu().numpy(), want_ids)
+    assert np.array_equal(id_slot.cpu().numpy()[want_ids], np.arange(n)) and int(id_slot[-1]) == n
+    for world in (1, 3, 8):
+        table, stats = eng.table_buffers(n + 5)
+        table.fill_(float("nan")); stats.fill_(float("nan"))
+        for r in reversed(range(world)):
+            lo, hi = shard_bounds(n, world, r)
+            eng.table_rows(id_list, lo, hi - lo, src, table, stats)
+        assert _eq(eng.forward_table(ids, table, stats, id_slot, lang), ref), f"world {world}"
+        parts = [eng.forward_table(ids[slice(*shard_bounds(rows, world, r))], table, stats, id_slot, lang) for r in range(world)]
+        assert _eq([None if parts[0][k] is None else torch.cat([p[k] for p in parts]) for k in range(3)], ref)
+    eng.set_option("max_chunk_tokens", 1024)
+    table2, stats2 = eng.table_buffers(n)
+    eng.table_rows(id_list, 0, n, src, table2, stats2)
+    assert torch.equal(table2.view(torch.int16), table[:n].view(torch.int16)) and torch.equal(stats2, stats[:n])
+    assert _eq(eng.forward_table(ids, table2, stats2, id_slot, lang), ref)
+    eng.set_option("max_chunk_tokens", 1 << 22)
+    # the helper the sharded callers use, as rank 2 of 4 would build it (its own slice only) and as one rank builds all of it
+    one = SharedTable(eng, ids, src)
+    assert one.n_ids == n and _eq(one.predict(lang)(ids), ref)
+    part = SharedTable(eng, ids, src, only_rank=2, world=4)
+    lo, hi = part.rows
+    assert (lo, hi) == (2 * part.per, min(3 * part.per, n)) and torch.equal(part.table[lo:hi].view(torch.int16), table[lo:hi].view(torch.int16))
+    assert part.bytes_received() == 3 * part.per * (cfg["hn_hidden_size"] * 2 + 8)
+    # a plain forward behind a table forward is the plain forward again (the handle keeps nothing of the external table)
+    assert _eq(_run(eng, ids, src, lang), ref)
+    eng.set_option("table_lo", 0)
+    with pytest.raises(ValueError):
+        eng.table_rows(id_list, 0, n, src, table2, stats2)
+    with pytest.raises(ValueError):
+        eng.forward_table(ids, table2, stats2, id_slot, lang)
+    b16 = _engine(cfg, 5, "bf16")
+    with pytest.raises(ValueError):
+        b16.table_rows(id_list, 0, n, src, *b16.table_buffers(n))

@@ -33,8 +33,8 @@ def _torchrun(script_args, port, timeout=900):
 
 @needs_two_gpus
 @pytest.mark.parametrize("extra", [[], ["--serial-allgather"], ["--chunks", "3"], ["--gather-mode", "fanout"], ["--serial-allgather", "--gather-mode", "fanout"],
-                                   ["--serial-allgather", "--no-early-gather"], ["--partition", "affinity", "--gather-mode", "fanout"]],
-                         ids=["two-blocks-self-launched", "serial", "three-blocks", "fanout", "serial-fanout", "serial-late", "affinity-fanout"])
+                                   ["--serial-allgather", "--no-early-gather"], ["--partition", "affinity", "--gather-mode", "fanout"], ["--table-exchange"]],
+                         ids=["two-blocks-self-launched", "serial", "three-blocks", "fanout", "serial-fanout", "serial-late", "affinity-fanout", "shared-table"])
 def test_bench_two_gpus_nccl(extra):
     bench_args = [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "tinyllama_neox",
                   "--rows", "30001", "--no-cpu-baseline"] + extra

@@ -25,6 +25,7 @@ ABI_SYMBOLS = (
     "zett_retok_create", "zett_retok_destroy", "zett_retokenize", "zett_check_range", "zett_get_gemm_log",
     "zett_stream_wait_output", "zett_forward_prepare", "zett_retokenize_async", "zett_retok_result", "zett_retok_set_option",
     "zett_partition_rows", "zett_partition_workspace_bytes", "zett_scatter_rows",
+    "zett_table_plan", "zett_table_rows", "zett_forward_table",
     # training primitives (zett_amd/autograd.py)
     "zett_op_gemm_f32", "zett_op_transpose_f32", "zett_op_colsum_f32", "zett_op_elementwise_f32", "zett_op_rowdot_f32",
     "zett_op_layernorm_fwd_f32", "zett_op_layernorm_bwd_f32", "zett_op_gelu_fwd_f32", "zett_op_gelu_bwd_f32",
@@ -41,7 +42,7 @@ class ZettConfig(C.Structure):
         ("ln_eps_encoder", C.c_float), ("ln_eps_projector", C.c_float)]
 
 
-ABI_VERSION = 7      # ZETT_ABI_VERSION of include/zett_hip.h
+ABI_VERSION = 8      # ZETT_ABI_VERSION of include/zett_hip.h
 
 
 class ZettStats(C.Structure):
@@ -114,6 +115,10 @@ def load():
                                               C.c_void_p, C.c_void_p]
         lib.zett_retok_result.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.zett_forward_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        lib.zett_table_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+        lib.zett_table_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.zett_forward_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.zett_partition_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         lib.zett_scatter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
         lib.zett_partition_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),

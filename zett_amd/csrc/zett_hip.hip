@@ -106,8 +106,13 @@ struct zett_hypernet {
         int64_t n_rows = 0;
         int seq = 0;
         bool pair_plan = false;           // the layout it was made with (an option changed in between: the forward plans again)
+        const int32_t* ext_id_slot = nullptr;   // the id -> table-slot map its tok_slot was written with (null: the plan's own)
         bool pending = false;
     } plan[2];
+    PlanSlot table_plan;              // (ABI 8) scratch plan of zett_table_plan: the distinct ids of a WHOLE vocabulary, never taken by a forward
+    // (ABI 8) the hoisted table of the forward in flight comes from the caller (zett_forward_table): rows of the global distinct-id
+    // list computed by zett_table_rows — on this rank and on its peers — instead of this call's own distinct ids
+    struct ExtTable { const void* table = nullptr; const float* stats = nullptr; const int32_t* id_slot = nullptr; } ext;
     int plan_cur = 0;                 // slot of the most recent forward
     hipStream_t plan_stream = nullptr;
     hipEvent_t plan_fork = nullptr;
@@ -325,7 +330,12 @@ static int enqueue_plan(zett_hypernet* h, zett_hypernet::PlanSlot& s, const int3
     hipLaunchKernelGGL(plan_rows_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
     launch_exclusive_scan(p.row_count, p.row_offset, N, L.scan_tmp, st);
     launch_exclusive_scan(p.id_flag, p.id_slot, (int64_t)V, L.scan_tmp, st);
-    hipLaunchKernelGGL(plan_tokens_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, p);
+    {
+        // (ABI 8) a forward on a caller-provided table: a token's table slot is its id's slot in the GLOBAL distinct-id list
+        PlanArrays pt = p;
+        if (h->ext.id_slot) pt.id_slot = const_cast<int32_t*>(h->ext.id_slot);
+        hipLaunchKernelGGL(plan_tokens_kernel, dim3(rb), dim3(256), 0, st, sfm, N, seq, c.pad_token_id, lam, V, pt);
+    }
     if (L.pair_plan) {
         launch_exclusive_scan(p.pair_flag, p.pair_slot, L.PK, L.scan_tmp, st);
         hipLaunchKernelGGL(plan_pairs_kernel, dim3((unsigned)((max_tok + 255) / 256)), dim3(256), 0, st, N, p);
@@ -335,13 +345,15 @@ static int enqueue_plan(zett_hypernet* h, zett_hypernet::PlanSlot& s, const int3
     // the row offsets and, right behind them, the three counters (distinct ids, error word, distinct pairs) to the host: one copy
     HIP_TRY(hipMemcpyAsync(s.host, p.row_offset, ((size_t)N + 1 + 3) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(s.done, st));
-    s.sfm = sfm; s.n_rows = N; s.seq = seq; s.pair_plan = L.pair_plan;
+    s.sfm = sfm; s.n_rows = N; s.seq = seq; s.pair_plan = L.pair_plan; s.ext_id_slot = h->ext.id_slot;
     return 0;
 }
 
 template <typename T>
 int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const void* src, int src_dtype,
                int64_t v_src, int lang_index, float* out_in, float* out_out, float* out_bias, hipStream_t st);
+template <typename T>
+int do_table_rows(zett_hypernet* h, const int32_t* id_list, int first, int count, const void* src, int src_dtype, void* table_out, float* stats_out, hipStream_t st);
 
 }  // namespace
 
@@ -384,7 +396,8 @@ int zett_destroy(zett_hypernet* h) {
     for (void* p : h->owned) (void)hipFree(p);
     for (DevBuf* b : {&h->table, &h->x0, &h->yf, &h->yt, &h->big, &h->pre, &h->ctx, &h->cf, &h->ct, &h->lnstats, &h->lnparts})
         b->release();
-    for (auto& ps : h->plan) {
+    for (zett_hypernet::PlanSlot* psp : {&h->plan[0], &h->plan[1], &h->table_plan}) {
+        zett_hypernet::PlanSlot& ps = *psp;
         ps.i32.release(); ps.u8.release();
         if (ps.host) (void)hipHostFree(ps.host);
         if (ps.done) (void)hipEventDestroy(ps.done);
@@ -791,6 +804,77 @@ int zett_forward(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows,
     return do_forward<float>(h, surface_forms, n_rows, seq, source_embeddings, src_dtype, v_src, lang_index, out_in, out_out, out_bias, st);
 }
 
+// ---- (ABI 8) the hoisted table shared between ranks: SURVEY 8e's optional second exchange ---------------------------------
+int zett_table_plan(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq, int32_t* id_slot_out, int32_t* id_list_out,
+                    int64_t* n_ids_out, void* stream) {
+    if (!h) return fail(ZETT_E_INVALID, "null handle");
+    if (!h->finalized) return fail(ZETT_E_STATE, "zett_finalize has not been called");
+    if (!surface_forms || !id_slot_out || !id_list_out || !n_ids_out) return fail(ZETT_E_INVALID, "null argument");
+    if (n_rows < 1 || seq < 1) return fail(ZETT_E_INVALID, "bad surface-form shape [%lld, %d]", (long long)n_rows, seq);
+    if (n_rows * (int64_t)(seq + 1) >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many positions for one call");
+    const zett_config& c = h->cfg;
+    const int V = c.original_vocab_size + c.n_extra;
+    ZETT_ON_DEVICE(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    zett_hypernet::PlanSlot& ps = h->table_plan;
+    const zett_hypernet::ExtTable saved = h->ext;
+    h->ext = zett_hypernet::ExtTable{};          // (this plan numbers the ids itself)
+    const int rc = enqueue_plan(h, ps, surface_forms, n_rows, seq, st);
+    h->ext = saved;
+    if (rc) return rc;
+    HIP_TRY(hipEventSynchronize(ps.done));
+    const int32_t* hoff = ps.host;
+    if (hoff[n_rows + 2] != 0)
+        return fail(ZETT_E_INDEX, "surface-form row %d holds an id outside [0, %d) (original_vocab_size %d + %d fallback rows)",
+                    hoff[n_rows + 2] - 1, V, c.original_vocab_size, c.n_extra);
+    const int D = hoff[n_rows + 1];
+    const PlanLayout L = plan_layout(h, ps, n_rows, seq);
+    HIP_TRY(hipMemcpyAsync(id_slot_out, L.p.id_slot, ((size_t)V + 1) * 4, hipMemcpyDeviceToDevice, st));
+    if (D > 0) HIP_TRY(hipMemcpyAsync(id_list_out, L.p.id_list, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+    *n_ids_out = D;
+    return 0;
+}
+
+int zett_table_rows(zett_hypernet* h, const int32_t* id_list, int64_t first, int64_t count, const void* source_embeddings, int src_dtype,
+                    int64_t v_src, void* table_out, float* stats_out, void* stream) {
+    if (!h) return fail(ZETT_E_INVALID, "null handle");
+    if (!h->finalized) return fail(ZETT_E_STATE, "zett_finalize has not been called");
+    if (first < 0 || count < 0 || first + count >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "bad table range [%lld, +%lld)", (long long)first, (long long)count);
+    if (count == 0) return 0;
+    if (!id_list || !source_embeddings || !table_out || !stats_out) return fail(ZETT_E_INVALID, "null tensor argument");
+    if (src_dtype < ZETT_F32 || src_dtype > ZETT_BF16) return fail(ZETT_E_INVALID, "unknown source dtype %d", src_dtype);
+    if (v_src < h->cfg.original_vocab_size) return fail(ZETT_E_INDEX, "source_embeddings has %lld rows, config.original_vocab_size is %d", (long long)v_src, h->cfg.original_vocab_size);
+    ZETT_ON_DEVICE(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->precision == ZETT_PREC_F16) return do_table_rows<f16_t>(h, id_list, (int)first, (int)count, source_embeddings, src_dtype, table_out, stats_out, st);
+    if (h->precision == ZETT_PREC_BF16) return do_table_rows<bf16_t>(h, id_list, (int)first, (int)count, source_embeddings, src_dtype, table_out, stats_out, st);
+    return fail(ZETT_E_INVALID, "zett_table_rows: the folded 16-bit table exists in the 16-bit modes only");
+}
+
+int zett_forward_table(zett_hypernet* h, const int32_t* surface_forms, int64_t n_rows, int32_t seq, const void* table, const float* table_stats,
+                       const int32_t* id_slot, int32_t lang_index, float* out_in, float* out_out, float* out_bias, void* stream) {
+    if (!h) return fail(ZETT_E_INVALID, "null handle");
+    if (!h->finalized) return fail(ZETT_E_STATE, "zett_finalize has not been called");
+    const zett_config& c = h->cfg;
+    if (n_rows < 1 || seq < 1) return fail(ZETT_E_INVALID, "bad surface-form shape [%lld, %d]", (long long)n_rows, seq);
+    if (seq + (c.embed_lang ? 1 : 0) > c.max_positions) return fail(ZETT_E_INDEX, "sequence %d exceeds position_embeddings (%d rows)", seq, c.max_positions);
+    if (!surface_forms || !table || !table_stats || !id_slot || !out_in || !out_bias) return fail(ZETT_E_INVALID, "null tensor argument");
+    if (c.separate_out && !out_out) return fail(ZETT_E_INVALID, "out_out is required when separate_out_embeddings is set");
+    if (c.embed_lang && (lang_index < 0 || lang_index >= c.n_langs)) return fail(ZETT_E_INDEX, "lang_index %d outside [0,%d)", lang_index, c.n_langs);
+    if (n_rows * (int64_t)(seq + 1) >= (int64_t)0x7fffffff) return fail(ZETT_E_INVALID, "too many positions for one call");
+    if (h->precision == ZETT_PREC_F32) return fail(ZETT_E_INVALID, "zett_forward_table: the folded 16-bit table exists in the 16-bit modes only");
+    ZETT_ON_DEVICE(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    h->ext.table = table; h->ext.stats = table_stats; h->ext.id_slot = id_slot;
+    int rc;
+    if (h->precision == ZETT_PREC_F16)
+        rc = do_forward<f16_t>(h, surface_forms, n_rows, seq, nullptr, ZETT_F32, 0, lang_index, out_in, out_out, out_bias, st);
+    else
+        rc = do_forward<bf16_t>(h, surface_forms, n_rows, seq, nullptr, ZETT_F32, 0, lang_index, out_in, out_out, out_bias, st);
+    h->ext = zett_hypernet::ExtTable{};
+    return rc;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------
@@ -954,6 +1038,68 @@ void launch_gather(hipStream_t st, const int32_t* id_list, int s0, int m, const 
                        c.original_vocab_size, fallback, sw, sb, out, range_flag);
 }
 
+// The hoisted table (A2-A4): input_projection once per distinct source id — rows id_list[first .. first + count) into table rows
+// [first, first + count) (the fp32 table `tbl32`, or — folded — the 16-bit pre-LayerNorm sums `tbl16` with (mean, rstd) in
+// `tblst`), in chunks of MC rows through the caller's workspace.  Errors land in R.rc.
+template <typename T>
+void table_phase(Runner<T>& R, const int32_t* id_list, int first, int count, const void* src, int src_dtype, int64_t MC, size_t MCS,
+                 T* X0, float* Zf, T* Zt, T* BIG, float* PRE, float2* PARTS, bool table_lo, T* tbl16, float* tblst, float* tbl32) {
+    zett_hypernet* h = R.h;
+    const zett_config& c = h->cfg;
+    const int H = c.hidden, EIN = c.n_in_embd;
+    hipStream_t st = R.st;
+    const float* in_w = c.rescale ? R.Wf("in_scaler.w") : nullptr;
+    const float* in_b = c.rescale ? R.Wf("in_scaler.b") : nullptr;
+    for (int s0 = first; s0 < first + count && !R.rc; s0 += (int)MC) {
+        const int m = (int)std::min<int64_t>(MC, first + count - s0);
+        const float* fb = R.Wf("fallback_embeddings.weight");
+        if (src_dtype == ZETT_F32) launch_gather<T, 0>(st, id_list, s0, m, src, c, fb, in_w, in_b, X0, h->range_word);
+        else if (src_dtype == ZETT_F16) launch_gather<T, 1>(st, id_list, s0, m, src, c, fb, in_w, in_b, X0, h->range_word);
+        else launch_gather<T, 2>(st, id_list, s0, m, src, c, fb, in_w, in_b, X0, h->range_word);
+        R.check("gather_src");
+        GemmEpilogue<T> e0 = R.epi();
+        e0.bias = R.Wf("input_projection.0.bias"); e0.out_f32 = Zf; e0.ld_f32 = H; e0.out_lo = Zt; e0.ld_lo = H;
+        R.gemm(X0, EIN, R.Wlo("input_projection.0.weight"), EIN, m, H, EIN, e0);
+        if (table_lo) R.projector("input_projection.1.", Zt, Zf, m, BIG, PRE, nullptr, tbl16 + (size_t)s0 * H, PARTS, (int)MCS, tblst + 2 * (size_t)s0);
+        else R.projector("input_projection.1.", Zt, Zf, m, BIG, PRE, tbl32 + (size_t)s0 * H, nullptr);
+    }
+}
+
+// true when this handle's forward keeps the hoisted table folded (16-bit pre-LayerNorm sums + statistics): the predicate of do_forward
+template <typename T>
+bool folded_table_mode(const zett_hypernet* h) {
+    const zett_config& c = h->cfg;
+    const int H = c.hidden;
+    const bool fold = h->ln_fold && !std::is_same<T, float>::value && h->gemm_variant == 0 && H % 128 == 0 && H >= 512 && (int)h->fold_up.size() == c.layers;
+    const bool lo_stream = fold && c.layers >= 1 && sizeof(T) == 2 && (h->residual_lo == 2 || (h->residual_lo == 1 && std::is_same<T, f16_t>::value));
+    return lo_stream && h->table_lo != 0;
+}
+
+// (ABI 8) zett_table_rows: rows [first, first + count) of the folded table of the distinct-id list `id_list` into the caller's buffers
+template <typename T>
+int do_table_rows(zett_hypernet* h, const int32_t* id_list, int first, int count, const void* src, int src_dtype, void* table_out, float* stats_out, hipStream_t st) {
+    const zett_config& c = h->cfg;
+    if (!folded_table_mode<T>(h))
+        return fail(ZETT_E_INVALID, "zett_table_rows needs the folded 16-bit table: f16 arithmetic with the LayerNorm fold, the 16-bit residual stream and table_lo on");
+    const WorkspaceSizes ws = workspace_sizes(c, sizeof(T), 1, count, count, h->max_chunk_tokens);
+    const int64_t MC = ws.chunk_tokens;
+    const size_t MCS = (size_t)MC + 768;
+    if (int rc = h->x0.reserve(ws.x0)) return rc;
+    if (int rc = h->yf.reserve(ws.f32_rows)) return rc;
+    if (int rc = h->yt.reserve(ws.lo_rows)) return rc;
+    if (int rc = h->big.reserve(ws.big)) return rc;
+    if (int rc = h->pre.reserve(ws.f32_rows)) return rc;
+    if (int rc = h->lnparts.reserve((size_t)(c.hidden / 128) * MCS * sizeof(float2))) return rc;
+    Runner<T> R{h, st};
+    R.a_rows_readable = (long)MCS;
+    // (per-launch events and the launch log belong to a forward: zett_forward resets both when it starts)
+    struct NoTiming { zett_hypernet* h; int saved; ~NoTiming() { h->time_gemm = saved; } } no_timing{h, h->time_gemm};
+    h->time_gemm = 0;
+    table_phase<T>(R, id_list, first, count, src, src_dtype, MC, MCS, h->x0.as<T>(), h->yf.as<float>(), h->yt.as<T>(), h->big.as<T>(), h->pre.as<float>(),
+                   h->lnparts.as<float2>(), true, (T*)table_out, stats_out, nullptr);
+    return R.rc;
+}
+
 template <typename T>
 int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const void* src, int src_dtype,
                int64_t v_src, int lang_index, float* out_in, float* out_out, float* out_bias, hipStream_t st) {
@@ -975,7 +1121,8 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     // plan stream, the host waits for THAT (not for earlier work on st) and st is ordered behind it.  Otherwise the plan is
     // made here, on st, and the host waits for it — and so for whatever was enqueued on st before.
     zett_hypernet::PlanSlot& ps = h->plan[h->plan_cur ^ 1];
-    if (ps.pending && ps.sfm == sfm && ps.n_rows == N && ps.seq == seq && ps.pair_plan == plan_layout(h, ps, N, seq).pair_plan) {
+    if (ps.pending && ps.sfm == sfm && ps.n_rows == N && ps.seq == seq && ps.pair_plan == plan_layout(h, ps, N, seq).pair_plan &&
+        ps.ext_id_slot == h->ext.id_slot) {
         HIP_TRY(hipStreamWaitEvent(st, ps.done, 0));
     } else {
         if (ps.pending) HIP_TRY(hipEventSynchronize(ps.done));       // a prepared plan nobody took: let it finish before the slot is reused
@@ -1053,8 +1200,13 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     // the pre-LayerNorm sum replaces none: the same step the encoder's stream takes per layer.  The buffer keeps its fp32 size:
     // [D, H] 16-bit values, then [D] (mean, rstd).
     const bool table_lo = lo_stream && h->table_lo != 0;
-    T* TBL16 = (T*)h->table.as<float>();
-    float* TBLST = (float*)((char*)h->table.as<float>() + (((size_t)D * H * sizeof(T) + 15) / 16) * 16);
+    // (ABI 8) zett_forward_table: the table is the caller's — rows of the GLOBAL distinct-id list in the folded 16-bit layout,
+    // computed by zett_table_rows here and on the peer ranks; tok_slot already holds global slots (enqueue_plan)
+    const bool ext_table = h->ext.table != nullptr;
+    if (ext_table && !table_lo)
+        return fail(ZETT_E_INVALID, "zett_forward_table needs the folded 16-bit table: f16 arithmetic with the LayerNorm fold, the 16-bit residual stream and table_lo on");
+    T* TBL16 = ext_table ? (T*)const_cast<void*>(h->ext.table) : (T*)h->table.as<float>();
+    float* TBLST = ext_table ? const_cast<float*>(h->ext.stats) : (float*)((char*)h->table.as<float>() + (((size_t)D * H * sizeof(T) + 15) / 16) * 16);
     T* X0 = h->x0.as<T>();
     float* Zf = h->yf.as<float>();
     T* Zt = h->yt.as<T>();
@@ -1074,21 +1226,8 @@ int do_forward(zett_hypernet* h, const int32_t* sfm, int64_t N, int seq, const v
     R.a_rows_readable = (long)MCS;
 
     // ---- table: input_projection once per distinct source id (A2-A4) -----------------
-    const float* in_w = c.rescale ? R.Wf("in_scaler.w") : nullptr;
-    const float* in_b = c.rescale ? R.Wf("in_scaler.b") : nullptr;
-    for (int s0 = 0; s0 < D && !R.rc; s0 += (int)MC) {
-        const int m = (int)std::min<int64_t>(MC, D - s0);
-        const float* fb = R.Wf("fallback_embeddings.weight");
-        if (src_dtype == ZETT_F32) launch_gather<T, 0>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0, h->range_word);
-        else if (src_dtype == ZETT_F16) launch_gather<T, 1>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0, h->range_word);
-        else launch_gather<T, 2>(st, p.id_list, s0, m, src, c, fb, in_w, in_b, X0, h->range_word);
-        R.check("gather_src");
-        GemmEpilogue<T> e0 = R.epi();
-        e0.bias = R.Wf("input_projection.0.bias"); e0.out_f32 = Zf; e0.ld_f32 = H; e0.out_lo = Zt; e0.ld_lo = H;
-        R.gemm(X0, EIN, R.Wlo("input_projection.0.weight"), EIN, m, H, EIN, e0);
-        if (table_lo) R.projector("input_projection.1.", Zt, Zf, m, BIG, PRE, nullptr, TBL16 + (size_t)s0 * H, PARTS, (int)MCS, TBLST + 2 * (size_t)s0);
-        else R.projector("input_projection.1.", Zt, Zf, m, BIG, PRE, TBL + (size_t)s0 * H, nullptr);
-    }
+    if (!ext_table)
+        table_phase<T>(R, p.id_list, 0, D, src, src_dtype, MC, MCS, X0, Zf, Zt, BIG, PRE, PARTS, table_lo, TBL16, TBLST, TBL);
     if (R.rc) return R.rc;
 
     // ---- encoder + heads over row chunks -----------------------------------------------

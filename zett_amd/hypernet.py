@@ -186,6 +186,65 @@ class HipEngine:
         _lib.check(rc, "zett_forward")
         return out_in, out_out, out_bias
 
+    # ---- the hoisted table shared between ranks (ABI 8; zett_amd/sharding.py SharedTable) -----------------------------------
+    def table_plan(self, surface_forms_all: torch.Tensor):
+        """zett_table_plan: the distinct source ids the WHOLE vocabulary's surface-form matrix references, ascending ->
+        (id_slot int32 [V + 1]: table slot of every id, id_list int32 [n_ids]: slot -> id, n_ids).  One host round trip."""
+        ids = surface_forms_all.to(torch.int32).contiguous()
+        if ids.dim() != 2 or ids.device != self.device:
+            raise ValueError(f"table_plan takes the [n_tokens, surface_maxlen] matrix on {self.device}")
+        v = self.dims.original_vocab_size + self.dims.n_extra
+        id_slot = torch.empty((v + 1,), dtype=torch.int32, device=self.device)
+        id_list = torch.empty((v,), dtype=torch.int32, device=self.device)
+        n_ids = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self.lib.zett_table_plan(self.handle, C.c_void_p(ids.data_ptr()), ids.shape[0], ids.shape[1], C.c_void_p(id_slot.data_ptr()),
+                                                C.c_void_p(id_list.data_ptr()), C.byref(n_ids), C.c_void_p(stream)), "zett_table_plan")
+        return id_slot, id_list[:n_ids.value], int(n_ids.value)
+
+    def table_buffers(self, n_rows: int):
+        """Empty buffers of a folded table of n_rows rows: (table [n_rows, H] in the engine's 16-bit type, stats float32 [n_rows, 2])."""
+        lo = {"f16": torch.float16, "fp16": torch.float16, "float16": torch.float16, "bf16": torch.bfloat16}.get(self.precision)
+        if lo is None:
+            raise ValueError("the folded 16-bit table exists in the 16-bit modes only")
+        return (torch.empty((n_rows, self.dims.hidden), dtype=lo, device=self.device), torch.empty((n_rows, 2), dtype=torch.float32, device=self.device))
+
+    def table_rows(self, id_list: torch.Tensor, first: int, count: int, source_embeddings: torch.Tensor, table: torch.Tensor, stats: torch.Tensor) -> None:
+        """zett_table_rows: rows [first, first + count) of the table of `id_list` into `table` / `stats` (whole-table buffers). Asynchronous."""
+        src = source_embeddings
+        if src.dtype not in _TORCH_TO_ZETT:
+            src = src.float()
+        src = src.contiguous()
+        if src.dim() != 2 or src.shape[1] != self.dims.n_in_embd or src.device != self.device:
+            raise ValueError(f"source_embeddings must be [V, {self.dims.n_in_embd}] on {self.device}, got {tuple(src.shape)}")
+        if not (table.is_contiguous() and stats.is_contiguous() and table.shape[0] >= first + count and stats.shape[0] >= first + count and id_list.numel() >= first + count):
+            raise ValueError("table / stats / id_list are smaller than the requested rows")
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self.lib.zett_table_rows(self.handle, C.c_void_p(id_list.data_ptr()), first, count, C.c_void_p(src.data_ptr()), _TORCH_TO_ZETT[src.dtype],
+                                                src.shape[0], C.c_void_p(table.data_ptr()), C.c_void_p(stats.data_ptr()), C.c_void_p(stream)), "zett_table_rows")
+
+    def forward_table(self, surface_forms: torch.Tensor, table: torch.Tensor, stats: torch.Tensor, id_slot: torch.Tensor, lang_index: int):
+        """zett_forward_table: forward() on a complete shared table instead of source embeddings; same outputs, bit for bit."""
+        d = self.dims
+        if surface_forms.dim() != 2 or surface_forms.device != self.device:
+            raise ValueError(f"target_surface_forms must be [n_tokens, surface_maxlen] on {self.device}")
+        ids = surface_forms.to(torch.int32).contiguous()
+        n, seq = ids.shape
+        out_in = torch.empty((n, d.n_embd), dtype=torch.float32, device=self.device)
+        out_out = torch.empty((n, d.n_embd), dtype=torch.float32, device=self.device) if d.separate_out else None
+        out_bias = torch.empty((n,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.zett_forward_table(
+                self.handle, C.c_void_p(ids.data_ptr()), n, seq, C.c_void_p(table.data_ptr()), C.c_void_p(stats.data_ptr()), C.c_void_p(id_slot.data_ptr()),
+                int(lang_index), C.c_void_p(out_in.data_ptr()), C.c_void_p(out_out.data_ptr() if out_out is not None else 0),
+                C.c_void_p(out_bias.data_ptr()), C.c_void_p(stream))
+        self._prepared = None
+        _lib.check(rc, "zett_forward_table")
+        return out_in, out_out, out_bias
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             self.lib.zett_destroy(self.handle)

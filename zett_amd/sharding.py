@@ -341,6 +341,51 @@ def all_gather_rows(local: torch.Tensor, n_rows: int, per: int, group=None) -> t
     return full[:n_rows]
 
 
+class SharedTable:
+    """The hoisted input-projection table computed ONCE across the ranks (SURVEY.md 8e's optional second exchange; zett_table_* of
+    ABI 8).  `input_projection(in_scaler(source_embeddings[id]))` depends on the source id only; a rank of a row-sharded prediction
+    otherwise computes it for the distinct ids of ITS rows — 8 340 of the headline vocabulary's 29 187 on each of 8 ranks, 2.3 x the
+    work in all.  Here every rank passes the WHOLE vocabulary's surface-form matrix (as the id-affinity order needs it too), the
+    ranks agree on the distinct ids without talking (the same plan on the same matrix), rank r computes rows [r * per, (r + 1) * per)
+    of the folded 16-bit table, and one all-gather per buffer (2 bytes per element + 8 per row: 239 MB at the headline) completes
+    it everywhere.  A table row's bits do not depend on the rank or tile that computed it: `predict` gives zett_forward's rows bit
+    for bit.  f16 arithmetic (the default) only — the folded table does not exist in bf16 / f32 mode (ValueError).
+
+        shared = SharedTable(engine, sfm_all, source_embeddings)            # every rank, same arguments
+        full = predict_sharded(shared.predict(lang), sfm_all, ready=engine.stream_wait_output)
+
+    Without a process group it is one rank's whole table (the single-GPU proxy and the tests)."""
+
+    def __init__(self, engine, surface_forms_all: torch.Tensor, source_embeddings: torch.Tensor, group=None, only_rank: Optional[int] = None, world: Optional[int] = None,
+                 buffers=None):
+        """only_rank / world: build what THAT rank of `world` ranks computes, without an exchange (the single-GPU proxy of a P-GPU step);
+        buffers = (table, stats) of an earlier complete table of the same matrix: the slice is written into them instead of new ones."""
+        live = dist.is_available() and dist.is_initialized()
+        self.world = world if world is not None else (dist.get_world_size(group) if live else 1)
+        self.rank = only_rank if only_rank is not None else (dist.get_rank(group) if live else 0)
+        self.engine = engine
+        self.id_slot, self.id_list, self.n_ids = engine.table_plan(surface_forms_all)
+        self.per = -(-max(self.n_ids, 1) // self.world)
+        self.table, self.stats = buffers if buffers is not None else engine.table_buffers(self.per * self.world)
+        if self.table.shape[0] < self.per * self.world or self.stats.shape[0] < self.per * self.world:
+            raise ValueError("buffers are smaller than the table")
+        lo, hi = min(self.rank * self.per, self.n_ids), min((self.rank + 1) * self.per, self.n_ids)
+        self.rows = (lo, hi)
+        engine.table_rows(self.id_list, lo, hi - lo, source_embeddings, self.table, self.stats)
+        if live and self.world > 1 and only_rank is None:
+            # (the padding rows behind n_ids travel too and are never read: id_slot only names rows < n_ids)
+            for buf in (self.table.view(torch.uint8), self.stats):          # (bytes: a dtype every backend carries)
+                mine = buf[self.rank * self.per:(self.rank + 1) * self.per].clone()
+                dist.all_gather_into_tensor(buf, mine, group=group)
+
+    def bytes_received(self) -> int:
+        """what a rank receives in the table exchange"""
+        return int((self.world - 1) * self.per * (self.table.shape[1] * self.table.element_size() + 8))
+
+    def predict(self, lang_index: int) -> Callable:
+        return lambda rows: self.engine.forward_table(rows, self.table, self.stats, self.id_slot, lang_index)
+
+
 def predict_sharded(predict: Callable, target_surface_forms: torch.Tensor, group=None, chunks: int = 2,
                     ready: Optional[Callable] = None, mode: str = "auto", prepare: Optional[Callable] = None,
                     order: Optional[torch.Tensor] = None, min_rows_per_shard: int = 4096):
