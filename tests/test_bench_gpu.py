@@ -81,7 +81,9 @@ def test_default_line_is_short_and_complete(tmp_path):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert d["parity_vs_cpu_port_rel_l2"] < 2.5e-3
-    assert [c["workload"] for c in d["configs"]] == ["xlmr_gpt2", "tinyllama_neox", "mistral_gpt2_32k", "mistral_gpt2_32k"] and all("error" not in c for c in d["configs"])
+    assert [c["workload"] for c in d["configs"]] == ["xlmr_gpt2", "tinyllama_neox", "mistral_gpt2_32k", "mistral_gpt2_32k", "mistral_gpt2_32k"] and all("error" not in c for c in d["configs"])
+    # (r6) the third shard proxy runs on the hoisted table shared between 8 ranks: fewer table rows than the contiguous shard computes
+    assert "shared table" in d["configs"][4]["shard"] and d["configs"][4]["table_mb_received"] > 100 and d["configs"][4]["ms_per_step"] < d["configs"][2]["ms_per_step"]
     assert len(d["api_path"]) == 2 and all("error" not in a for a in d["api_path"]) and "error" not in d["train_step"]
     full = json.loads((tmp_path / "bench_side.json").read_text())
     assert abs(full["value"] / d["value"] - 1) < 1e-3 and "by_class" in full["configs"][0]["roofline"]
