@@ -342,6 +342,13 @@ ok = ok and torch.equal(alone.table[:1000], shared.table[:1000]) and torch.equal
 for chunks in (1, 2):
     t_full = predict_sharded(shared.predict(3), big, chunks=chunks); t_one = alone.predict(3)(big)
     ok = ok and torch.equal(t_full[0], t_one[0]) and t_full[1] is None and torch.equal(t_full[2], t_one[2])
+# a rank's share in three pieces, each all-gathered behind its computation (rows of one piece of all ranks are contiguous): the same table
+piecewise = SharedTable(eng, big, src_t, pieces=3)
+ok = ok and piecewise.pieces == 3 and len(piecewise.ranges) == 3 and piecewise.per == 3 * piecewise.piece_rows
+ok = ok and all(lo == min((k * world + rank) * piecewise.piece_rows, 1000) for k, (lo, hi) in enumerate(piecewise.ranges))
+ok = ok and torch.equal(piecewise.table[:1000], alone.table[:1000]) and torch.equal(piecewise.stats[:1000], alone.stats[:1000])
+p_full = predict_sharded(piecewise.predict(3), big); p_one = alone.predict(3)(big)
+ok = ok and torch.equal(p_full[0], p_one[0]) and torch.equal(p_full[2], p_one[2])
 shapes = [tuple(t.shape) for t in full]
 if rank == 0:
     json.dump({{"ok": ok, "shapes": shapes}}, open({out!r}, "w"))

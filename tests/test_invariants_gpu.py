@@ -477,6 +477,13 @@ def test_shared_table_reproduces_the_forward(name, rows):
     lo, hi = part.rows
     assert (lo, hi) == (2 * part.per, min(3 * part.per, n)) and torch.equal(part.table[lo:hi].view(torch.int16), table[lo:hi].view(torch.int16))
     assert part.bytes_received() == 3 * part.per * (cfg["hn_hidden_size"] * 2 + 8)
+    # a rank's share as two pieces (each all-gathered behind its computation in a real group): both ranks' pieces fill the same table
+    pa = SharedTable(eng, ids, src, only_rank=0, world=2, pieces=2)
+    pb = SharedTable(eng, ids, src, only_rank=1, world=2, pieces=2, buffers=(pa.table, pa.stats))
+    cs = pa.piece_rows
+    assert pa.ranges == [(min(0, n), min(cs, n)), (min(2 * cs, n), min(3 * cs, n))] and pb.ranges == [(min(cs, n), min(2 * cs, n)), (min(3 * cs, n), min(4 * cs, n))]
+    assert torch.equal(pa.table[:n].view(torch.int16), table[:n].view(torch.int16)) and torch.equal(pa.stats[:n], stats[:n])
+    assert _eq(pa.predict(lang)(ids), ref)
     # a plain forward behind a table forward is the plain forward again (the handle keeps nothing of the external table)
     assert _eq(_run(eng, ids, src, lang), ref)
     eng.set_option("table_lo", 0)

@@ -357,26 +357,44 @@ class SharedTable:
     Without a process group it is one rank's whole table (the single-GPU proxy and the tests)."""
 
     def __init__(self, engine, surface_forms_all: torch.Tensor, source_embeddings: torch.Tensor, group=None, only_rank: Optional[int] = None, world: Optional[int] = None,
-                 buffers=None):
+                 buffers=None, pieces: Optional[int] = None):
         """only_rank / world: build what THAT rank of `world` ranks computes, without an exchange (the single-GPU proxy of a P-GPU step);
-        buffers = (table, stats) of an earlier complete table of the same matrix: the slice is written into them instead of new ones."""
+        buffers = (table, stats) of an earlier complete table of the same matrix: the slice is written into them instead of new ones.
+        pieces: a rank's share as that many row ranges, each all-gathered (asynchronously, on the backend's stream) as soon as it is computed, so that
+        the exchange of piece k runs under the computation of piece k + 1.  Table row (k * world + r) * cs + i is row i of rank r's piece k: the rows
+        of one piece of all ranks are contiguous, which is what all_gather_into_tensor takes.  Default: one piece per 4 096 rows of a rank's share, at
+        most four — a piece is a GEMM of that many rows, and under 4 096 rows (one round of 256 x 256 tiles at H = 4096) it would leave CUs idle; so
+        the headline's 3 648 rows per rank go in one piece (nothing to overlap with), Llama-3's 16 k in four."""
         live = dist.is_available() and dist.is_initialized()
         self.world = world if world is not None else (dist.get_world_size(group) if live else 1)
         self.rank = only_rank if only_rank is not None else (dist.get_rank(group) if live else 0)
         self.engine = engine
         self.id_slot, self.id_list, self.n_ids = engine.table_plan(surface_forms_all)
-        self.per = -(-max(self.n_ids, 1) // self.world)
+        share = -(-max(self.n_ids, 1) // self.world)
+        exchange = live and self.world > 1 and only_rank is None
+        self.pieces = int(pieces) if pieces else max(1, min(4, share // 4096))
+        self.piece_rows = -(-share // self.pieces)                       # cs: rows of one piece of one rank
+        self.per = self.piece_rows * self.pieces                        # rows of a rank's share (the last ranks' may hold padding)
         self.table, self.stats = buffers if buffers is not None else engine.table_buffers(self.per * self.world)
         if self.table.shape[0] < self.per * self.world or self.stats.shape[0] < self.per * self.world:
             raise ValueError("buffers are smaller than the table")
-        lo, hi = min(self.rank * self.per, self.n_ids), min((self.rank + 1) * self.per, self.n_ids)
-        self.rows = (lo, hi)
-        engine.table_rows(self.id_list, lo, hi - lo, source_embeddings, self.table, self.stats)
-        if live and self.world > 1 and only_rank is None:
-            # (the padding rows behind n_ids travel too and are never read: id_slot only names rows < n_ids)
-            for buf in (self.table.view(torch.uint8), self.stats):          # (bytes: a dtype every backend carries)
-                mine = buf[self.rank * self.per:(self.rank + 1) * self.per].clone()
-                dist.all_gather_into_tensor(buf, mine, group=group)
+        self.ranges = []
+        works = []
+        cs = self.piece_rows
+        for k in range(self.pieces):
+            lo = min((k * self.world + self.rank) * cs, self.n_ids)
+            hi = min(lo + cs, self.n_ids)
+            self.ranges.append((lo, hi))
+            engine.table_rows(self.id_list, lo, hi - lo, source_embeddings, self.table, self.stats)
+            if exchange:
+                # (the padding rows behind n_ids travel too and are never read: id_slot only names rows < n_ids.  Bytes: a dtype every backend carries)
+                for buf in (self.table.view(torch.uint8), self.stats):
+                    region = buf[k * self.world * cs:(k + 1) * self.world * cs]
+                    mine = region[self.rank * cs:(self.rank + 1) * cs].clone()
+                    works.append(dist.all_gather_into_tensor(region, mine, group=group, async_op=True))
+        for w in works:
+            w.wait()          # (device tensors: the current stream waits; the host does not)
+        self.rows = self.ranges[0] if self.pieces == 1 else None
 
     def bytes_received(self) -> int:
         """what a rank receives in the table exchange"""
