@@ -187,3 +187,51 @@ T.main()
     assert "injected failure on rank 1" in res.stderr
     assert elapsed < 300, f"the surviving rank kept the job alive for {elapsed:.0f} s"
     assert not os.path.exists(os.path.join(out, "model.safetensors"))
+
+
+def test_batched_prediction_computes_the_hoisted_table_once_per_job(monkeypatch):
+    """r6 (ABI 8): a vocabulary predicted in several batches (the reference CLI's default, scripts/transfer.py:243-262 with --batch_size)
+    computes input_projection(in_scaler(source_embeddings[id])) ONCE for the distinct ids of the whole vocabulary (SharedTable) and runs
+    every batch on that table, instead of once per batch for the batch's ids: the same predictions BIT FOR BIT as the single forward and as
+    the batches without the table (ZETT_JOB_TABLE=0).  f16 policy and a hypernet with the folded table only: the tiny hypernet (H = 128) and
+    an explicit float32 / bfloat16 run predict as before."""
+    from zett_amd.transfer import Args, predict_vocabulary
+    cfg, _, src_dtype, hist = synth.workload("xlmr_gpt2")
+    w = synth.make_weights(cfg, 8)
+    src = torch.from_numpy(synth.make_source_embeddings(cfg, 8, dtype=src_dtype)).cuda()
+    sfm = torch.from_numpy(synth.make_surface_forms(cfg, 2500, seed=8, hist=hist, n_special=2)).cuda()
+    lang = torch.tensor(3)
+    model = util.hip_model(cfg, w, "f16").eval()
+
+    def same(a, b):
+        return all((x is None and y is None) or torch.equal(x, y) for x, y in zip(a, b))
+
+    monkeypatch.delenv("ZETT_JOB_TABLE", raising=False)
+    predict_vocabulary.last_job_table = None
+    one = predict_vocabulary(model, sfm, src, lang, Args(output="", do_batching=False))
+    assert predict_vocabulary.last_job_table is None                  # (one forward: the class's own call)
+    batched = predict_vocabulary(model, sfm, src, lang, Args(output="", batch_size=700))
+    assert predict_vocabulary.last_job_table is True and same(batched, one)
+    pri = -np.abs(np.random.default_rng(3).standard_normal(2500))
+    sampled = predict_vocabulary(model, sfm, src, lang, Args(output="", batch_size=700, sample_batches=True, n_samples=12, min_k=2), target_priors=pri,
+                                 rng=np.random.default_rng(5))
+    assert predict_vocabulary.last_job_table is True
+    for a, b in zip(sampled, one):          # (rows predicted several times are averaged: equal to rounding of the mean)
+        assert a is None and b is None or torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    monkeypatch.setenv("ZETT_JOB_TABLE", "0")
+    predict_vocabulary.last_job_table = None
+    assert same(predict_vocabulary(model, sfm, src, lang, Args(output="", batch_size=700)), one) and predict_vocabulary.last_job_table is None
+    monkeypatch.delenv("ZETT_JOB_TABLE")
+    model.precision = "bf16"
+    predict_vocabulary.last_job_table = None
+    b1 = predict_vocabulary(model, sfm, src, lang, Args(output="", do_batching=False))
+    assert same(predict_vocabulary(model, sfm, src, lang, Args(output="", batch_size=700)), b1) and predict_vocabulary.last_job_table is None
+    # a hypernet without the folded table (H = 128): the job asks for the table, the library refuses, the batches predict as before
+    tcfg = synth.workload("tiny")[0]
+    tw = synth.make_weights(tcfg, 8)
+    tsrc = torch.from_numpy(synth.make_source_embeddings(tcfg, 8)).cuda()
+    tsfm = torch.from_numpy(synth.make_surface_forms(tcfg, 900, seed=8, n_special=2)).cuda()
+    tiny = util.hip_model(tcfg, tw, "f16").eval()
+    t1 = predict_vocabulary(tiny, tsfm, tsrc, torch.tensor(2), Args(output="", do_batching=False))
+    t2 = predict_vocabulary(tiny, tsfm, tsrc, torch.tensor(2), Args(output="", batch_size=256))
+    assert predict_vocabulary.last_job_table is False and same(t1, t2)

@@ -147,7 +147,22 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
     # shards every batch over its local devices (scripts/transfer.py:90-91, zett/utils.py:26).  All ranks then hold the
     # whole result; they must walk the SAME batches, so the batch order comes from one seed, broadcast from rank 0.
     predict = predict_local
-    sharded = _world_size() > 1 and hasattr(hypernet, "engine")
+    # The hoisted table once per JOB (r6, ABI 8): input_projection(in_scaler(source_embeddings[id])) depends on the id only, and a
+    # vocabulary walked in several batches (the reference's default: --batch_size 16384) references most ids in every batch — the
+    # table of the whole vocabulary's distinct ids is then computed once (1/P of it per rank, all-gathered: zett_amd.sharding.SharedTable)
+    # and every batch's forward runs on it; the same rows bit for bit.  f16 arithmetic (the default policy) and a hypernet with the
+    # folded table (H >= 512) only — anything else predicts as before.  ZETT_JOB_TABLE=0 switches it off; a ONE-batch job on several
+    # ranks shares the table only with ZETT_SHARED_TABLE=1 (there the exchange is not amortised: DESIGN.md section 6).
+    n_rows = int(target_surface_form_matrix.shape[0])
+    n_batches = 1 if not args.do_batching else (int(args.n_samples) if args.sample_batches else -(-n_rows // max(int(args.batch_size), 1)))
+    f16_names = ("f16", "fp16", "float16")
+
+    def want_table(precision):
+        if os.environ.get("ZETT_JOB_TABLE", "1") == "0" or precision not in f16_names or not source_embeddings.is_cuda:
+            return False
+        return n_batches >= 2 or (_world_size() > 1 and os.environ.get("ZETT_SHARED_TABLE") == "1")
+
+    sharded = hasattr(hypernet, "engine") and (_world_size() > 1 or want_table(getattr(hypernet, "precision", None)))
     if _world_size() > 1 and not sharded:              # (a stand-in model without an engine: plain sharding)
         from zett_amd.sharding import predict_sharded
 
@@ -164,7 +179,7 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
         if hypernet.dims.embed_lang and lang_index is None:
             raise ValueError("this hypernetwork embeds a language id: lang_index is required")
         lang = int(lang_index) if hypernet.dims.embed_lang else -1
-        rng = _shared_rng(rng, target_surface_form_matrix.device)
+        rng = _shared_rng(rng, target_surface_form_matrix.device) if _world_size() > 1 else (rng or np.random.default_rng())
         state = {"rng_state": rng.bit_generator.state}
 
         def run_with(precision):
@@ -178,10 +193,20 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
                 return None, _lib.RANGE_WEIGHT
             eng.set_option("range_accumulate", 1)
             eng.range_flags()                           # (clears whatever an earlier call left)
+            shared = None
+            if want_table(precision):
+                from zett_amd.sharding import SharedTable
+                try:
+                    shared = SharedTable(eng, target_surface_form_matrix.to(device=device, dtype=torch.int32).contiguous(), source_embeddings)
+                except ValueError:                      # no folded table for this hypernet / mode (H < 512, LayerNorm fold off): predict as before
+                    shared = None
+            predict_vocabulary.last_job_table = shared is not None      # (what the last call did: tests, logs)
+            fwd = (lambda r: eng.forward_table(r, shared.table, shared.stats, shared.id_slot, lang)) if shared is not None else \
+                  (lambda r: eng.forward(r, source_embeddings, lang))
 
             def predict_rows(rows):
                 r32 = rows.to(device=device, dtype=torch.int32).contiguous()        # what the C ABI takes: prepare() and forward() see one pointer
-                return predict_sharded(lambda r: eng.forward(r, source_embeddings, lang), r32, ready=eng.stream_wait_output, prepare=eng.prepare)
+                return predict_sharded(fwd, r32, ready=eng.stream_wait_output, prepare=None if shared is not None else eng.prepare)
 
             if not args.do_batching:
                 out = predict_rows(target_surface_form_matrix)
@@ -190,7 +215,7 @@ def predict_vocabulary(hypernet, target_surface_form_matrix: torch.Tensor, sourc
                 gen.bit_generator.state = state["rng_state"]        # the same batch order on a repeat
                 out = batched_inference(predict_rows, target_surface_form_matrix, hypernet.config.n_embd, args.batch_size,
                                         args.sample_batches, target_priors, args.min_k, args.n_samples, gen)
-            flags = reduce_flag_word(eng.range_flags(), device)
+            flags = reduce_flag_word(eng.range_flags(), device) if _world_size() > 1 else eng.range_flags()
             eng.set_option("range_accumulate", 0)
             return out, flags
 
