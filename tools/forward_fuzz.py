@@ -66,15 +66,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, nargs=2, default=[0, 200])
     ap.add_argument("--budget-s", type=float, default=1e9)
+    ap.add_argument("--shared-table", action="store_true", help="r6 campaign: every case in the mode that keeps the folded 16-bit table (f16, hidden 512 / 640 / 768 / 1024, LayerNorm "
+                    "fold and 16-bit stream on, no forced tile variant), everything else drawn as usual: the bit identity of zett_forward_table with zett_forward")
     args = ap.parse_args()
     t0 = time.time()
     done, bad, seed = 0, None, args.seeds[0]
     arith_limited = []
     by_precision = {"f32": 0, "f16": 0, "bf16": 0}
+    shared_table = {"checked": 0, "refused": 0}
     for seed in range(*args.seeds):
         if time.time() - t0 > args.budget_s:
             break
         cfg, rows, opts, precision, n_special = case(seed)
+        if args.shared_table:
+            r7 = np.random.default_rng(818000 + seed)
+            h = int(r7.choice([512, 640, 768, 1024]))
+            cfg = dict(cfg, hn_hidden_size=h, hn_num_attention_heads=h // 64)
+            precision = "f16"
+            opts.update(gemm_variant=0, ln_fold=int(r7.choice([1, 2])), residual_lo=int(r7.choice([1, 2])), table_lo=1)
+            opts.pop("gemm4d_min_k", None)
         try:
             w = synth.make_weights(cfg, seed)
             src = synth.make_source_embeddings(cfg, seed)
@@ -116,6 +126,25 @@ def main():
                         if not (np.isfinite(g[keep]).all() and rel_got <= 1.5 * rel_emu):
                             raise AssertionError(f"{name}: rel-L2 {rel_got:.3e} against the fp32 math; the oracle on {precision} operands: {rel_emu:.3e}")
                         arith_limited.append({"seed": seed, "precision": precision, "output": name, "rel": rel_got, "rel_emulated": rel_emu})
+            # r6 (ABI 8): where the handle keeps the folded 16-bit table, the same forward on a table computed in P slices of the whole matrix's
+            # distinct ids (zett_table_plan / zett_table_rows / zett_forward_table) must give the SAME BITS; every other mode must refuse
+            dev = torch.device("cuda:0")
+            ids_t, src_t = torch.from_numpy(ids).to(dev), torch.from_numpy(src).to(dev)
+            lang_t = -1 if lang is None else lang
+            plain = eng.forward(ids_t, src_t, lang_t)
+            try:
+                id_slot, id_list, n_ids = eng.table_plan(ids_t)
+                table, stats = eng.table_buffers(n_ids + 3)
+                parts = int(np.random.default_rng(717000 + seed).choice([1, 2, 5]))
+                for r in range(parts):
+                    lo, hi = (n_ids * r) // parts, (n_ids * (r + 1)) // parts
+                    eng.table_rows(id_list, lo, hi - lo, src_t, table, stats)
+                on_table = eng.forward_table(ids_t, table, stats, id_slot, lang_t)
+                shared_table["checked"] += 1
+                if not all((a is None and b is None) or torch.equal(a, b) for a, b in zip(on_table, plain)):
+                    raise AssertionError("zett_forward_table differs from zett_forward")
+            except ValueError:
+                shared_table["refused"] += 1          # (no folded table in this mode: f32 / bf16, H < 512, fold or stream off, forced tile variant)
             del model, eng
         except Exception as e:
             bad = {"seed": seed, "precision": precision, "rows": rows, "opts": opts, "error": repr(e)[:400],
@@ -123,7 +152,7 @@ def main():
             break
         done += 1
         by_precision[precision] += 1
-    print(json.dumps({"seeds": [args.seeds[0], seed + 1], "cases": done, "by_precision": by_precision, "first_failure": bad, "outside_bare_tolerance_but_within_1.5x_of_the_emulated_arithmetic": arith_limited, "seconds": round(time.time() - t0, 1)}))
+    print(json.dumps({"seeds": [args.seeds[0], seed + 1], "cases": done, "by_precision": by_precision, "shared_table": shared_table, "first_failure": bad, "outside_bare_tolerance_but_within_1.5x_of_the_emulated_arithmetic": arith_limited, "seconds": round(time.time() - t0, 1)}))
     sys.exit(1 if bad else 0)
 
 
