@@ -235,3 +235,50 @@ def test_batched_prediction_computes_the_hoisted_table_once_per_job(monkeypatch)
     t1 = predict_vocabulary(tiny, tsfm, tsrc, torch.tensor(2), Args(output="", do_batching=False))
     t2 = predict_vocabulary(tiny, tsfm, tsrc, torch.tensor(2), Args(output="", batch_size=256))
     assert predict_vocabulary.last_job_table is False and same(t1, t2)
+
+
+def test_two_ranks_share_the_job_table_in_predict_vocabulary(tmp_path):
+    """predict_vocabulary under torchrun (two ranks; on a 1-GPU box both on cuda:0 over gloo): the job's hoisted table is computed half per
+    rank and all-gathered once, every batch is sharded over the ranks and runs on it, and every rank ends with the single forward's
+    predictions bit for bit — also for a ONE-batch job with ZETT_SHARED_TABLE=1.  XLM-R-shaped hypernet, 3 001 rows, f16."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = tmp_path / "job_table_worker.py"
+    worker.write_text(f"""
+import os, sys
+sys.path.insert(0, {repo!r})
+import numpy as np, torch, torch.distributed as dist
+from tests import util
+from zett_amd import synth
+from zett_amd.transfer import Args, init_distributed, predict_vocabulary
+device = init_distributed()
+cfg, _, src_dtype, hist = synth.workload("xlmr_gpt2")
+w = synth.make_weights(cfg, 8)
+src = torch.from_numpy(synth.make_source_embeddings(cfg, 8, dtype=src_dtype)).to(device)
+sfm = torch.from_numpy(synth.make_surface_forms(cfg, 3001, seed=8, hist=hist, n_special=2)).to(device)
+model = util.hip_model(cfg, w, "f16").eval()
+lang = torch.tensor(3)
+eng = model.engine(device)
+one = eng.forward(sfm, src, 3)                      # the plain local forward of the whole matrix
+same = lambda a, b: all((x is None and y is None) or torch.equal(x, y) for x, y in zip(a, b))
+predict_vocabulary.last_job_table = None
+got = predict_vocabulary(model, sfm, src, lang, Args(output="", batch_size=1000))
+assert predict_vocabulary.last_job_table is True and same(got, one), "batched job on the shared table"
+os.environ["ZETT_SHARED_TABLE"] = "1"
+got = predict_vocabulary(model, sfm, src, lang, Args(output="", do_batching=False))
+assert predict_vocabulary.last_job_table is True and same(got, one), "one-batch job on the shared table"
+del os.environ["ZETT_SHARED_TABLE"]
+got = predict_vocabulary(model, sfm, src, lang, Args(output="", do_batching=False))
+assert predict_vocabulary.last_job_table is False and same(got, one), "one-batch job, own tables"
+dist.barrier(); dist.destroy_process_group()
+print("rank", os.environ["RANK"], "ok")
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 2:
+        env["ZETT_ONE_DEVICE_TEST"] = "1"
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29820 + os.getpid() % 100), str(worker)], cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
